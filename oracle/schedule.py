@@ -1,0 +1,100 @@
+"""Noise schedule, timesteps, eta(t) tables and the closed-form DDIM steps (CPU oracle; test
+infrastructure).  All scalars are float64 numpy unless stated; tensors are torch CPU.
+
+Follows (reference file:line):
+  * scheduler construction           modules/inversion/diffusion_inversion.py:100-172,
+                                     modules/models/__init__.py:134 (scaled_linear 0.00085..0.012,
+                                     clip_sample=False, set_alpha_to_one=False, steps_offset=0)
+  * inverse DDIM step ("sameshift")   modules/inverse_schedulers/scheduling_ddim_inverse.py:71-142
+  * eta(t) table                      modules/inversion/eta_inversion.py:52-58, 107-139
+  * backward DDIM-eta step / variance [3P] diffusers 0.21.1 DDIMScheduler.step/_get_variance as
+                                     called at eta_inversion.py:245,310-312 (formulas: SURVEY App. B)
+"""
+import numpy as np
+import torch
+
+NUM_TRAIN = 1000
+
+
+def alphas_cumprod(beta_start=0.00085, beta_end=0.012, n=NUM_TRAIN) -> np.ndarray:
+    """fp32 cumprod exactly as the [3P] scheduler builds it (torch fp32 linspace**2, cumprod)."""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, dim=0).numpy().copy()
+
+
+def timesteps_backward(S: int, steps_offset: int = 0) -> np.ndarray:
+    """'leading' spacing: t_k = (S-1-k) * (1000 // S) + offset  (980..0 for S=50)."""
+    ratio = NUM_TRAIN // S
+    return (np.arange(0, S) * ratio).round()[::-1].astype(np.int64) + steps_offset
+
+
+def timesteps_forward(S: int, steps_offset: int = 0) -> np.ndarray:
+    """scheduling_ddim_inverse.py:51-69: reversed backward timesteps ("sameshift")."""
+    return timesteps_backward(S, steps_offset)[::-1].copy()
+
+
+def alpha_at(ac: np.ndarray, tau: int) -> float:
+    """scheduling_ddim_inverse.py:85-92: clamp at 999; tau<0 -> final_alpha_cumprod = ac[0]."""
+    tau = min(int(tau), NUM_TRAIN - 1)
+    return float(ac[tau]) if tau >= 0 else float(ac[0])
+
+
+def ddim_inverse_coeffs(ac: np.ndarray, t: int, S: int, inv_steps: str = "sameshift"):
+    """Return (a_from, a_to) for the forward (inversion) step evaluated at loop timestep t
+    (scheduling_ddim_inverse.py:127-137)."""
+    d = NUM_TRAIN // S
+    if inv_steps == "sameshift":
+        t_from, t_to = t - d, t
+    elif inv_steps in ("samesame", "shiftshift"):
+        t_from, t_to = t, t + d
+    else:
+        raise Exception(inv_steps)
+    return alpha_at(ac, t_from), alpha_at(ac, t_to)
+
+
+def ddim_step(x: torch.Tensor, eps: torch.Tensor, a_from: float, a_to: float) -> torch.Tensor:
+    """scheduling_ddim_inverse.py:94-98."""
+    x0 = (x - (1 - a_from) ** 0.5 * eps) / a_from ** 0.5
+    return a_to ** 0.5 * x0 + (1 - a_to) ** 0.5 * eps
+
+
+def variance(ac: np.ndarray, t: int, S: int) -> float:
+    """[3P] DDIMScheduler._get_variance(t, t - 1000//S) as called at eta_inversion.py:312."""
+    p = t - NUM_TRAIN // S
+    a_t = float(ac[t])
+    a_p = float(ac[p]) if p >= 0 else float(ac[0])
+    return (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
+
+
+def ddim_eta_step(x, eps, ac, t: int, S: int, eta, noise=None):
+    """[3P] DDIMScheduler.step with (possibly per-pixel tensor) eta and explicit variance noise,
+    as called at eta_inversion.py:245/260/310/369.  `eta` float or tensor broadcastable to x."""
+    p = t - NUM_TRAIN // S
+    a_t = float(ac[t])
+    a_p = float(ac[p]) if p >= 0 else float(ac[0])
+    var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
+    x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
+    std = eta * var ** 0.5
+    direction = (1 - a_p - std ** 2) ** 0.5 * eps
+    prev = a_p ** 0.5 * x0 + direction
+    if noise is not None:
+        prev = prev + std * noise
+    return prev
+
+
+def _eta_pow(p1, p2, p=1):
+    """eta_inversion.py:52-58 without eval(): a*(clip(t,x1,x2)-x1)**p + y1."""
+    (x1, y1), (x2, y2) = p1, p2
+    a = (y2 - y1) / (x2 - x1) ** p
+    return lambda t: a * (np.clip(t, x1, x2) - x1) ** p + y1
+
+
+def eta_table(eta=(0.0, 0.4)) -> np.ndarray:
+    """etas[1000] indexed by raw timestep (eta_inversion.py:121-139)."""
+    if not isinstance(eta, (tuple, list)):
+        eta = (eta, eta)
+    if len(eta) == 3 or isinstance(eta[0], (tuple, list)):
+        etas = _eta_pow(*eta)(np.linspace(0, 1, NUM_TRAIN))
+    else:
+        etas = np.linspace(eta[0], eta[1], NUM_TRAIN)
+    return np.clip(etas, 0, None)

@@ -1,0 +1,443 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/*.npz by RUNNING THE REFERENCE'S OWN CODE.
+
+Run in the build container only (needs /root/reference):
+    cd /tmp && python /root/repo/tests/golden/make_golden.py [--only NAME]
+
+What it does:
+  * installs import stubs for packages the image lacks (diffusers, cv2, torchvision, IPython).
+    The `diffusers.DDIMScheduler` stub restates the published [3P] diffusers==0.21.1 scheduler
+    (closed form) -- diffusers is not vendored in the reference, so that class
+    cannot be imported; everything under `modules/` below IS the reference's own code;
+  * pre-registers a bare `modules` package so the eager `modules/__init__.py` is skipped;
+  * builds a fake pipeline whose `.unet` is the oracle's UNet restatement (toy widths, seeded
+    synthetic weights) exposing 32 `Attention`-named submodules for the reference's hooks;
+  * runs the reference's DDIMInverseScheduler / EtaInversion / ptp / seq_aligner / masactrl /
+    editors on seeded inputs and stores inputs + outputs as small npz fixtures.
+The fixtures travel with the repo; the reference source and this script's import of it do not
+(nothing in tests/ reads /root/reference at test time).
+"""
+import argparse
+import importlib.machinery
+import json
+import os
+import sys
+import types
+import zlib
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parents[2]
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+
+# ----------------------------------------------------------------------------- stubs
+def _mod(name, is_pkg=True, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None, is_package=is_pkg)
+    if is_pkg:
+        m.__path__ = []
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+class DDIMScheduler:
+    """[3P] diffusers 0.21.1 DDIMScheduler, restated (epsilon prediction, leading spacing)."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                 clip_sample=True, set_alpha_to_one=True, steps_offset=0, prediction_type="epsilon", **kw):
+        self.config = _Cfg(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                           beta_schedule=beta_schedule, clip_sample=clip_sample, set_alpha_to_one=set_alpha_to_one,
+                           steps_offset=steps_offset, prediction_type=prediction_type, **kw)
+        assert beta_schedule == "scaled_linear"
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+
+    @classmethod
+    def from_config(cls, config):
+        return cls(**dict(config))
+
+    def set_timesteps(self, n, device=None):
+        self.num_inference_steps = n
+        ratio = self.config.num_train_timesteps // n
+        ts = (np.arange(0, n) * ratio).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
+        self.timesteps = torch.from_numpy(ts)
+
+    def _get_variance(self, timestep, prev_timestep):
+        a_t = self.alphas_cumprod[timestep]
+        a_p = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        return (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
+
+    def step(self, model_output, timestep, sample, eta=0.0, use_clipped_model_output=False, generator=None,
+             variance_noise=None, return_dict=True):
+        prev_timestep = timestep - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[timestep]
+        a_p = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        b_t = 1 - a_t
+        x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
+        variance = self._get_variance(timestep, prev_timestep)
+        std_dev_t = eta * variance ** 0.5
+        direction = (1 - a_p - std_dev_t ** 2) ** 0.5 * model_output
+        prev = a_p ** 0.5 * x0 + direction
+        if eta > 0:
+            if variance_noise is None:
+                variance_noise = torch.randn(model_output.shape, generator=generator, dtype=model_output.dtype)
+            prev = prev + std_dev_t * variance_noise
+        return types.SimpleNamespace(prev_sample=prev, pred_original_sample=x0)
+
+
+class _Dummy:
+    def __init__(self, *a, **k):
+        pass
+
+
+def install_stubs():
+    _mod("diffusers", DDIMScheduler=DDIMScheduler, DDPMScheduler=_Dummy, DPMSolverMultistepScheduler=_Dummy,
+         StableDiffusionPipeline=_Dummy)
+    _mod("diffusers.schedulers")
+    _mod("diffusers.schedulers.scheduling_ddim", False, DDIMSchedulerOutput=_Dummy)
+    _mod("diffusers.pipelines")
+    _mod("diffusers.pipelines.stable_diffusion")
+    _mod("diffusers.pipelines.stable_diffusion.pipeline_stable_diffusion", False, StableDiffusionPipeline=_Dummy)
+    _mod("diffusers.models")
+    _mod("diffusers.models.unet_2d_condition", False, UNet2DConditionOutput=_Dummy, UNet2DConditionModel=_Dummy)
+    _mod("cv2", False)
+    tv = _mod("torchvision")
+    tvu = _mod("torchvision.utils", False, save_image=lambda *a, **k: None)
+    tv.utils = tvu
+    ip = _mod("IPython")
+    ipd = _mod("IPython.display", False, display=lambda *a, **k: None)
+    ip.display = ipd
+    pkg = types.ModuleType("modules")
+    pkg.__path__ = [str(REF / "modules")]
+    pkg.__spec__ = importlib.machinery.ModuleSpec("modules", None, is_package=True)
+    sys.modules["modules"] = pkg
+    sys.path.insert(0, str(REF))
+    import modules.utils.ptp_utils  # noqa: F401  (must precede modules.utils.ptp: circular import in the reference)
+
+
+# ----------------------------------------------------------------------------- fake pipeline
+class FakeTokenizer:
+    """Word-level stand-in (same rule as oracle.ptp.WordTokenizer, restated so the fixtures do not
+    depend on the oracle): id = 1000 + crc32(word) % 40000, BOS 49406, EOS/pad 49407."""
+    model_max_length = 77
+
+    def __init__(self):
+        self.rev = {49406: "<|startoftext|>", 49407: "<|endoftext|>"}
+
+    def encode(self, text):
+        ids = [49406]
+        for w in text.split(" "):
+            if w == "":
+                continue
+            i = 1000 + zlib.crc32(w.encode()) % 40000
+            self.rev[i] = w
+            ids.append(i)
+        return ids + [49407]
+
+    def decode(self, ids):
+        return " ".join(self.rev[int(i)] for i in ids)
+
+    def __call__(self, texts, padding=None, max_length=77, truncation=True, return_tensors="pt"):
+        rows = []
+        for t in texts:
+            ids = self.encode(t)[:max_length]
+            rows.append(ids + [49407] * (max_length - len(ids)))
+        return types.SimpleNamespace(input_ids=torch.tensor(rows, dtype=torch.int64))
+
+
+def text_embed(ids: torch.Tensor, dim=768):
+    """Deterministic stand-in text encoder: per-token-id seeded normal + per-position seeded normal."""
+    out = torch.zeros(ids.shape[0], ids.shape[1], dim)
+    for b in range(ids.shape[0]):
+        for p in range(ids.shape[1]):
+            g = torch.Generator().manual_seed(int(ids[b, p]))
+            gp = torch.Generator().manual_seed(900000 + p)
+            out[b, p] = torch.randn(dim, generator=g) + 0.3 * torch.randn(dim, generator=gp)
+    return out
+
+
+class FakeVAE:
+    dtype = torch.float32
+
+    def encode(self, image):     # "image" is already a latent / 0.18215 (VAE is outside the hot loop)
+        return {"latent_dist": types.SimpleNamespace(mean=image)}
+
+    def decode(self, z):
+        return {"sample": z}
+
+
+def make_pipe(unet):
+    pipe = types.SimpleNamespace()
+    pipe.device = torch.device("cpu")
+    pipe.unet = unet
+    pipe.vae = FakeVAE()
+    pipe.tokenizer = FakeTokenizer()
+    pipe.text_encoder = lambda ids: (text_embed(ids),)
+    pipe.scheduler = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                   clip_sample=False, set_alpha_to_one=False)
+    return pipe
+
+
+def toy_unet(seed=0):
+    from oracle.unet import build_unet
+    return build_unet(seed, block_out_channels=(32, 64, 128, 128))
+
+
+def save(name, **arrs):
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = v
+    np.savez_compressed(OUT / f"{name}.npz", **conv)
+    print(f"wrote {name}.npz: " + ", ".join(f"{k}{list(np.shape(v))}" for k, v in conv.items()))
+
+
+# ----------------------------------------------------------------------------- generators
+def gen_schedule():
+    from modules.inversion.eta_inversion import EtaInversion
+    out = {}
+    for S in (10, 50, 100):
+        inv = EtaInversion(make_pipe(toy_unet()), scheduler="ddim", num_inference_steps=S)
+        out[f"t_bwd_{S}"] = inv.get_timesteps_backward().numpy()
+        out[f"t_fwd_{S}"] = torch.stack(list(inv.get_timesteps_forward())).numpy()
+        out[f"var_{S}"] = np.array([float(inv.scheduler_bwd._get_variance(int(t), int(t) - 1000 // S))
+                                    for t in inv.get_timesteps_backward()])
+    out["alphas_cumprod"] = inv.scheduler_bwd.alphas_cumprod.numpy()
+    out["final_alpha_cumprod"] = np.array(float(inv.scheduler_bwd.final_alpha_cumprod))
+    for key, eta in {"lin": (0.0, 0.4), "paper": [[0.6, 0], [1, 0.7]], "paper2": [[0.3, 0], [1, 0.2]],
+                     "pow3": [[0.2, 0.1], [0.9, 0.8], 3], "const": 0.25}.items():
+        out[f"etas_{key}"] = EtaInversion(make_pipe(toy_unet()), eta=eta).etas
+    save("schedule", **out)
+
+
+def gen_ddim_inverse():
+    from modules.inverse_schedulers import DDIMInverseScheduler
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 4, 8, 8, generator=g, dtype=torch.float64)
+    e = torch.randn(1, 4, 8, 8, generator=g, dtype=torch.float64)
+    out = {"x": x, "eps": e}
+    for S in (10, 50):
+        for mode in ("sameshift", "samesame"):
+            sch = DDIMInverseScheduler.from_scheduler(make_pipe(None).scheduler, inv_steps=mode)
+            sch.set_timesteps(S)
+            ts = [int(t) for t in sch.timesteps]
+            for t in (ts[0], ts[1], ts[len(ts) // 2], ts[-1]):
+                out[f"S{S}_{mode}_t{t}"] = sch.step(e, torch.tensor(t), x).prev_sample
+    save("ddim_inverse", **out)
+
+
+class _ConstUnet:
+    """unet stand-in returning a fixed tensor (for eta-step known answers)."""
+    dtype = torch.float32
+
+    def __init__(self, out):
+        self.out = out
+
+    def __call__(self, x, t, encoder_hidden_states=None):
+        return {"sample": self.out}
+
+
+def gen_eta_step():
+    from modules.inversion.eta_inversion import EtaInversion
+    from tests.golden.recipes import ETA_CASES, eta_case_inputs, crc
+    out = {}
+    for name, (eta, t, fp16, use_mask) in ETA_CASES.items():
+        inp = eta_case_inputs(name)
+        latent, unet_out, src_prev, mask_map, noise = (inp[k] for k in ("latent", "unet_out", "src_prev", "mask_map", "noise"))
+        dt = latent.dtype
+        cu = _ConstUnet(unet_out)
+        cu.dtype = dt
+        pipe = make_pipe(cu)
+        inv = EtaInversion(pipe, scheduler="ddim", num_inference_steps=50, eta=eta, use_mask=use_mask)
+        inv.attn_maps_forward = {"mean": [mask_map, mask_map]}
+        gen = torch.Generator().manual_seed(5)          # draws exactly `noise` (eta_inversion.py:156)
+        ctx = torch.zeros(4, 77, 8, dtype=dt)
+        with inv.use_controller(None):
+            new, eps = inv.predict_step_backward(latent.clone(), torch.tensor(t), ctx, source_latent_prev=src_prev,
+                                                 generator=gen, mask=None, edit_word_idx=(0, 0))
+            res = inv.get_eta_variance_noise(src_prev, latent[:1], torch.tensor(t), eps[:1],
+                                             torch.Generator().manual_seed(5))
+        losses = torch.square(noise - inv.compute_optimal_variance_noise(src_prev, latent[:1], torch.tensor(t),
+                                                                       inv.etas[t], eps[:1])).reshape(10, -1).mean(1)
+        best = int(torch.argmin(losses).item())
+        assert torch.equal(res["variance_noise"], noise[best]), (name, best)
+        out.update({f"{name}/new": new.float(), f"{name}/best": np.array(best), f"{name}/losses": losses.float(),
+                    f"{name}/eta": np.array(float(inv.etas[t])),
+                    f"{name}/crc": np.array([crc(latent), crc(unet_out), crc(src_prev), crc(mask_map), crc(noise)])})
+    save("eta_step", **out)
+
+
+PROMPT_PAIRS = [
+    ("a cat sitting next to a mirror", "a tiger sitting next to a mirror"),
+    ("a photo of a house on a hill", "a photo of a wooden house on a snowy hill"),
+    ("a dog", "a very fluffy dog running"),
+    ("two birds sitting on a branch", "two origami birds sitting on a branch"),
+    ("a bowl of soup", "a bowl of soup"),
+]
+
+
+def gen_ptp_tables():
+    from modules.utils import seq_aligner, ptp_utils, ptp
+    tok = FakeTokenizer()
+    out = {}
+    for i, (a, b) in enumerate(PROMPT_PAIRS):
+        mapper, alphas = seq_aligner.get_refinement_mapper([a, b], tok)
+        out[f"p{i}/mapper"], out[f"p{i}/alphas"] = mapper, alphas
+        out[f"p{i}/ids_a"], out[f"p{i}/ids_b"] = np.array(tok.encode(a)), np.array(tok.encode(b))
+        for S in (10, 50):
+            out[f"p{i}/ctw_{S}"] = ptp_utils.get_time_words_attention_alpha([a, b], S, {"default_": 0.4}, tok)
+        out[f"p{i}/ctw_word"] = ptp_utils.get_time_words_attention_alpha(
+            [a, b], 50, {"default_": 0.8, b.split(" ")[1]: (0.1, 0.5)}, tok)
+        w = b.split(" ")[1]
+        pipe = types.SimpleNamespace(tokenizer=tok)
+        out[f"p{i}/eq"] = ptp.get_equalizer(pipe, b, (w,), (2,))
+        out[f"p{i}/inds_w1"] = ptp_utils.get_word_inds(b, w, tok)
+        out[f"p{i}/inds_i2"] = ptp_utils.get_word_inds(b, 2, tok) if len(b.split(" ")) > 2 else np.array([])
+        if len(a.split(" ")) == len(b.split(" ")):
+            out[f"p{i}/replace"] = seq_aligner.get_replacement_mapper([a, b], tok)
+    save("ptp_tables", **out)
+    (OUT / "prompt_pairs.json").write_text(json.dumps(PROMPT_PAIRS, indent=1))
+
+
+PTP_VARIANTS = {
+    "refine": dict(is_replace_controller=False, cross_replace_steps={"default_": .4}, self_replace_steps=.6,
+                   blend_words=(("cat",), ("tiger",)), equilizer_params={"words": ("tiger",), "values": (2,)}),
+    "replace": dict(is_replace_controller=True, cross_replace_steps={"default_": .8}, self_replace_steps=.4,
+                    blend_words=None, equilizer_params=None),
+}
+
+
+def gen_ptp_algebra():
+    """Drive the reference controllers (Refine+Reweight+LocalBlend; Replace) and AttentionStore with the seeded
+    random probabilities of tests/golden/recipes.py through 32 layers x a few steps, in the real layer order."""
+    from modules.utils import ptp
+    from modules.editing.ptp_editor import PromptToPromptControllerBase
+    from tests.golden.recipes import drive_edit_controller, drive_store_controller
+    S = 10
+    src, tgt = PROMPT_PAIRS[0]
+    pipe = make_pipe(types.SimpleNamespace(dtype=torch.float32))
+    pipe.scheduler.set_timesteps(S)
+    out = {}
+    for variant, cfg in PTP_VARIANTS.items():
+        ctrl = ptp.make_controller(pipe, [src, tgt], **cfg)
+        ctrl.num_att_layers = 32
+        for k, v in drive_edit_controller(ctrl).items():
+            out[f"{variant}/{k}"] = v
+        out[f"{variant}/cross_alpha"] = ctrl.cross_replace_alpha
+    store_ctrl = PromptToPromptControllerBase(pipe, ptp.AttentionStore(max_size=16))
+    store_ctrl.controller.num_att_layers = 32
+    out["store/maps"] = drive_store_controller(
+        store_ctrl.controller,
+        lambda: torch.stack([store_ctrl.get_attention_map(src, w, res=16, from_where=["up", "down"], resize=64)
+                             for w in src.split(" ")]))
+    save("ptp_algebra", **out)
+
+
+def gen_masactrl():
+    from modules.utils.masactrl import MutualSelfAttentionControl
+    ed = MutualSelfAttentionControl(4, 10)
+    ed.num_att_layers = 32
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    heads, n, d = 8, 16, 8
+    for step, layer in ((0, 0), (4, 19), (4, 20), (4, 21), (5, 31), (49, 26), (50, 26)):
+        ed.cur_step, ed.cur_att_layer = step, layer
+        is_cross = layer % 2 == 1
+        q = torch.randn(4 * heads, n, d, generator=g)
+        k = torch.randn(4 * heads, 77 if is_cross else n, d, generator=g)
+        v = torch.randn(4 * heads, 77 if is_cross else n, d, generator=g)
+        sim = torch.einsum("bid,bjd->bij", q, k) * d ** -0.5
+        attn = sim.softmax(-1)
+        o = ed(q, k, v, sim, attn, is_cross, "up", heads, scale=d ** -0.5)
+        out.update({f"s{step}_l{layer}/q": q, f"s{step}_l{layer}/k": k, f"s{step}_l{layer}/v": v, f"s{step}_l{layer}/out": o})
+    save("masactrl", **out)
+
+
+def gen_e2e(S=3):
+    """Full reference loop (EtaInversion + editors) on the toy-width oracle UNet at the reference's hard-coded
+    64x64 latent size.  Pins the oracle's loop restatement end to end."""
+    from modules.inversion.eta_inversion import EtaInversion
+    from modules.editing.simple_editor import SimpleEditor
+    from modules.editing.ptp_editor import PromptToPromptEditor
+    from modules.editing.masactrl_editor import MasactrlEditor
+    import modules.utils.masactrl as masa_mod
+    src, tgt = PROMPT_PAIRS[0]
+    unet = toy_unet(0)
+    g = torch.Generator().manual_seed(2024)
+    z0 = 0.8 * torch.randn(1, 4, 64, 64, generator=g)
+    out = {"z0": z0}
+    ptp_cfg = dict(is_replace_controller=False, prompts=[src, tgt], cross_replace_steps={"default_": .4},
+                   self_replace_steps=0.6, blend_words=(("cat",), ("tiger",)),
+                   equilizer_params={"words": ("tiger",), "values": (2,)})
+    for name, eta, S_ in (("simple", (0.0, 0.4), S), ("ptp", [[0.6, 0], [1, 0.7]], 5), ("masactrl", (0.0, 0.4), 6)):
+        pipe = make_pipe(unet)
+        inv = EtaInversion(pipe, scheduler="ddim", num_inference_steps=S_, eta=eta, noise_sample_count=10, seed=0)
+        if name == "simple":
+            ed = SimpleEditor(inv)
+            cfg = None
+        elif name == "ptp":
+            ed = PromptToPromptEditor(inv)
+            cfg = {**ptp_cfg}
+        else:
+            ed = MasactrlEditor(inv, step=2, layer=10)
+            cfg = None
+            # MasaCtrl hard-codes total_steps=50; with S=6 steps 2..5 are active (masactrl.py:20,36)
+        trace = []
+        orig = inv.predict_step_backward
+
+        def wrapped(*a, _orig=orig, **k):
+            new, eps = _orig(*a, **k)
+            trace.append((new.clone(), eps.clone()))
+            return new, eps
+        inv.predict_step_backward = wrapped
+        captured = {}
+        orig_inv = inv.invert
+
+        def wrapped_inv(*a, _o=orig_inv, **k):
+            r = _o(*a, **k)
+            captured["inv"] = r
+            return r
+        inv.invert = wrapped_inv
+        res = ed.edit(z0 / 0.18215, src, tgt, cfg=cfg, inv_cfg=dict(edit_word_idx=(1, 1)))
+        invr = captured["inv"]
+        out[f"{name}/S"] = np.array(S_)
+        out[f"{name}/ctx_src"] = invr["context"]
+        out[f"{name}/ctx_tgt"] = inv.create_context(tgt)
+        out[f"{name}/inv_latents"] = torch.cat(invr["latents"])
+        out[f"{name}/maps_mean"] = torch.stack(inv.attn_maps_forward["mean"])
+        out[f"{name}/latent_inv"] = res["latent_inv"]
+        out[f"{name}/latent"] = res["latent"]
+        out[f"{name}/bwd_latents"] = torch.stack([t[0] for t in trace])
+        out[f"{name}/bwd_eps"] = torch.stack([t[1] for t in trace])
+    out["noise_crc"] = np.array(zlib.crc32(torch.randn((10, 1, 4, 64, 64), generator=torch.Generator().manual_seed(0)).numpy().tobytes()))
+    save("e2e_toy", **out)
+
+
+GENS = {"schedule": gen_schedule, "ddim_inverse": gen_ddim_inverse, "eta_step": gen_eta_step,
+        "ptp_tables": gen_ptp_tables, "ptp_algebra": gen_ptp_algebra, "masactrl": gen_masactrl, "e2e": gen_e2e}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    assert Path.cwd() != REPO, "run from a scratch cwd (reference has an import-time `rm -rf result/...`)"
+    install_stubs()
+    torch.set_grad_enabled(False)
+    for k, f in GENS.items():
+        if a.only in (None, k):
+            print("==", k)
+            f()

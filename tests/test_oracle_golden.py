@@ -1,0 +1,185 @@
+"""CPU oracle vs the golden vectors captured from the reference's own code (tests/golden/make_golden.py)."""
+import json
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import schedule as sch
+from oracle import ptp as optp
+from oracle import loop as oloop
+from tests.golden import recipes
+
+GOLDEN_DIR = recipes.__file__.rsplit("/", 1)[0]
+
+
+def test_schedule_tables(golden):
+    g = golden("schedule")
+    ac = sch.alphas_cumprod()
+    np.testing.assert_array_equal(ac, g["alphas_cumprod"])          # bit-exact fp32 table
+    assert float(g["final_alpha_cumprod"]) == float(ac[0])
+    for S in (10, 50, 100):
+        np.testing.assert_array_equal(sch.timesteps_backward(S), g[f"t_bwd_{S}"])
+        np.testing.assert_array_equal(sch.timesteps_forward(S), g[f"t_fwd_{S}"])
+        var = np.array([sch.variance(ac, int(t), S) for t in sch.timesteps_backward(S)])
+        np.testing.assert_allclose(var, g[f"var_{S}"], rtol=5e-5, atol=1e-9)  # ref: fp32 scalars
+    for key, eta in {"lin": (0.0, 0.4), "paper": [[0.6, 0], [1, 0.7]], "paper2": [[0.3, 0], [1, 0.2]],
+                     "pow3": [[0.2, 0.1], [0.9, 0.8], 3], "const": 0.25}.items():
+        np.testing.assert_allclose(sch.eta_table(eta), g[f"etas_{key}"], rtol=1e-12, atol=1e-15)
+
+
+def test_ddim_inverse_known_answers(golden):
+    g = golden("ddim_inverse")
+    ac = sch.alphas_cumprod()
+    x, e = torch.from_numpy(g["x"]), torch.from_numpy(g["eps"])
+    n = 0
+    for key in g.files:
+        if not key.startswith("S"):
+            continue
+        S, mode, t = key.split("_")
+        S, t = int(S[1:]), int(t[1:])
+        a_from, a_to = sch.ddim_inverse_coeffs(ac, t, S, mode)
+        out = sch.ddim_step(x, e, a_from, a_to)
+        # reference scalars are fp32 0-dim tensors, oracle scalars float64: agree to fp32 rounding
+        np.testing.assert_allclose(out.numpy(), g[key], rtol=5e-6, atol=5e-6)
+        n += 1
+    assert n == 16
+
+
+@pytest.mark.parametrize("name", list(recipes.ETA_CASES))
+def test_eta_step_known_answers(golden, name):
+    g = golden("eta_step")
+    eta_spec, t, fp16, use_mask = recipes.ETA_CASES[name]
+    inp = recipes.eta_case_inputs(name)
+    crcs = [recipes.crc(inp[k]) for k in ("latent", "unet_out", "src_prev", "mask_map", "noise")]
+    assert crcs == list(g[f"{name}/crc"]), "seeded input recipe drifted (torch RNG changed?)"
+
+    class U:
+        def __call__(self, x, t, encoder_hidden_states=None):
+            return {"sample": inp["unet_out"]}
+
+        def set_ctrl(self, c):
+            pass
+    o = oloop.EtaInversionOracle(U(), S=50, eta=eta_spec, use_mask=use_mask)
+    assert float(o.etas[t]) == float(g[f"{name}/eta"])
+    ctx = torch.zeros(4, 77, 8, dtype=inp["latent"].dtype)
+    new, eps, best, losses = o.step_backward(inp["latent"].clone(), t, ctx, inp["src_prev"], inp["noise"],
+                                             inp["mask_map"], None)
+    if fp16:
+        # reference evaluates in fp16 (overflowing losses -> argmin 0, SURVEY E-7); oracle mirrors dtype
+        assert int(g[f"{name}/best"]) == best
+        np.testing.assert_allclose(new.float().numpy(), g[f"{name}/new"], rtol=2e-2, atol=5e-2)
+        return
+    gl = g[f"{name}/losses"]
+    if np.isfinite(gl).all():
+        np.testing.assert_allclose(losses.numpy(), gl, rtol=1e-4)
+    assert best == int(g[f"{name}/best"])
+    np.testing.assert_allclose(new.numpy(), g[f"{name}/new"], rtol=1e-5, atol=2e-5)
+
+
+def test_ptp_tables(golden):
+    g = golden("ptp_tables")
+    pairs = json.load(open(f"{GOLDEN_DIR}/prompt_pairs.json"))
+    tok = optp.WordTokenizer()
+    for i, (a, b) in enumerate(pairs):
+        np.testing.assert_array_equal(np.array(tok.encode(a)), g[f"p{i}/ids_a"])
+        mapper, alphas = optp.refinement_mapper(a, b, tok)
+        np.testing.assert_array_equal(mapper, g[f"p{i}/mapper"][0])
+        np.testing.assert_array_equal(alphas, g[f"p{i}/alphas"][0])
+        for S in (10, 50):
+            np.testing.assert_array_equal(optp.time_words_alpha([a, b], S, {"default_": 0.4}, tok),
+                                          g[f"p{i}/ctw_{S}"].reshape(S + 1, 1, 77))
+        w = b.split(" ")[1]
+        np.testing.assert_array_equal(
+            optp.time_words_alpha([a, b], 50, {"default_": 0.8, w: (0.1, 0.5)}, tok), g[f"p{i}/ctw_word"].reshape(51, 1, 77))
+        np.testing.assert_array_equal(optp.equalizer(b, (w,), (2,), tok), g[f"p{i}/eq"][0])
+        np.testing.assert_array_equal(optp.word_inds(b, w, tok), g[f"p{i}/inds_w1"])
+        if len(b.split(" ")) > 2:
+            np.testing.assert_array_equal(optp.word_inds(b, 2, tok), g[f"p{i}/inds_i2"])
+        if f"p{i}/replace" in g.files:
+            np.testing.assert_array_equal(optp.replacement_mapper(a, b, tok), g[f"p{i}/replace"][0])
+
+
+PTP_VARIANTS = {
+    "refine": dict(is_replace_controller=False, cross_replace_steps={"default_": .4}, self_replace_steps=.6,
+                   blend_words=(("cat",), ("tiger",)), equilizer_params={"words": ("tiger",), "values": (2,)}),
+    "replace": dict(is_replace_controller=True, cross_replace_steps={"default_": .8}, self_replace_steps=.4,
+                    blend_words=None, equilizer_params=None),
+}
+
+
+@pytest.mark.parametrize("variant", list(PTP_VARIANTS))
+def test_ptp_controller_algebra(golden, variant):
+    g = golden("ptp_algebra")
+    src, tgt = json.load(open(f"{GOLDEN_DIR}/prompt_pairs.json"))[0]
+    ctrl = optp.make_edit_controller(src, tgt, 10, optp.WordTokenizer(), **PTP_VARIANTS[variant])
+    np.testing.assert_array_equal(ctrl.cross_alpha.numpy().reshape(11, 77), g[f"{variant}/cross_alpha"].reshape(11, 77))
+    out = recipes.drive_edit_controller(ctrl)
+    keys = [k for k in g.files if k.startswith(variant + "/") and not k.endswith("cross_alpha")]
+    assert len(keys) == len(out)
+    for k in keys:
+        np.testing.assert_allclose(out[k.split("/", 1)[1]].numpy(), g[k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_attention_store_maps(golden):
+    g = golden("ptp_algebra")
+    src, _ = json.load(open(f"{GOLDEN_DIR}/prompt_pairs.json"))[0]
+    store = optp.AttentionStore()
+    words = src.split(" ")
+    maps = recipes.drive_store_controller(
+        store, lambda: torch.stack([optp.attention_map(store, words.index(w) + 1, res=16, resize=64) for w in words]))
+    np.testing.assert_allclose(maps.numpy(), g["store/maps"], rtol=1e-5, atol=1e-6)
+
+
+def test_masactrl(golden):
+    g = golden("masactrl")
+    cases = sorted({k.split("/")[0] for k in g.files})
+    assert len(cases) == 7
+    for c in cases:
+        step, layer = int(c.split("_")[0][1:]), int(c.split("_")[1][1:])
+        m = oloop.MasaCtrl(4, 10)
+        m.cur_step, m.cur_att_layer = step, layer
+        q, k, v = (torch.from_numpy(g[f"{c}/{n}"]) for n in "qkv")
+        out = m(layer % 2 == 1, layer, "up", q, k, v, q.shape[-1] ** -0.5, 8)
+        np.testing.assert_allclose(out.numpy(), g[f"{c}/out"], rtol=1e-5, atol=1e-6, err_msg=c)
+
+
+# ----------------------------------------------------------------------------- end-to-end loop replay
+@pytest.fixture(scope="module")
+def toy_unet():
+    from oracle.unet import build_unet
+    return build_unet(0, block_out_channels=(32, 64, 128, 128))
+
+
+E2E = {"simple": dict(eta=(0.0, 0.4)), "ptp": dict(eta=[[0.6, 0], [1, 0.7]]), "masactrl": dict(eta=(0.0, 0.4))}
+
+
+@pytest.mark.parametrize("name", ["ptp", pytest.param("simple", marks=pytest.mark.slow),
+                                  pytest.param("masactrl", marks=pytest.mark.slow)])
+def test_e2e_loop_vs_reference(golden, toy_unet, name):
+    """The reference's EtaInversion + editor ran on this same toy-width UNet at its hard-coded 64x64 latent
+    (make_golden.gen_e2e); the oracle's loop restatement must land on the same latents."""
+    g = golden("e2e_toy")
+    S = int(g[f"{name}/S"])
+    src, tgt = json.load(open(f"{GOLDEN_DIR}/prompt_pairs.json"))[0]
+    noise = oloop.noise_table(S, 10, 64, seed=0)
+    assert zlib.crc32(noise[0].numpy().tobytes()) == int(g["noise_crc"])
+    z0 = torch.from_numpy(g["z0"])
+    ctx_s, ctx_t = torch.from_numpy(g[f"{name}/ctx_src"]), torch.from_numpy(g[f"{name}/ctx_tgt"])
+    with torch.no_grad():
+        o = oloop.EtaInversionOracle(toy_unet, S=S, **E2E[name])
+        inv = o.invert(z0, ctx_s, src)
+        np.testing.assert_allclose(torch.cat(inv["latents"]).numpy(), g[f"{name}/inv_latents"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(torch.stack(inv["attn_maps_mean"]).numpy(), g[f"{name}/maps_mean"], rtol=1e-3, atol=1e-4)
+        controller = masa = None
+        if name == "ptp":
+            controller = optp.make_edit_controller(src, tgt, S, optp.WordTokenizer(), **PTP_VARIANTS["refine"])
+        elif name == "masactrl":
+            masa = oloop.MasaCtrl(2, 10)
+        trace = []
+        z = o.sample(inv, ctx_s, ctx_t, noise, edit_word_idx=(1, 1), controller=controller, masactrl=masa, trace=trace)
+    np.testing.assert_allclose(torch.stack([t["eps"] for t in trace]).numpy(), g[f"{name}/bwd_eps"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(torch.stack([t["latent"] for t in trace]).numpy(), g[f"{name}/bwd_latents"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(z[:1].numpy(), g[f"{name}/latent_inv"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(z[1:].numpy(), g[f"{name}/latent"], rtol=1e-3, atol=2e-4)
