@@ -1,0 +1,504 @@
+// Attention kernels for the SD1.x transformer blocks (heads = 8, head_dim 40 / 80 / 160).
+//
+// self_attn_kernel : flash-style softmax(Q K^T * scale) V over N = 64 .. 9216 tokens.  The N x N probability
+//   matrix the reference materialises for its hooks (ptp_utils.py:238-253: 2.9 GB of traffic per sample
+//   forward) never exists; the prompt-to-prompt self-replace (ptp.py:194-199: target probs := source probs,
+//   i.e. softmax(Q_s K_s^T) V_t) and MasaCtrl (masactrl.py:56-72: K, V of the source sample) are expressed as
+//   per-row batch-index remaps of the Q/K and V operands.
+// cross_attn_kernel: 77 text keys (padded to 96), single pass; fuses the prompt-to-prompt cross edit
+//   (Refine ptp.py:245-251, Reweight :261-268, time blend :212-214) and the AttentionStore accumulation of
+//   the (L/4)^2-token layers (ptp.py:150-167) into the softmax epilogue.
+//
+// MFMA orientation (both kernels): S^T = K Q^T and O^T = V^T P^T with v_mfma_f32_16x16x32, so the QUERY
+// index lives on lane&15 for scores, probabilities and output alike: row max / sum are 2 shuffles, the
+// online-softmax rescale is lane-local, and the S^T accumulator registers are already the B operand of the
+// PV product (keys of a 32-key step are taken in the order the accumulators hold them; V^T is read in that
+// same order), so P never touches LDS.  Output: 4 consecutive head channels per lane -> 8-byte stores.
+#include "common.h"
+#include "kernels.h"
+
+namespace etainv {
+
+template <typename T> struct Frag;
+template <> struct Frag<f16> {
+  typedef f16x8 v8;
+  typedef f16x4 v4;
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Frag<bf16> {
+  typedef bf16x8 v8;
+  typedef bf16x4 v4;
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+constexpr float NEG_BIG = -1.0e30f;
+
+// batch-row roles for the backward layout [u_s x B, u_t x B, c_s x B, c_t x B]
+__device__ __forceinline__ void row_roles(int b, int n_img, int& half, int& role, int& img) {
+  half = b / (2 * n_img);
+  role = (b / n_img) & 1;
+  img = b % n_img;
+}
+
+// ------------------------------------------------------------------------------------------------ self
+// mode: 0 plain; 1 ptp self-replace (cond target rows take Q,K of their source row); 2 masactrl (target rows
+// of both halves take K,V of their source row)
+template <typename T, int D, int QT>
+__global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads,
+                                                        float scale_log2, int mode, int n_img) {
+  typedef typename Frag<T>::v8 v8;
+  typedef typename Frag<T>::v4 v4;
+  constexpr int DP = (D + 31) / 32 * 32;
+  constexpr int KS = DP / 32;
+  constexpr int DT = (D + 15) / 16;
+  constexpr int NCH = D / 8;
+  constexpr int KV = 64;
+  constexpr int KSTR = DP + 8;
+  constexpr int VSTR = KV + 8;
+  constexpr int NLD = (KV * NCH + 255) / 256;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sK = reinterpret_cast<T*>(smem);      // [KV][KSTR]
+  T* sVt = sK + KV * KSTR;                 // [DT*16][VSTR]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, q4 = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int C = heads * D, C3 = 3 * C;
+  int bq = b, bk = b, bv = b;
+  if (mode != 0) {
+    int half, role, img;
+    row_roles(b, n_img, half, role, img);
+    if (mode == 1 && half == 1 && role == 1) { bq = b - n_img; bk = b - n_img; }
+    if (mode == 2 && role == 1) { bk = b - n_img; bv = b - n_img; }
+  }
+  const int q_base = blockIdx.x * (64 * QT) + wid * (16 * QT);
+
+  // zero the K padding columns once (Q pad is zero too, but 0 * garbage could be NaN)
+  if (DP > D) {
+    constexpr int PCH = (DP - D) / 8;
+    for (int idx = tid; idx < KV * PCH; idx += 256) {
+      int key = idx / PCH, ch = idx % PCH;
+      *reinterpret_cast<u32x4*>(sK + key * KSTR + D + ch * 8) = (u32x4){0u, 0u, 0u, 0u};
+    }
+  }
+
+  // Q fragments (B operand of S^T): lane holds Q[query fr][d = ks*32 + q4*8 .. +7]
+  v8 qf[QT][KS];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    int query = q_base + qt * 16 + fr;
+    query = query < N ? query : N - 1;
+    const T* qp = qkv + ((int64_t)bq * N + query) * C3 + h * D;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = ks * 32 + q4 * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (d0 < D) v = *reinterpret_cast<const u32x4*>(qp + d0);
+      qf[qt][ks] = *reinterpret_cast<v8*>(&v);
+    }
+  }
+
+  u32x4 rk[NLD], rv[NLD];
+  const T* kbase = qkv + (int64_t)bk * N * C3 + C + h * D;
+  const T* vbase = qkv + (int64_t)bv * N * C3 + 2 * C + h * D;
+  auto load_kv = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + 256 * i;
+      u32x4 a = {0u, 0u, 0u, 0u}, c = {0u, 0u, 0u, 0u};
+      if (idx < KV * NCH) {
+        {
+          const int key = idx / NCH, ch = idx % NCH;
+          if (kv0 + key < N) a = *reinterpret_cast<const u32x4*>(kbase + (int64_t)(kv0 + key) * C3 + ch * 8);
+        }
+        {
+          const int key = idx % KV, ch = idx / KV;
+          if (kv0 + key < N) c = *reinterpret_cast<const u32x4*>(vbase + (int64_t)(kv0 + key) * C3 + ch * 8);
+        }
+      }
+      rk[i] = a;
+      rv[i] = c;
+    }
+  };
+  auto store_kv = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < KV * NCH) {
+        {
+          const int key = idx / NCH, ch = idx % NCH;
+          *reinterpret_cast<u32x4*>(sK + key * KSTR + ch * 8) = rk[i];
+        }
+        {
+          const int key = idx % KV, ch = idx / KV;
+          const T* e = reinterpret_cast<const T*>(&rv[i]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sVt[(ch * 8 + j) * VSTR + key] = e[j];
+        }
+      }
+    }
+  };
+
+  float m_run[QT], l_run[QT];
+  f32x4 acc[QT][DT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    m_run[qt] = NEG_BIG;
+    l_run[qt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int ntiles = (N + KV - 1) / KV;
+  load_kv(0);
+  __syncthreads();  // pad zeroing done
+  store_kv();
+  __syncthreads();
+
+  for (int j = 0; j < ntiles; ++j) {
+    const int kv0 = j * KV;
+    if (j + 1 < ntiles) load_kv(kv0 + KV);
+
+    // ---- S^T = K Q^T : s[qt][kt] holds keys kt*16 + q4*4 + r for query fr
+    f32x4 s[QT][4];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) s[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        v8 kf = *reinterpret_cast<const v8*>(sK + (kt * 16 + fr) * KSTR + ks * 32 + q4 * 8);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) s[qt][kt] = Frag<T>::mfma(kf, qf[qt][ks], s[qt][kt]);
+      }
+
+    // ---- online softmax per query (lane-local + 2 shuffles), P packed straight into PV operands
+    v8 pf[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = s[qt][kt][r] * scale_log2;
+          if (kv0 + kt * 16 + q4 * 4 + r >= N) v = NEG_BIG;
+          s[qt][kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[qt], mx);
+      const float alpha = exp2f(m_run[qt] - m_new);
+      m_run[qt] = m_new;
+      float rs = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = exp2f(s[qt][kt][r] - m_new);
+          rs += p;
+          pf[qt][kt >> 1][(kt & 1) * 4 + r] = (T)p;
+        }
+      l_run[qt] = l_run[qt] * alpha + rs;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) acc[qt][dt] *= alpha;
+    }
+
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const T* vp = sVt + (dt * 16 + fr) * VSTR + ks * 32 + q4 * 4;
+        v4 lo = *reinterpret_cast<const v4*>(vp);
+        v4 hi = *reinterpret_cast<const v4*>(vp + 16);
+        v8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) acc[qt][dt] = Frag<T>::mfma(vf, pf[qt][ks], acc[qt][dt]);
+      }
+
+    __syncthreads();
+    if (j + 1 < ntiles) {
+      store_kv();
+      __syncthreads();
+    }
+  }
+
+  // ---- normalise and store: lane holds channels dt*16 + q4*4 + r of query fr
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float l = l_run[qt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.f / l;
+    const int query = q_base + qt * 16 + fr;
+    if (query >= N) continue;
+    T* op = out + ((int64_t)b * N + query) * C + h * D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int dc = dt * 16 + q4 * 4;
+      if (dc < D) {
+        T o[4] = {(T)(acc[qt][dt][0] * inv), (T)(acc[qt][dt][1] * inv), (T)(acc[qt][dt][2] * inv), (T)(acc[qt][dt][3] * inv)};
+        *reinterpret_cast<u32x2*>(op + dc) = *reinterpret_cast<u32x2*>(o);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ cross
+template <typename T, int D, int QT>
+__global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ kv, T* __restrict__ out,
+                                                         CrossParams p) {
+  typedef typename Frag<T>::v8 v8;
+  typedef typename Frag<T>::v4 v4;
+  constexpr int DP = (D + 31) / 32 * 32;
+  constexpr int KS = DP / 32;
+  constexpr int DT = (D + 15) / 16;
+  constexpr int NCH = D / 8;
+  constexpr int KC = 96;           // padded key count (6 tiles of 16; tile 5 is all padding)
+  constexpr int KT = 5;            // key tiles that can hold real keys (80 >= 77)
+  constexpr int KSTR = DP + 8;
+  constexpr int VSTR = KC + 8;
+  constexpr int PSTR = 81;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sK = reinterpret_cast<T*>(smem);            // [KC][KSTR]  keys of this row
+  T* sKs = sK + KC * KSTR;                       // [KC][KSTR]  keys of the source row (edit only)
+  T* sVt = sKs + KC * KSTR;                      // [DT*16][VSTR]
+  float* sP = reinterpret_cast<float*>(sVt + DT * 16 * VSTR);  // [4 waves][QT][16][PSTR] source probabilities
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, q4 = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int N = p.N, C = p.heads * D, C2 = 2 * C;
+
+  int img = 0, role = -1, is_cond = 0;
+  if (p.layout == 2) {
+    int half;
+    row_roles(b, p.n_img, half, role, img);
+    is_cond = half;
+  } else if (p.layout == 1) {
+    img = b % p.n_img;
+    is_cond = (p.rows == p.n_img) ? 1 : (b / p.n_img);
+    role = 0;
+  }
+  const bool do_edit = p.edit && p.layout == 2 && is_cond && role == 1;
+  const bool do_store = p.map_layer >= 0 && is_cond;
+  const int bs = b - p.n_img;  // source cond row of a target cond row
+
+  // ---- stage K (and source K), V^T; zero all padding
+  for (int idx = tid; idx < KC * (KSTR / 8); idx += 256) {
+    const int key = idx / (KSTR / 8), ch = idx % (KSTR / 8);
+    u32x4 a = {0u, 0u, 0u, 0u}, s = {0u, 0u, 0u, 0u};
+    if (key < p.n_ctx && ch < NCH) {
+      a = *reinterpret_cast<const u32x4*>(kv + ((int64_t)b * p.n_ctx + key) * C2 + h * D + ch * 8);
+      if (do_edit) s = *reinterpret_cast<const u32x4*>(kv + ((int64_t)bs * p.n_ctx + key) * C2 + h * D + ch * 8);
+    }
+    *reinterpret_cast<u32x4*>(sK + key * KSTR + ch * 8) = a;
+    *reinterpret_cast<u32x4*>(sKs + key * KSTR + ch * 8) = s;
+  }
+  for (int idx = tid; idx < KC * NCH; idx += 256) {
+    const int key = idx % KC, ch = idx / KC;
+    u32x4 c = {0u, 0u, 0u, 0u};
+    if (key < p.n_ctx) c = *reinterpret_cast<const u32x4*>(kv + ((int64_t)b * p.n_ctx + key) * C2 + C + h * D + ch * 8);
+    const T* e = reinterpret_cast<const T*>(&c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sVt[(ch * 8 + j) * VSTR + key] = e[j];
+  }
+  __syncthreads();
+
+  const int q_base = blockIdx.x * (64 * QT) + wid * (16 * QT);
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    int query = q_base + qt * 16 + fr;
+    const bool q_ok = query < N;
+    query = q_ok ? query : N - 1;
+    float* sPw = sP + ((wid * QT + qt) * 16 + fr) * PSTR;
+
+    // probabilities of one (row, K-set): returns p[kt][r] for keys kt*16 + q4*4 + r
+    auto probs = [&](int brow, const T* keys, f32x4 (&pr)[KT]) {
+      const T* qp = q + ((int64_t)brow * N + query) * C + h * D;
+      f32x4 s[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int d0 = ks * 32 + q4 * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (d0 < D) v = *reinterpret_cast<const u32x4*>(qp + d0);
+        v8 qf = *reinterpret_cast<v8*>(&v);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          v8 kf = *reinterpret_cast<const v8*>(keys + (kt * 16 + fr) * KSTR + ks * 32 + q4 * 8);
+          s[kt] = Frag<T>::mfma(kf, qf, s[kt]);
+        }
+      }
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = s[kt][r] * p.scale_log2;
+          if (kt * 16 + q4 * 4 + r >= p.n_ctx) v = NEG_BIG;
+          s[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float rs = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float e = exp2f(s[kt][r] - mx);
+          s[kt][r] = e;
+          rs += e;
+        }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      const float inv = 1.f / rs;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) pr[kt] = s[kt] * inv;
+    };
+
+    f32x4 pr[KT];
+    if (do_edit) {
+      // source probabilities -> LDS (indexed by token), then the target's own probabilities, then the edit
+      f32x4 ps[KT];
+      probs(bs, sKs, ps);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sPw[kt * 16 + q4 * 4 + r] = ps[kt][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      probs(b, sK, pr);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + q4 * 4 + r;
+          if (key < p.n_ctx) {
+            const float tg = pr[kt][r];
+            float rep;
+            if (p.replace_mat) {                              // AttentionReplace: sum_w base[w] * M[w][key]
+              const float* mrow = p.replace_mat + (int64_t)img * 77 * 77 + key;
+              rep = 0.f;
+              for (int w = 0; w < p.n_ctx; ++w) rep += sPw[w] * mrow[w * 77];
+            } else {                                          // AttentionRefine
+              int mp = p.mapper[img * 77 + key];
+              if (mp < 0) mp += p.n_ctx;                      // python negative index: -1 -> last token
+              const float a = p.alphas[img * 77 + key];
+              rep = sPw[mp] * a + tg * (1.f - a);
+            }
+            if (p.equalizer) rep *= p.equalizer[img * 77 + key];
+            const float ca = p.cross_alpha[img * 77 + key];
+            pr[kt][r] = rep * ca + (1.f - ca) * tg;
+          }
+        }
+    } else {
+      probs(b, sK, pr);
+    }
+
+    if (do_store && q_ok) {
+      float* mp = p.maps_acc + (((((int64_t)p.map_layer * p.n_img_cap + img) * 2 + role) * p.heads + h) * N + query) * 77;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + q4 * 4 + r;
+          if (key < p.n_ctx) mp[key] += pr[kt][r];
+        }
+    }
+
+    // ---- O^T = V^T P^T over 3 k-steps of 32 keys (keys 80..95 are padding with p = 0)
+    v8 pf[3];
+#pragma unroll
+    for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pf[kt >> 1][(kt & 1) * 4 + r] = (kt < KT) ? (T)pr[kt < KT ? kt : 0][r] : (T)0.f;
+    f32x4 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const T* vp = sVt + (dt * 16 + fr) * VSTR + ks * 32 + q4 * 4;
+        v4 lo = *reinterpret_cast<const v4*>(vp);
+        v4 hi = *reinterpret_cast<const v4*>(vp + 16);
+        v8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        acc[dt] = Frag<T>::mfma(vf, pf[ks], acc[dt]);
+      }
+    if (q_ok) {
+      T* op = out + ((int64_t)b * N + query) * C + h * D;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int dc = dt * 16 + q4 * 4;
+        if (dc < D) {
+          T o[4] = {(T)acc[dt][0], (T)acc[dt][1], (T)acc[dt][2], (T)acc[dt][3]};
+          *reinterpret_cast<u32x2*>(op + dc) = *reinterpret_cast<u32x2*>(o);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int D>
+static int launch_self_t(const void* qkv, void* out, int b, int n, int heads, int mode, int n_img, hipStream_t s) {
+  constexpr int QT = 2;
+  constexpr int DP = (D + 31) / 32 * 32, DT = (D + 15) / 16;
+  const size_t lds = (size_t)(64 * (DP + 8) + DT * 16 * (64 + 8)) * sizeof(T);
+  const float scale_log2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+  hipLaunchKernelGGL((self_attn_kernel<T, D, QT>), dim3(cdiv(n, 64 * QT), heads, b), dim3(256), lds, s, (const T*)qkv, (T*)out, n,
+                     heads, scale_log2, mode, n_img);
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int heads, int d, int mode, int n_img, int dtype,
+                               hipStream_t s) {
+  ETAINV_CHECK(qkv && out && b > 0 && n > 0, "bad arguments");
+  ETAINV_CHECK(mode == 0 || (n_img > 0 && b == 4 * n_img), "ptp / masactrl modes need the 4*n_img backward layout");
+  ETAINV_DISPATCH_HALF(dtype, T, switch (d) {
+    case 40: return launch_self_t<T, 40>(qkv, out, b, n, heads, mode, n_img, s);
+    case 80: return launch_self_t<T, 80>(qkv, out, b, n, heads, mode, n_img, s);
+    case 160: return launch_self_t<T, 160>(qkv, out, b, n, heads, mode, n_img, s);
+    default: ETAINV_FAIL("head_dim must be 40, 80 or 160");
+  });
+  return 0;
+}
+
+template <typename T, int D>
+static int launch_cross_t(const void* q, const void* kv, void* out, int b, const CrossParams& p, hipStream_t s) {
+  constexpr int QT = 2;
+  constexpr int DP = (D + 31) / 32 * 32, DT = (D + 15) / 16;
+  const size_t lds = (size_t)(2 * 96 * (DP + 8) + DT * 16 * (96 + 8)) * sizeof(T) + (size_t)4 * QT * 16 * 81 * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn_kernel<T, D, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((cross_attn_kernel<T, D, QT>), dim3(cdiv(p.N, 64 * QT), p.heads, b), dim3(256), lds, s, (const T*)q,
+                     (const T*)kv, (T*)out, p);
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_cross_attention_p(const void* q, const void* kv, void* out, int b, int d, const CrossParams& p, int dtype, hipStream_t s) {
+  ETAINV_CHECK(q && kv && out && b > 0, "bad arguments");
+  ETAINV_CHECK(p.n_ctx >= 1 && p.n_ctx <= 77, "n_ctx must be in [1,77]");
+  ETAINV_DISPATCH_HALF(dtype, T, switch (d) {
+    case 40: return launch_cross_t<T, 40>(q, kv, out, b, p, s);
+    case 80: return launch_cross_t<T, 80>(q, kv, out, b, p, s);
+    case 160: return launch_cross_t<T, 160>(q, kv, out, b, p, s);
+    default: ETAINV_FAIL("head_dim must be 40, 80 or 160");
+  });
+  return 0;
+}
+
+}  // namespace etainv

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libetainv_hip.so for gfx950 in-tree (the .so is git-ignored but travels to the GPU box with gpurun).
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/../etainv/lib"
+mkdir -p "$OUT" "$HERE/obj"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+pids=()
+for f in step_kernels igemm norm attention misc maps; do
+  if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/kernels.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/etainv.h" -nt "$HERE/obj/$f.o" ]; then
+    hipcc $FLAGS -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" &
+    pids+=($!)
+  fi
+done
+hipcc $FLAGS -x hip -c "$HERE/engine.cpp" -o "$HERE/obj/engine.o" &
+pids+=($!)
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libetainv_hip.so" "$HERE"/obj/{step_kernels,igemm,norm,attention,misc,maps,engine}.o
+echo "built $OUT/libetainv_hip.so"

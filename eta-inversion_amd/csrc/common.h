@@ -1,0 +1,87 @@
+// Shared helpers for the gfx950 kernels of libetainv_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/etainv.h"
+
+namespace etainv {
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// ---- error plumbing (thread-local message, integer status; no exceptions across the ABI)
+void set_error(const std::string& msg);
+#define ETAINV_FAIL(msg)                                                        \
+  do {                                                                          \
+    ::etainv::set_error(std::string(__func__) + ": " + (msg));                  \
+    return 1;                                                                   \
+  } while (0)
+#define ETAINV_CHECK(cond, msg) \
+  do {                          \
+    if (!(cond)) ETAINV_FAIL(msg); \
+  } while (0)
+#define ETAINV_HIP(expr)                                                                   \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) ETAINV_FAIL(std::string(#expr) + " -> " + hipGetErrorString(_e)); \
+  } while (0)
+#define ETAINV_LAUNCH_CHECK()                                                          \
+  do {                                                                                 \
+    hipError_t _e = hipGetLastError();                                                 \
+    if (_e != hipSuccess) ETAINV_FAIL(std::string("launch: ") + hipGetErrorString(_e)); \
+  } while (0)
+
+// ---- scalar conversions
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<f16>(f16 v) { return (float)v; }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// ---- wave64 reductions (DPP-free shuffles; 64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// dispatch a generic lambda over the three element types
+#define ETAINV_DISPATCH_DTYPE(dt, T, ...)                          \
+  switch (dt) {                                                    \
+    case ETAINV_F32: { typedef float T; __VA_ARGS__; } break;      \
+    case ETAINV_F16: { typedef ::etainv::f16 T; __VA_ARGS__; } break;  \
+    case ETAINV_BF16: { typedef ::etainv::bf16 T; __VA_ARGS__; } break; \
+    default: ETAINV_FAIL("bad dtype");                             \
+  }
+#define ETAINV_DISPATCH_HALF(dt, T, ...)                           \
+  switch (dt) {                                                    \
+    case ETAINV_F16: { typedef ::etainv::f16 T; __VA_ARGS__; } break;  \
+    case ETAINV_BF16: { typedef ::etainv::bf16 T; __VA_ARGS__; } break; \
+    default: ETAINV_FAIL("compute dtype must be f16 or bf16");     \
+  }
+
+}  // namespace etainv

@@ -1,0 +1,758 @@
+// UNet executor + C ABI of libetainv_hip.so.
+//
+// The engine owns: (1) the SD1.x UNet weights, re-laid-out for the kernels (conv [O][tap][I], fused QKV / KV,
+// GEGLU row-interleave, one concatenated time-embedding projection), (2) a preallocated NHWC activation
+// workspace sized for `max_unet_batch` rows, (3) the attention-map store.  etainv_unet_forward walks the static
+// SD1.x graph and only enqueues kernels on the caller's stream: no allocation, no host sync.
+// It replaces `self.unet(latent_input, t, encoder_hidden_states=context)["sample"]`
+// (reference modules/inversion/eta_inversion.py:321) including what the reference's monkey-patched attention
+// forwards do (modules/utils/ptp_utils.py:205-260, modules/utils/masactrl_utils.py:84-127), driven by the
+// declarative etainv_attn_ctrl.
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace etainv {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+enum PackMode { PK_PLAIN = 0, PK_CONV = 1, PK_GEGLU = 2, PK_CONV_IN = 3, PK_CONV_OUT = 4 };
+
+struct WeightSlot {
+  std::string name;
+  int64_t shape[4] = {0, 0, 0, 0};
+  int ndim = 0;
+  void* dst = nullptr;
+  int pack = PK_PLAIN;
+  int taps = 1;
+  int dst_dtype = ETAINV_F32;  // F32 or the compute dtype (-1 placeholder replaced at build)
+  bool set = false;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    return n;
+  }
+};
+
+struct Norm { float* g = nullptr; float* b = nullptr; };
+struct Lin { void* w = nullptr; float* b = nullptr; int n = 0, k = 0; };
+
+struct ResBlock {
+  int cin = 0, cout = 0;
+  Norm n1, n2;
+  Lin conv1, conv2, shortcut;  // conv weights [cout][9][cin]
+  int tproj_off = 0;           // column offset into the concatenated time-embedding projection
+};
+struct TBlock {
+  int c = 0;
+  Norm gn, ln1, ln2, ln3;
+  Lin proj_in, qkv, out1, q, kv, out2, ff1, ff2, proj_out;
+};
+
+}  // namespace etainv
+
+using namespace etainv;
+
+struct etainv_engine {
+  etainv_engine_config cfg{};
+  int dt = ETAINV_F16;
+  int L = 64, maxB = 4, max_img = 1;
+  static constexpr int kHeads = 8, kCtx = 77, kCtxDim = 768, kGroups = 32, kTemb = 1280, kCh0 = 320;
+
+  std::vector<WeightSlot> slots;
+  std::unordered_map<std::string, int> slot_by_name;
+  char* warena = nullptr;
+  size_t wbytes = 0;
+  char* wsarena = nullptr;
+  size_t wsbytes = 0;
+
+  // model
+  void* conv_in_w = nullptr; float* conv_in_b = nullptr;
+  void* conv_out_w = nullptr; float* conv_out_b = nullptr;
+  Norm norm_out;
+  Lin time1, time2, tproj;  // tproj: concatenated [sum_co][1280]
+  int tproj_total = 0;
+  std::vector<ResBlock> res;  // execution order: down (8), mid (2), up (12)
+  std::vector<TBlock> tb;     // execution order: 16
+  Lin down_conv[3], up_conv[3];
+
+  // workspace (2-byte elements unless noted)
+  void *skip[12] = {}, *tmp[3] = {}, *gnbuf = nullptr, *h1 = nullptr, *scbuf = nullptr;
+  void *hsA = nullptr, *hsB = nullptr, *lnbuf = nullptr, *qkvbuf = nullptr, *attnbuf = nullptr, *qbuf = nullptr, *kvbuf = nullptr,
+       *ffbuf = nullptr, *ctxT = nullptr, *tembuf = nullptr, *temb1 = nullptr, *temb2 = nullptr;
+  float *tprojbuf = nullptr, *gn_scratch = nullptr, *t_dev = nullptr, *maps_acc = nullptr;
+  float* t_host_pinned = nullptr;
+  int t_ring = 0;
+  static constexpr int kTRing = 64;
+  size_t maps_bytes = 0;
+};
+
+namespace {
+
+struct ArenaPlan {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  }
+};
+
+// ---- model construction: registers every diffusers parameter name with its destination and packing
+struct Builder {
+  etainv_engine* e;
+  ArenaPlan plan;
+  std::vector<std::function<void(char*)>> fixups;  // resolve offsets -> pointers after allocation
+
+  template <typename P>
+  void want(P** field, size_t bytes) {
+    size_t off = plan.take(bytes);
+    fixups.push_back([field, off](char* base) { *field = reinterpret_cast<P*>(base + off); });
+  }
+  void add_slot(const std::string& name, std::vector<int64_t> shape, void** dst_field_holder, size_t dst_off_bytes, int pack, int taps,
+                int dst_dtype) {
+    WeightSlot s;
+    s.name = name;
+    s.ndim = (int)shape.size();
+    for (int i = 0; i < s.ndim; ++i) s.shape[i] = shape[i];
+    s.pack = pack;
+    s.taps = taps;
+    s.dst_dtype = dst_dtype;
+    int idx = (int)e->slots.size();
+    e->slots.push_back(s);
+    e->slot_by_name[name] = idx;
+    etainv_engine* eng = e;
+    fixups.push_back([eng, idx, dst_field_holder, dst_off_bytes](char*) {
+      eng->slots[idx].dst = reinterpret_cast<char*>(*dst_field_holder) + dst_off_bytes;
+    });
+  }
+  // fp32 vector parameter (bias / norm scale)
+  void vec(const std::string& name, float** field, int n) {
+    want(field, (size_t)n * 4);
+    add_slot(name, {n}, reinterpret_cast<void**>(field), 0, PK_PLAIN, 1, ETAINV_F32);
+  }
+  void norm(const std::string& prefix, Norm& nm, int c) {
+    vec(prefix + ".weight", &nm.g, c);
+    vec(prefix + ".bias", &nm.b, c);
+  }
+  // linear [n][k] in compute dtype (+ optional fp32 bias)
+  void linear(const std::string& prefix, Lin& l, int n, int k, bool bias, int pack = PK_PLAIN) {
+    l.n = n;
+    l.k = k;
+    want(&l.w, (size_t)n * k * 2);
+    add_slot(prefix + ".weight", {n, k}, &l.w, 0, pack, 1, e->dt);
+    if (bias) {
+      want(&l.b, (size_t)n * 4);
+      add_slot(prefix + ".bias", {n}, reinterpret_cast<void**>(&l.b), 0, pack == PK_GEGLU ? PK_GEGLU : PK_PLAIN, 1, ETAINV_F32);
+    }
+  }
+  void conv1x1(const std::string& prefix, Lin& l, int n, int k) {
+    l.n = n;
+    l.k = k;
+    want(&l.w, (size_t)n * k * 2);
+    add_slot(prefix + ".weight", {n, k, 1, 1}, &l.w, 0, PK_PLAIN, 1, e->dt);
+    want(&l.b, (size_t)n * 4);
+    add_slot(prefix + ".bias", {n}, reinterpret_cast<void**>(&l.b), 0, PK_PLAIN, 1, ETAINV_F32);
+  }
+  void conv3x3(const std::string& prefix, Lin& l, int n, int k) {
+    l.n = n;
+    l.k = k;
+    want(&l.w, (size_t)n * k * 9 * 2);
+    add_slot(prefix + ".weight", {n, k, 3, 3}, &l.w, 0, PK_CONV, 9, e->dt);
+    want(&l.b, (size_t)n * 4);
+    add_slot(prefix + ".bias", {n}, reinterpret_cast<void**>(&l.b), 0, PK_PLAIN, 1, ETAINV_F32);
+  }
+  void resblock(const std::string& prefix, int cin, int cout) {
+    e->res.emplace_back();
+    // NB: pointers into e->res are taken after all blocks exist (vector may grow) -> reserve() up front
+    ResBlock& r = e->res.back();
+    r.cin = cin;
+    r.cout = cout;
+    norm(prefix + ".norm1", r.n1, cin);
+    conv3x3(prefix + ".conv1", r.conv1, cout, cin);
+    r.tproj_off = e->tproj_total;
+    // time_emb_proj rows live inside the concatenated projection matrix
+    add_slot(prefix + ".time_emb_proj.weight", {cout, etainv_engine::kTemb}, &e->tproj.w,
+             (size_t)r.tproj_off * etainv_engine::kTemb * 2, PK_PLAIN, 1, e->dt);
+    add_slot(prefix + ".time_emb_proj.bias", {cout}, reinterpret_cast<void**>(&e->tproj.b), (size_t)r.tproj_off * 4, PK_PLAIN, 1,
+             ETAINV_F32);
+    e->tproj_total += cout;
+    norm(prefix + ".norm2", r.n2, cout);
+    conv3x3(prefix + ".conv2", r.conv2, cout, cout);
+    if (cin != cout) conv1x1(prefix + ".conv_shortcut", r.shortcut, cout, cin);
+  }
+  void tblock(const std::string& prefix, int c) {
+    e->tb.emplace_back();
+    TBlock& t = e->tb.back();
+    t.c = c;
+    const std::string tp = prefix + ".transformer_blocks.0";
+    norm(prefix + ".norm", t.gn, c);
+    conv1x1(prefix + ".proj_in", t.proj_in, c, c);
+    norm(tp + ".norm1", t.ln1, c);
+    // fused QKV [3c][c]
+    t.qkv.n = 3 * c;
+    t.qkv.k = c;
+    want(&t.qkv.w, (size_t)3 * c * c * 2);
+    add_slot(tp + ".attn1.to_q.weight", {c, c}, &t.qkv.w, 0, PK_PLAIN, 1, e->dt);
+    add_slot(tp + ".attn1.to_k.weight", {c, c}, &t.qkv.w, (size_t)c * c * 2, PK_PLAIN, 1, e->dt);
+    add_slot(tp + ".attn1.to_v.weight", {c, c}, &t.qkv.w, (size_t)2 * c * c * 2, PK_PLAIN, 1, e->dt);
+    linear(tp + ".attn1.to_out.0", t.out1, c, c, true);
+    norm(tp + ".norm2", t.ln2, c);
+    linear(tp + ".attn2.to_q", t.q, c, c, false);
+    t.kv.n = 2 * c;
+    t.kv.k = etainv_engine::kCtxDim;
+    want(&t.kv.w, (size_t)2 * c * etainv_engine::kCtxDim * 2);
+    add_slot(tp + ".attn2.to_k.weight", {c, etainv_engine::kCtxDim}, &t.kv.w, 0, PK_PLAIN, 1, e->dt);
+    add_slot(tp + ".attn2.to_v.weight", {c, etainv_engine::kCtxDim}, &t.kv.w, (size_t)c * etainv_engine::kCtxDim * 2, PK_PLAIN, 1, e->dt);
+    linear(tp + ".attn2.to_out.0", t.out2, c, c, true);
+    norm(tp + ".norm3", t.ln3, c);
+    linear(tp + ".ff.net.0.proj", t.ff1, 8 * c, c, true, PK_GEGLU);
+    linear(tp + ".ff.net.2", t.ff2, c, 4 * c, true);
+    conv1x1(prefix + ".proj_out", t.proj_out, c, c);
+  }
+};
+
+int build_model(etainv_engine* e) {
+  Builder b{e};
+  e->res.reserve(22);
+  e->tb.reserve(16);
+  const int ch[4] = {320, 640, 1280, 1280};
+  // conv_in / conv_out keep fp32 weights in their own layouts
+  b.want(&e->conv_in_w, (size_t)36 * ch[0] * 4);
+  b.add_slot("conv_in.weight", {ch[0], 4, 3, 3}, &e->conv_in_w, 0, PK_CONV_IN, 9, ETAINV_F32);
+  b.vec("conv_in.bias", &e->conv_in_b, ch[0]);
+  b.linear("time_embedding.linear_1", e->time1, etainv_engine::kTemb, ch[0], true);
+  b.linear("time_embedding.linear_2", e->time2, etainv_engine::kTemb, etainv_engine::kTemb, true);
+  // concatenated time-embedding projection: total = sum of cout over the 22 resblocks = 21120... computed below;
+  // reserve the maximum up front (22 * 1280) and trim logically via tproj_total
+  b.want(&e->tproj.w, (size_t)22 * 1280 * etainv_engine::kTemb * 2);
+  b.want(&e->tproj.b, (size_t)22 * 1280 * 4);
+  // down
+  int cin = ch[0];
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 2; ++j) {
+      b.resblock("down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), j == 0 ? cin : ch[i], ch[i]);
+      if (i < 3) b.tblock("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), ch[i]);
+    }
+    if (i < 3) b.conv3x3("down_blocks." + std::to_string(i) + ".downsamplers.0.conv", e->down_conv[i], ch[i], ch[i]);
+    cin = ch[i];
+  }
+  // mid
+  b.resblock("mid_block.resnets.0", 1280, 1280);
+  b.tblock("mid_block.attentions.0", 1280);
+  b.resblock("mid_block.resnets.1", 1280, 1280);
+  // up: rev = (1280,1280,640,320)
+  const int rev[4] = {1280, 1280, 640, 320};
+  int prev = 1280;
+  for (int i = 0; i < 4; ++i) {
+    const int cout = rev[i];
+    const int cin_skip = rev[std::min(i + 1, 3)];
+    for (int j = 0; j < 3; ++j) {
+      const int skipc = (j == 2) ? cin_skip : cout;
+      const int rin = (j == 0) ? prev : cout;
+      b.resblock("up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), rin + skipc, cout);
+      if (i > 0) b.tblock("up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), cout);
+    }
+    if (i < 3) b.conv3x3("up_blocks." + std::to_string(i) + ".upsamplers.0.conv", e->up_conv[i], cout, cout);
+    prev = cout;
+  }
+  b.norm("conv_norm_out", e->norm_out, ch[0]);
+  b.want(&e->conv_out_w, (size_t)9 * ch[0] * 4 * 4);
+  b.add_slot("conv_out.weight", {4, ch[0], 3, 3}, &e->conv_out_w, 0, PK_CONV_OUT, 9, ETAINV_F32);
+  b.vec("conv_out.bias", &e->conv_out_b, 4);
+  e->tproj.n = e->tproj_total;
+  e->tproj.k = etainv_engine::kTemb;
+
+  e->wbytes = b.plan.off;
+  ETAINV_HIP(hipMalloc(reinterpret_cast<void**>(&e->warena), e->wbytes));
+  ETAINV_HIP(hipMemset(e->warena, 0, e->wbytes));
+  // two passes: first resolve `want` fields (pointers), then slot destinations that depend on them
+  for (auto& f : b.fixups) f(e->warena);
+  for (auto& f : b.fixups) f(e->warena);
+  return 0;
+}
+
+int build_workspace(etainv_engine* e) {
+  ArenaPlan plan;
+  std::vector<std::function<void(char*)>> fix;
+  auto want = [&](void** field, size_t bytes) {
+    size_t off = plan.take(bytes);
+    fix.push_back([field, off](char* base) { *field = base + off; });
+  };
+  const size_t B = (size_t)e->maxB, L = (size_t)e->L;
+  const size_t hw[4] = {L * L, (L / 2) * (L / 2), (L / 4) * (L / 4), (L / 8) * (L / 8)};
+  const size_t skip_el[12] = {hw[0] * 320, hw[0] * 320, hw[0] * 320, hw[1] * 320,  hw[1] * 640,  hw[1] * 640,
+                              hw[2] * 640, hw[2] * 1280, hw[2] * 1280, hw[3] * 1280, hw[3] * 1280, hw[3] * 1280};
+  for (int i = 0; i < 12; ++i) want(&e->skip[i], B * skip_el[i] * 2);
+  // largest activation [HW x C] over the levels is L^2 x 320 (x2 after an upsample conv never exceeds it)
+  const size_t hmax = hw[0] * 320;
+  // block outputs: the up_blocks.2 upsample conv emits L^2 x 640
+  for (int i = 0; i < 3; ++i) want(&e->tmp[i], B * hw[0] * 640 * 2);
+  want(&e->gnbuf, B * hw[0] * 960 * 2);
+  want(&e->h1, B * hmax * 2);
+  want(&e->scbuf, B * hmax * 2);
+  want(&e->hsA, B * hmax * 2);
+  want(&e->hsB, B * hmax * 2);
+  want(&e->lnbuf, B * hmax * 2);
+  want(&e->qkvbuf, B * hmax * 3 * 2);
+  want(&e->attnbuf, B * hmax * 2);
+  want(&e->qbuf, B * hmax * 2);
+  want(&e->kvbuf, B * 77 * 2 * 1280 * 2);
+  want(&e->ffbuf, B * hmax * 4 * 2);
+  want(&e->ctxT, B * 77 * 768 * 2);
+  want(&e->tembuf, B * 320 * 2);
+  want(&e->temb1, B * 1280 * 2);
+  want(&e->temb2, B * 1280 * 2);
+  want(reinterpret_cast<void**>(&e->tprojbuf), B * (size_t)e->tproj_total * 4);
+  want(reinterpret_cast<void**>(&e->gn_scratch), B * (GN_MAX_CHUNKS + 1) * etainv_engine::kGroups * 2 * 4);
+  want(reinterpret_cast<void**>(&e->t_dev), (size_t)etainv_engine::kTRing * B * 4);
+  const size_t res = L / 4;
+  e->maps_bytes = (size_t)5 * e->max_img * 2 * etainv_engine::kHeads * res * res * 77 * 4;
+  want(reinterpret_cast<void**>(&e->maps_acc), e->maps_bytes);
+  e->wsbytes = plan.off;
+  ETAINV_HIP(hipMalloc(reinterpret_cast<void**>(&e->wsarena), e->wsbytes));
+  for (auto& f : fix) f(e->wsarena);
+  ETAINV_HIP(hipMemset(e->maps_acc, 0, e->maps_bytes));
+  ETAINV_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->t_host_pinned), (size_t)etainv_engine::kTRing * B * 4));
+  return 0;
+}
+
+// ---- forward helpers
+struct Fwd {
+  etainv_engine* e;
+  hipStream_t s;
+  int rows;
+  const etainv_attn_ctrl* ctrl;
+  int tblock_idx = 0;
+
+  int gemm(const void* a, const Lin& l, void* out, int M, const void* residual = nullptr, int geglu = 0, const void* a2 = nullptr,
+           int c1 = 0, int c2 = 0) {
+    IGemmParams p;
+    p.a1 = a;
+    p.a2 = a2;
+    p.w = l.w;
+    p.bias = l.b;
+    p.residual = residual;
+    p.out = out;
+    p.M = M;
+    p.N = l.n;
+    p.c1 = a2 ? c1 : l.k;
+    p.c2 = a2 ? c2 : 0;
+    p.H = 1;
+    p.W = M;
+    p.Ho = 1;
+    p.Wo = M;
+    p.taps = 1;
+    p.geglu = geglu;
+    p.rows_per_batch = M;
+    return launch_igemm(p, e->dt, s);
+  }
+  int conv(const void* a, const Lin& l, void* out, int H, int W, int stride, int ups, const float* rowvec, const void* residual) {
+    IGemmParams p;
+    p.a1 = a;
+    p.w = l.w;
+    p.bias = l.b;
+    p.rowvec = rowvec;
+    p.rowvec_stride = e->tproj_total;
+    p.residual = residual;
+    p.out = out;
+    p.c1 = l.k;
+    p.H = H;
+    p.W = W;
+    p.Ho = ups ? H * 2 : (stride == 2 ? H / 2 : H);
+    p.Wo = ups ? W * 2 : (stride == 2 ? W / 2 : W);
+    p.stride = stride;
+    p.ups = ups;
+    p.taps = 9;
+    p.M = rows * p.Ho * p.Wo;
+    p.N = l.n;
+    p.rows_per_batch = p.Ho * p.Wo;
+    return launch_igemm(p, e->dt, s);
+  }
+  // x = cat[x1 (c1), x2 (c2)] -> out
+  int resblock(const ResBlock& r, const void* x1, const void* x2, int c1, int c2, int side, void* out) {
+    const int hw = side * side;
+    if (launch_groupnorm(x1, x2, c1, c2, r.n1.g, r.n1.b, e->gnbuf, rows, hw, etainv_engine::kGroups, 1e-5f, 1, e->gn_scratch, e->dt, s)) return 1;
+    if (conv(e->gnbuf, r.conv1, e->h1, side, side, 1, 0, e->tprojbuf + r.tproj_off, nullptr)) return 1;
+    if (launch_groupnorm(e->h1, nullptr, r.cout, 0, r.n2.g, r.n2.b, e->gnbuf, rows, hw, etainv_engine::kGroups, 1e-5f, 1, e->gn_scratch, e->dt, s)) return 1;
+    const void* residual = x1;
+    if (r.shortcut.w) {
+      if (gemm(x1, r.shortcut, e->scbuf, rows * hw, nullptr, 0, x2, c1, c2)) return 1;
+      residual = e->scbuf;
+    }
+    return conv(e->gnbuf, r.conv2, out, side, side, 1, 0, nullptr, residual);
+  }
+  int transformer(const TBlock& t, const void* x, int side, void* out) {
+    const int hw = side * side, M = rows * hw, c = t.c, d = c / etainv_engine::kHeads;
+    const int blk = tblock_idx++;
+    if (launch_groupnorm(x, nullptr, c, 0, t.gn.g, t.gn.b, e->gnbuf, rows, hw, etainv_engine::kGroups, 1e-6f, 0, e->gn_scratch, e->dt, s)) return 1;
+    if (gemm(e->gnbuf, t.proj_in, e->hsA, M)) return 1;
+    // self-attention
+    if (launch_layernorm(e->hsA, t.ln1.g, t.ln1.b, e->lnbuf, M, c, 1e-5f, e->dt, s)) return 1;
+    if (gemm(e->lnbuf, t.qkv, e->qkvbuf, M)) return 1;
+    int mode = 0, n_img = 1;
+    if (ctrl) {
+      n_img = ctrl->n_img;
+      if (ctrl->mode == ETAINV_ATTN_PTP && ctrl->self_replace_active && hw <= ctrl->self_max_tokens) mode = 1;
+      if (ctrl->mode == ETAINV_ATTN_MASA && ctrl->masa_active && blk >= ctrl->masa_first_block) mode = 2;
+    }
+    if (launch_self_attention_mode(e->qkvbuf, e->attnbuf, rows, hw, etainv_engine::kHeads, d, mode, n_img, e->dt, s)) return 1;
+    if (gemm(e->attnbuf, t.out1, e->hsB, M, e->hsA)) return 1;
+    // cross-attention
+    if (launch_layernorm(e->hsB, t.ln2.g, t.ln2.b, e->lnbuf, M, c, 1e-5f, e->dt, s)) return 1;
+    if (gemm(e->lnbuf, t.q, e->qbuf, M)) return 1;
+    if (gemm(e->ctxT, t.kv, e->kvbuf, rows * etainv_engine::kCtx)) return 1;
+    CrossParams cp;
+    cp.N = hw;
+    cp.heads = etainv_engine::kHeads;
+    cp.n_ctx = etainv_engine::kCtx;
+    cp.scale_log2 = (1.0f / std::sqrt((float)d)) * 1.4426950408889634f;
+    cp.rows = rows;
+    cp.n_img_cap = e->max_img;
+    cp.maps_acc = e->maps_acc;
+    if (ctrl && (ctrl->mode == ETAINV_ATTN_PTP || ctrl->mode == ETAINV_ATTN_STORE)) {
+      cp.n_img = ctrl->n_img;
+      cp.layout = ctrl->mode == ETAINV_ATTN_PTP ? 2 : 1;
+      if (ctrl->mode == ETAINV_ATTN_PTP && ctrl->cross_alpha && (ctrl->mapper || ctrl->replace_mat)) {
+        cp.edit = 1;
+        cp.mapper = ctrl->mapper;
+        cp.alphas = ctrl->alphas;
+        cp.replace_mat = ctrl->replace_mat;
+        cp.equalizer = ctrl->equalizer;
+        cp.cross_alpha = ctrl->cross_alpha;
+      }
+      const int res = e->L / 4;
+      if (ctrl->store_maps && hw == res * res) {
+        // the five (L/4)^2-token cross layers: transformer blocks 4,5 (down) and 7,8,9 (up)
+        static const int layer_of_block[16] = {-1, -1, -1, -1, 0, 1, -1, 2, 3, 4, -1, -1, -1, -1, -1, -1};
+        cp.map_layer = layer_of_block[blk];
+      }
+    }
+    if (launch_cross_attention_p(e->qbuf, e->kvbuf, e->attnbuf, rows, d, cp, e->dt, s)) return 1;
+    if (gemm(e->attnbuf, t.out2, e->hsA, M, e->hsB)) return 1;
+    // feed-forward (GEGLU)
+    if (launch_layernorm(e->hsA, t.ln3.g, t.ln3.b, e->lnbuf, M, c, 1e-5f, e->dt, s)) return 1;
+    if (gemm(e->lnbuf, t.ff1, e->ffbuf, M, nullptr, 1)) return 1;
+    if (gemm(e->ffbuf, t.ff2, e->hsB, M, e->hsA)) return 1;
+    return gemm(e->hsB, t.proj_out, out, M, x);
+  }
+};
+
+void* pick_tmp(etainv_engine* e, const void* a, const void* b) {
+  for (int i = 0; i < 3; ++i)
+    if (e->tmp[i] != a && e->tmp[i] != b) return e->tmp[i];
+  return nullptr;
+}
+
+}  // namespace
+
+// =============================================================================================== C ABI
+extern "C" int etainv_abi_version(void) { return ETAINV_ABI_VERSION; }
+extern "C" const char* etainv_last_error(void) { return g_err.c_str(); }
+
+extern "C" int etainv_engine_create(const etainv_engine_config* cfg, etainv_engine_t** out) {
+  ETAINV_CHECK(cfg && out, "null argument");
+  ETAINV_CHECK(cfg->compute_dtype == ETAINV_F16 || cfg->compute_dtype == ETAINV_BF16, "compute_dtype must be f16 or bf16");
+  ETAINV_CHECK(cfg->latent_size >= 8 && cfg->latent_size % 8 == 0 && cfg->latent_size <= 128, "latent_size must be a multiple of 8 in [8,128]");
+  ETAINV_CHECK(cfg->max_unet_batch >= 1 && cfg->max_img >= 1, "batch sizes must be positive");
+  int ndev = 0;
+  ETAINV_HIP(hipGetDeviceCount(&ndev));
+  ETAINV_CHECK(ndev > 0, "no HIP device visible: the etainv engine has no CPU fallback");
+  auto* e = new etainv_engine();
+  e->cfg = *cfg;
+  e->dt = cfg->compute_dtype;
+  e->L = cfg->latent_size;
+  e->maxB = cfg->max_unet_batch;
+  e->max_img = cfg->max_img;
+  if (build_model(e) || build_workspace(e)) {
+    etainv_engine_destroy(e);
+    return 1;
+  }
+  *out = e;
+  return 0;
+}
+
+extern "C" int etainv_engine_destroy(etainv_engine_t* e) {
+  if (!e) return 0;
+  if (e->warena) (void)hipFree(e->warena);
+  if (e->wsarena) (void)hipFree(e->wsarena);
+  if (e->t_host_pinned) (void)hipHostFree(e->t_host_pinned);
+  delete e;
+  return 0;
+}
+
+extern "C" int etainv_engine_num_weights(etainv_engine_t* e) { return e ? (int)e->slots.size() : 0; }
+
+extern "C" int etainv_engine_weight_info(etainv_engine_t* e, int i, char* name, int name_cap, int64_t shape[4], int* ndim) {
+  ETAINV_CHECK(e && i >= 0 && i < (int)e->slots.size() && name && shape && ndim, "bad arguments");
+  const WeightSlot& s = e->slots[i];
+  ETAINV_CHECK((int)s.name.size() + 1 <= name_cap, "name buffer too small");
+  std::memcpy(name, s.name.c_str(), s.name.size() + 1);
+  for (int k = 0; k < 4; ++k) shape[k] = s.shape[k];
+  *ndim = s.ndim;
+  return 0;
+}
+
+extern "C" int etainv_engine_set_weight(etainv_engine_t* e, const char* name, const float* data, int64_t numel, void* stream) {
+  ETAINV_CHECK(e && name && data, "null argument");
+  auto it = e->slot_by_name.find(name);
+  ETAINV_CHECK(it != e->slot_by_name.end(), std::string("unknown parameter ") + name);
+  WeightSlot& s = e->slots[it->second];
+  ETAINV_CHECK(numel == s.numel(), std::string("size mismatch for ") + name);
+  int64_t rows = s.shape[0], cols = s.numel() / s.shape[0];
+  if (s.ndim == 1) { rows = s.shape[0]; cols = 1; }
+  if (launch_pack_weight(data, s.dst, rows, cols, s.pack, s.taps, s.dst_dtype, (hipStream_t)stream)) return 1;
+  s.set = true;
+  return 0;
+}
+
+extern "C" int etainv_engine_weights_ready(etainv_engine_t* e) {
+  if (!e) return 0;
+  for (auto& s : e->slots)
+    if (!s.set) return 0;
+  return 1;
+}
+
+extern "C" int64_t etainv_engine_workspace_bytes(etainv_engine_t* e) { return e ? (int64_t)e->wsbytes : 0; }
+extern "C" int64_t etainv_engine_weight_bytes(etainv_engine_t* e) { return e ? (int64_t)e->wbytes : 0; }
+
+extern "C" int etainv_unet_forward(etainv_engine_t* e, const void* latent, int n_lat, const int64_t* t_host, const void* ctx, int n_rows,
+                                   const etainv_attn_ctrl* ctrl, void* out, int io_dtype, void* stream) {
+  ETAINV_CHECK(e && latent && t_host && ctx && out, "null argument");
+  ETAINV_CHECK(n_rows >= 1 && n_rows <= e->maxB, "n_rows exceeds max_unet_batch");
+  ETAINV_CHECK(n_lat >= 1 && n_rows % n_lat == 0, "n_rows must be a multiple of n_lat");
+  ETAINV_CHECK(etainv_engine_weights_ready(e), "weights not fully set");
+  if (ctrl) {
+    ETAINV_CHECK(ctrl->n_img >= 1 && ctrl->n_img <= e->max_img, "ctrl.n_img exceeds max_img");
+    if (ctrl->mode == ETAINV_ATTN_PTP || ctrl->mode == ETAINV_ATTN_MASA)
+      ETAINV_CHECK(n_rows == 4 * ctrl->n_img, "ptp / masactrl need 4*n_img UNet rows [u_s,u_t,c_s,c_t]");
+    if (ctrl->mode == ETAINV_ATTN_STORE)
+      ETAINV_CHECK(n_rows == 2 * ctrl->n_img || n_rows == ctrl->n_img, "store mode needs n_img or 2*n_img rows");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int L = e->L;
+  Fwd f{e, s, n_rows, ctrl};
+
+  // timesteps -> device (pinned ring slot, async copy), embedding, MLP, all 22 projections in one GEMM
+  float* th = e->t_host_pinned + (size_t)e->t_ring * e->maxB;
+  float* td = e->t_dev + (size_t)e->t_ring * e->maxB;
+  e->t_ring = (e->t_ring + 1) % etainv_engine::kTRing;
+  for (int i = 0; i < n_rows; ++i) th[i] = (float)t_host[i];
+  ETAINV_HIP(hipMemcpyAsync(td, th, (size_t)n_rows * 4, hipMemcpyHostToDevice, s));
+  if (launch_time_embedding(td, n_rows, etainv_engine::kCh0, e->tembuf, e->dt, s)) return 1;
+  if (f.gemm(e->tembuf, e->time1, e->temb1, n_rows)) return 1;
+  if (launch_silu(e->temb1, e->temb1, (int64_t)n_rows * etainv_engine::kTemb, e->dt, s)) return 1;
+  if (f.gemm(e->temb1, e->time2, e->temb2, n_rows)) return 1;
+  if (launch_silu(e->temb2, e->temb2, (int64_t)n_rows * etainv_engine::kTemb, e->dt, s)) return 1;
+  {
+    IGemmParams p;
+    p.a1 = e->temb2;
+    p.w = e->tproj.w;
+    p.bias = e->tproj.b;
+    p.out = e->tprojbuf;
+    p.out_f32 = 1;
+    p.M = n_rows;
+    p.N = e->tproj_total;
+    p.c1 = etainv_engine::kTemb;
+    p.W = n_rows;
+    p.Wo = n_rows;
+    p.rows_per_batch = n_rows;
+    if (launch_igemm(p, e->dt, s)) return 1;
+  }
+  if (launch_cast_f32(ctx, io_dtype, e->ctxT, e->dt, (int64_t)n_rows * etainv_engine::kCtx * etainv_engine::kCtxDim, s)) return 1;
+
+  // ---- down path
+  if (launch_conv_in(latent, io_dtype, n_lat, n_rows, L, e->conv_in_w, e->conv_in_b, etainv_engine::kCh0, e->skip[0], e->dt, s)) return 1;
+  const int ch[4] = {320, 640, 1280, 1280};
+  int ri = 0, ti = 0, si = 1, side = L;
+  const void* h = e->skip[0];
+  int hc = 320;
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 2; ++j) {
+      if (i < 3) {
+        void* r_out = pick_tmp(e, h, nullptr);
+        if (f.resblock(e->res[ri++], h, nullptr, hc, 0, side, r_out)) return 1;
+        if (f.transformer(e->tb[ti++], r_out, side, e->skip[si])) return 1;
+      } else {
+        if (f.resblock(e->res[ri++], h, nullptr, hc, 0, side, e->skip[si])) return 1;
+      }
+      h = e->skip[si++];
+      hc = ch[i];
+    }
+    if (i < 3) {
+      if (f.conv(h, e->down_conv[i], e->skip[si], side, side, 2, 0, nullptr, nullptr)) return 1;
+      h = e->skip[si++];
+      side /= 2;
+    }
+  }
+  // ---- mid
+  {
+    void* a = pick_tmp(e, h, nullptr);
+    if (f.resblock(e->res[ri++], h, nullptr, 1280, 0, side, a)) return 1;
+    void* b2 = pick_tmp(e, a, nullptr);
+    if (f.transformer(e->tb[ti++], a, side, b2)) return 1;
+    void* c = pick_tmp(e, b2, nullptr);
+    if (f.resblock(e->res[ri++], b2, nullptr, 1280, 0, side, c)) return 1;
+    h = c;
+    hc = 1280;
+  }
+  // ---- up path
+  const int rev[4] = {1280, 1280, 640, 320};
+  const int skip_c[12] = {320, 320, 320, 320, 640, 640, 640, 1280, 1280, 1280, 1280, 1280};
+  int sp = 11;
+  for (int i = 0; i < 4; ++i) {
+    const int cout = rev[i];
+    for (int j = 0; j < 3; ++j) {
+      const void* sk = e->skip[sp];
+      const int skc = skip_c[sp];
+      --sp;
+      void* r_out = pick_tmp(e, h, nullptr);
+      if (f.resblock(e->res[ri++], h, sk, hc, skc, side, r_out)) return 1;
+      h = r_out;
+      hc = cout;
+      if (i > 0) {
+        void* t_out = pick_tmp(e, h, nullptr);
+        if (f.transformer(e->tb[ti++], h, side, t_out)) return 1;
+        h = t_out;
+      }
+    }
+    if (i < 3) {
+      void* u = pick_tmp(e, h, nullptr);
+      if (f.conv(h, e->up_conv[i], u, side, side, 1, 1, nullptr, nullptr)) return 1;
+      h = u;
+      side *= 2;
+    }
+  }
+  // ---- out
+  if (launch_groupnorm(h, nullptr, 320, 0, e->norm_out.g, e->norm_out.b, e->gnbuf, n_rows, L * L, etainv_engine::kGroups, 1e-5f, 1,
+                       e->gn_scratch, e->dt, s))
+    return 1;
+  return launch_conv_out(e->gnbuf, n_rows, L, 320, e->conv_out_w, e->conv_out_b, out, io_dtype, e->dt, s);
+}
+
+extern "C" int etainv_maps_reset(etainv_engine_t* e, void* stream) {
+  ETAINV_CHECK(e, "null engine");
+  ETAINV_HIP(hipMemsetAsync(e->maps_acc, 0, e->maps_bytes, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int etainv_maps_word_maps(etainv_engine_t* e, int n_img, const int32_t* tokens, int n_tok, int steps_done, float* out,
+                                     int accumulate, float scale, void* stream) {
+  ETAINV_CHECK(e && n_img >= 1 && n_img <= e->max_img, "bad arguments");
+  return launch_word_maps(e->maps_acc, 5, e->max_img, 2, 0, etainv_engine::kHeads, e->L / 4, e->L, n_img, tokens, n_tok, steps_done, out,
+                          accumulate, scale, (hipStream_t)stream);
+}
+
+extern "C" int etainv_local_blend(etainv_engine_t* e, float* x, int n_img, const float* blend_alpha, float thres, void* stream) {
+  ETAINV_CHECK(e && n_img >= 1 && n_img <= e->max_img, "bad arguments");
+  return launch_local_blend(e->maps_acc, 5, e->max_img, etainv_engine::kHeads, e->L / 4, e->L, x, n_img, blend_alpha, thres,
+                            (hipStream_t)stream);
+}
+
+// ---- per-op entry points for the parity tests
+extern "C" int etainv_op_gemm(const void* a, const void* w, const void* bias, const void* residual, void* out, int m, int n, int k,
+                              int geglu, int dtype, void* stream) {
+  IGemmParams p;
+  p.a1 = a;
+  p.w = w;
+  p.bias = (const float*)bias;
+  p.residual = residual;
+  p.out = out;
+  p.M = m;
+  p.N = n;
+  p.c1 = k;
+  p.W = m;
+  p.Wo = m;
+  p.geglu = geglu;
+  p.rows_per_batch = m;
+  return launch_igemm(p, dtype, (hipStream_t)stream);
+}
+
+extern "C" int etainv_op_conv3x3(const void* x_nhwc, const void* x2_nhwc, int c1, int c2, const void* w_okkc, const void* bias,
+                                 const float* rowvec, const void* residual, void* out, int b, int h, int wd, int cout, int stride,
+                                 int upsample, int taps, int dtype, void* stream) {
+  IGemmParams p;
+  p.a1 = x_nhwc;
+  p.a2 = x2_nhwc;
+  p.w = w_okkc;
+  p.bias = (const float*)bias;
+  p.rowvec = rowvec;
+  p.rowvec_stride = cout;
+  p.residual = residual;
+  p.out = out;
+  p.c1 = c1;
+  p.c2 = c2;
+  p.H = h;
+  p.W = wd;
+  p.Ho = upsample ? h * 2 : (stride == 2 ? h / 2 : h);
+  p.Wo = upsample ? wd * 2 : (stride == 2 ? wd / 2 : wd);
+  p.stride = stride;
+  p.ups = upsample;
+  p.taps = taps;
+  p.M = b * p.Ho * p.Wo;
+  p.N = cout;
+  p.rows_per_batch = p.Ho * p.Wo;
+  return launch_igemm(p, dtype, (hipStream_t)stream);
+}
+
+extern "C" int etainv_op_groupnorm(const void* x_nhwc, const void* x2_nhwc, int c1, int c2, const float* gamma, const float* beta,
+                                   void* out, int b, int hw, int groups, float eps, int silu, float* scratch, int dtype, void* stream) {
+  return launch_groupnorm(x_nhwc, x2_nhwc, c1, c2, gamma, beta, out, b, hw, groups, eps, silu, scratch, dtype, (hipStream_t)stream);
+}
+
+extern "C" int etainv_op_layernorm(const void* x, const float* gamma, const float* beta, void* out, int rows, int c, float eps, int dtype,
+                                   void* stream) {
+  return launch_layernorm(x, gamma, beta, out, rows, c, eps, dtype, (hipStream_t)stream);
+}
+
+extern "C" int etainv_op_self_attention(const void* qkv, void* out, int b, int n, int heads, int d, int mode, int n_img, int dtype,
+                                        void* stream) {
+  return launch_self_attention_mode(qkv, out, b, n, heads, d, mode, n_img, dtype, (hipStream_t)stream);
+}
+
+extern "C" int etainv_op_cross_attention(const void* q, const void* kv, void* out, int b, int n, int heads, int d, int n_ctx,
+                                         const etainv_attn_ctrl* ctrl, int map_layer, int n_img_cap, float* maps_acc, int dtype,
+                                         void* stream) {
+  CrossParams cp;
+  cp.N = n;
+  cp.heads = heads;
+  cp.n_ctx = n_ctx;
+  cp.scale_log2 = (1.0f / std::sqrt((float)d)) * 1.4426950408889634f;
+  cp.rows = b;
+  cp.n_img_cap = n_img_cap;
+  cp.maps_acc = maps_acc;
+  if (ctrl && (ctrl->mode == ETAINV_ATTN_PTP || ctrl->mode == ETAINV_ATTN_STORE)) {
+    cp.n_img = ctrl->n_img;
+    cp.layout = ctrl->mode == ETAINV_ATTN_PTP ? 2 : 1;
+    if (ctrl->mode == ETAINV_ATTN_PTP && ctrl->cross_alpha && (ctrl->mapper || ctrl->replace_mat)) {
+      cp.edit = 1;
+      cp.mapper = ctrl->mapper;
+      cp.alphas = ctrl->alphas;
+      cp.replace_mat = ctrl->replace_mat;
+      cp.equalizer = ctrl->equalizer;
+      cp.cross_alpha = ctrl->cross_alpha;
+    }
+    if (ctrl->store_maps && maps_acc) cp.map_layer = map_layer;
+  }
+  return launch_cross_attention_p(q, kv, out, b, d, cp, dtype, (hipStream_t)stream);
+}
+
+extern "C" int etainv_op_word_maps(const float* maps_acc, int n_layers, int n_img_cap, int heads, int res, int L, int n_img,
+                                   const int32_t* tokens, int n_tok, int steps_done, float* out, int accumulate, float scale,
+                                   void* stream) {
+  return launch_word_maps(maps_acc, n_layers, n_img_cap, 2, 0, heads, res, L, n_img, tokens, n_tok, steps_done, out, accumulate, scale,
+                          (hipStream_t)stream);
+}
+
+extern "C" int etainv_op_local_blend(const float* maps_acc, int n_layers, int n_img_cap, int heads, int res, int L, float* x, int n_img,
+                                     const float* blend_alpha, float thres, void* stream) {
+  return launch_local_blend(maps_acc, n_layers, n_img_cap, heads, res, L, x, n_img, blend_alpha, thres, (hipStream_t)stream);
+}

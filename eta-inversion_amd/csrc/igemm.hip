@@ -1,0 +1,240 @@
+// MFMA implicit-GEMM for gfx950: one kernel family serves every contraction of the SD1.x UNet
+//   conv3x3 (stride 1 / stride 2 / fused nearest-2x upsample, zero pad 1)  : K = 9*Cin
+//   conv1x1 / Linear (QKV, out-proj, FF, shortcuts, proj_in/out, time MLP) : K = Cin
+// Activations are NHWC (= row-major [B*H*W][C]); weights are [Cout][taps][Cin] (K-contiguous), so both MFMA
+// operands are 8 consecutive K elements per lane (one ds_read_b128).  The channel concat of the decoder
+// (torch.cat([x, skip], 1)) is never materialised: the K loop walks two source tensors.
+//
+// Tile: BM x BN x 64, 256 threads = 2x2 waves, v_mfma_f32_16x16x32_{f16,bf16}, fp32 accumulate.
+// The weight tile is fed as the MFMA A operand and the activation tile as B, so an accumulator holds
+// 4 consecutive OUTPUT CHANNELS of one pixel per lane -> 8-byte NHWC stores, lane-local GEGLU pairing.
+// LDS image: [rows][8 x 16B chunks], physical chunk = chunk ^ (row & 7): conflict-free ds_read_b128
+// (bank analysis in DESIGN.md).  Double-buffered LDS, global loads for tile k+1 in flight during the MFMAs
+// of tile k, one barrier per K tile.
+// Epilogue (fused): + bias[n] + rowvec[batch][n] (time-embedding projection) + residual[m][n], or GEGLU
+// a * gelu_erf(g) with (a, g) columns interleaved per 32-column group at weight-pack time.
+#include "common.h"
+#include "kernels.h"
+
+namespace etainv {
+
+template <typename T> struct Mfma;
+template <> struct Mfma<f16> {
+  typedef f16x8 frag;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma<bf16> {
+  typedef bf16x8 frag;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+constexpr int BK = 64;  // K elements per LDS tile (8 chunks of 16 B per row)
+
+template <typename T, int BM, int BN>
+__global__ void __launch_bounds__(256) igemm_kernel(IGemmParams p) {
+  constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
+  constexpr int MT = WM / 16, NT = WN / 16;
+  constexpr int A_LOADS = BM * BK * 2 / (256 * 16);
+  constexpr int B_LOADS = BN * BK * 2 / (256 * 16);
+  typedef typename Mfma<T>::frag frag;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sA = reinterpret_cast<T*>(smem);                       // [2][BM*BK]
+  T* sB = reinterpret_cast<T*>(smem) + 2 * BM * BK;         // [2][BN*BK]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
+  // contiguous run of tiles; n varies fastest so neighbours reuse the same activation panel from L2.
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+
+  const int cin = p.c1 + p.c2;
+  const int kc = cin / BK;            // K tiles per tap
+  const int nk = p.taps * kc;
+  const int pad = (p.taps == 9) ? 1 : 0;
+  const int HWo = p.Ho * p.Wo;
+  const int Hin = p.ups ? p.H * 2 : p.H, Win = p.ups ? p.W * 2 : p.W;
+
+  // per-thread staging geometry: row = (tid >> 3) + 32 * i, 16-byte chunk = tid & 7
+  const int chunk = tid & 7;
+  int a_b[A_LOADS], a_y[A_LOADS], a_x[A_LOADS];
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) {
+    int m = m0 + (tid >> 3) + 32 * i;
+    m = m < p.M ? m : p.M - 1;
+    int b = m / HWo, r = m - b * HWo;
+    int oy = r / p.Wo, ox = r - oy * p.Wo;
+    a_b[i] = b;
+    a_y[i] = oy * p.stride - pad;
+    a_x[i] = ox * p.stride - pad;
+  }
+  const T* w_row[B_LOADS];
+#pragma unroll
+  for (int i = 0; i < B_LOADS; ++i) {
+    int n = n0 + (tid >> 3) + 32 * i;
+    n = n < p.N ? n : p.N - 1;
+    w_row[i] = reinterpret_cast<const T*>(p.w) + (int64_t)n * (p.taps * cin) + chunk * 8;
+  }
+
+  u32x4 ra[A_LOADS], rb[B_LOADS];
+
+  auto load_tile = [&](int kt) {
+    const int tap = kt / kc, c0 = (kt - tap * kc) * BK;
+    const int ky = (p.taps == 9) ? tap / 3 : 0, kx = (p.taps == 9) ? tap - ky * 3 : 0;
+    const bool second = c0 >= p.c1;
+    const T* src = reinterpret_cast<const T*>(second ? p.a2 : p.a1);
+    const int cs = second ? p.c2 : p.c1;
+    const int coff = (second ? c0 - p.c1 : c0) + chunk * 8;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      int iy = a_y[i] + ky, ix = a_x[i] + kx;
+      bool ok = (iy >= 0) & (iy < Hin) & (ix >= 0) & (ix < Win);
+      if (p.ups) { iy >>= 1; ix >>= 1; }
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) v = *reinterpret_cast<const u32x4*>(src + ((int64_t)(a_b[i] * p.H + iy) * p.W + ix) * cs + coff);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) rb[i] = *reinterpret_cast<const u32x4*>(w_row[i] + (int64_t)kt * BK);
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      int row = (tid >> 3) + 32 * i;
+      *reinterpret_cast<u32x4*>(sA + buf * BM * BK + row * BK + ((chunk ^ (row & 7)) << 3)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      int row = (tid >> 3) + 32 * i;
+      *reinterpret_cast<u32x4*>(sB + buf * BN * BK + row * BK + ((chunk ^ (row & 7)) << 3)) = rb[i];
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const T* tA = sA + cur * BM * BK;
+    const T* tB = sB + cur * BN * BK;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      frag fa[MT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        int row = wm * WM + i * 16 + fr;
+        fa[i] = *reinterpret_cast<const frag*>(tA + row * BK + (((kk * 4 + fq) ^ (row & 7)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        int row = wn * WN + j * 16 + fr;
+        fb[j] = *reinterpret_cast<const frag*>(tB + row * BK + (((kk * 4 + fq) ^ (row & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = Mfma<T>::run(fb[j], fa[i], acc[i][j]);
+    }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds out[m][n .. n+3], m = pixel (MFMA column), n = channel (MFMA row)
+  T* out = reinterpret_cast<T*>(p.out);
+  const T* res = reinterpret_cast<const T*>(p.residual);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * WM + i * 16 + fr;
+    if (m >= p.M) continue;
+    const int batch = m / p.rows_per_batch;
+    if (!p.geglu) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * WN + j * 16 + fq * 4;
+        if (n >= p.N) continue;
+        f32x4 v = acc[i][j];
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)batch * p.rowvec_stride + n);
+        if (res) {
+          const T* r = res + (int64_t)m * p.N + n;
+          v[0] += to_f32(r[0]); v[1] += to_f32(r[1]); v[2] += to_f32(r[2]); v[3] += to_f32(r[3]);
+        }
+        if (p.out_f32) {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.N + n) = v;
+        } else {
+          T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+          *reinterpret_cast<u32x2*>(out + (int64_t)m * p.N + n) = *reinterpret_cast<u32x2*>(o);
+        }
+      }
+    } else {
+      // GEGLU: wave columns [0, WN/2) hold a, [WN/2, WN) hold the matching gate g (weight rows interleaved per
+      // WN-column group by pack_geglu_rows); output width N/2.
+      const int No = p.N >> 1;
+#pragma unroll
+      for (int j = 0; j < NT / 2; ++j) {
+        const int n = n0 + wn * WN + j * 16 + fq * 4;          // physical column of a
+        const int no = ((n0 + wn * WN) >> 1) + j * 16 + fq * 4;  // output column
+        f32x4 a = acc[i][j], g = acc[i][j + NT / 2];
+        if (p.bias) {
+          a += *reinterpret_cast<const f32x4*>(p.bias + n);
+          g += *reinterpret_cast<const f32x4*>(p.bias + n + WN / 2);
+        }
+        T o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(a[q] * gelu_erf_f(g[q]));
+        *reinterpret_cast<u32x2*>(out + (int64_t)m * No + no) = *reinterpret_cast<u32x2*>(o);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN>
+static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
+  const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
+  const size_t lds = 2 * (BM + BN) * BK * sizeof(T);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(tiles), dim3(256), lds, s, p);
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_igemm(const IGemmParams& p, int dtype, hipStream_t s) {
+  ETAINV_CHECK(p.a1 && p.w && p.out, "null pointer");
+  ETAINV_CHECK(p.M > 0 && p.N > 0 && (p.N % 4) == 0, "N must be a positive multiple of 4");
+  ETAINV_CHECK(p.c1 % BK == 0 && p.c2 % BK == 0 && (p.c1 + p.c2) > 0, "channel counts must be multiples of 64");
+  ETAINV_CHECK(p.taps == 1 || p.taps == 9, "taps must be 1 or 9");
+  ETAINV_CHECK(!p.geglu || (p.N % 128) == 0, "GEGLU needs N % 128 == 0");
+  ETAINV_CHECK(p.rows_per_batch > 0, "rows_per_batch");
+  ETAINV_CHECK(!p.rowvec || p.rowvec_stride >= p.N, "rowvec_stride");
+  // tile choice: big tiles when they still fill the 256 CUs, else 64x64 (GEGLU pairing is per wave tile,
+  // so the packing of a GEGLU weight fixes its tile: always 128 wide)
+  const int64_t big_tiles = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128);
+  const bool big = p.geglu || big_tiles >= 192;
+  if (big) {
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 128, 128>(p, s)));
+  } else {
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 64, 64>(p, s)));
+  }
+  return 0;
+}
+
+}  // namespace etainv

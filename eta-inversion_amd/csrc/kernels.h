@@ -1,0 +1,82 @@
+// Internal launcher interface between the UNet executor (engine.cpp) and the kernel files.
+#pragma once
+#include "common.h"
+
+namespace etainv {
+
+// ---- igemm.hip
+struct IGemmParams {
+  const void* a1 = nullptr;   // activations, NHWC [B][H][W][c1]
+  const void* a2 = nullptr;   // optional second source (channel concat), NHWC [B][H][W][c2]
+  const void* w = nullptr;    // weights [N][taps][c1+c2]
+  const float* bias = nullptr;      // [N] (physical column order)
+  const float* rowvec = nullptr;    // [batch][rowvec_stride] fp32, added per batch row (time-embedding projection)
+  int rowvec_stride = 0;
+  int out_f32 = 0;                  // store fp32 instead of T (time-embedding projections)
+  const void* residual = nullptr;   // [M][N]
+  void* out = nullptr;              // [M][N]  (or [M][N/2] with geglu)
+  int M = 0, N = 0;
+  int c1 = 0, c2 = 0;
+  int H = 1, W = 1;           // source spatial dims (before the fused upsample)
+  int Ho = 1, Wo = 1;         // output spatial dims
+  int stride = 1, ups = 0, taps = 1;
+  int geglu = 0;
+  int rows_per_batch = 1;     // Ho*Wo for convs; M/batch for linears
+};
+int launch_igemm(const IGemmParams& p, int dtype, hipStream_t s);
+
+// ---- norm.hip
+// GroupNorm(32 groups) over NHWC with optional second (concatenated) source and fused SiLU.
+// scratch: >= b * GN_CHUNKS_MAX * groups * 2 floats
+constexpr int GN_MAX_CHUNKS = 64;
+int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float* gamma, const float* beta, void* out,
+                     int b, int hw, int groups, float eps, int silu, float* scratch, int dtype, hipStream_t s);
+int launch_layernorm(const void* x, const float* gamma, const float* beta, void* out, int rows, int c, float eps, int dtype,
+                     hipStream_t s);
+
+// ---- attention.hip
+// self-attention modes: 0 plain; 1 ptp self-replace (cond target rows use Q,K of their source row);
+// 2 masactrl (target rows use K,V of their source row).  Modes 1/2 need the 4*n_img backward row layout.
+int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int heads, int d, int mode, int n_img, int dtype,
+                               hipStream_t s);
+struct CrossParams {
+  int N = 0, heads = 8, n_ctx = 77;
+  float scale_log2 = 0.f;
+  int layout = 0;      // 0: no roles (plain); 1: forward store layout [u x B, c x B] or [c x B]; 2: backward 4B layout
+  int n_img = 1;
+  int rows = 0;        // batch rows in this call
+  int edit = 0;        // ptp cross edit on cond target rows
+  int map_layer = -1;  // >= 0: accumulate cond-half probabilities into maps_acc layer `map_layer`
+  int n_img_cap = 1;
+  const int32_t* mapper = nullptr;
+  const float* alphas = nullptr;
+  const float* replace_mat = nullptr;
+  const float* equalizer = nullptr;
+  const float* cross_alpha = nullptr;
+  float* maps_acc = nullptr;
+};
+int launch_cross_attention_p(const void* q, const void* kv, void* out, int b, int d, const CrossParams& p, int dtype, hipStream_t s);
+
+// ---- misc.hip
+// conv_in: NCHW io-dtype latent [n_lat][4][L][L] (row r reads r % n_lat) -> NHWC T [rows][L*L][cout], 3x3 pad 1
+int launch_conv_in(const void* latent, int io_dtype, int n_lat, int rows, int L, const void* w, const float* bias, int cout,
+                   void* out, int dtype, hipStream_t s);
+// conv_out: NHWC T [rows][L*L][cin] (already GroupNorm+SiLU'd) -> NCHW io-dtype [rows][4][L][L]
+int launch_conv_out(const void* x, int rows, int L, int cin, const void* w, const float* bias, void* out, int io_dtype, int dtype,
+                    hipStream_t s);
+// sinusoidal timestep embedding (flip_sin_to_cos, freq_shift 0): t [rows] float -> [rows][dim] T
+int launch_time_embedding(const float* t, int rows, int dim, void* out, int dtype, hipStream_t s);
+// y = silu(x) elementwise on T
+int launch_silu(const void* x, void* out, int64_t n, int dtype, hipStream_t s);
+// cast fp32 -> T with optional row permutation (weights)
+int launch_pack_weight(const float* src, void* dst, int64_t rows, int64_t cols, int mode, int taps, int dtype, hipStream_t s);
+int launch_cast_f32(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, hipStream_t s);
+
+// ---- maps.hip
+int launch_word_maps(const float* maps_acc, int n_layers, int n_img_cap, int rows_per_img, int row_sel, int heads, int res, int L,
+                     int n_img, const int32_t* tokens, int n_tok, int steps_done, float* out, int accumulate, float scale,
+                     hipStream_t s);
+int launch_local_blend(const float* maps_acc, int n_layers, int n_img_cap, int heads, int res, int L, float* x, int n_img,
+                       const float* blend_alpha, float thres, hipStream_t s);
+
+}  // namespace etainv

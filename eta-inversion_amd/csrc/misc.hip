@@ -1,0 +1,191 @@
+// Small kernels around the UNet body: conv_in / conv_out (the only convolutions whose channel count is not
+// a multiple of 64; 0.03 % of the FLOPs), sinusoidal timestep embedding, SiLU, weight packing, dtype casts.
+#include "common.h"
+#include "kernels.h"
+
+namespace etainv {
+
+template <typename TIO>
+__device__ __forceinline__ float ld_io(const void* p, int64_t i) { return to_f32(reinterpret_cast<const TIO*>(p)[i]); }
+
+// conv_in: x NCHW [n_lat][4][L][L] (io type) -> out NHWC [rows][L*L][cout] (T); UNet row r reads latent r % n_lat.
+// w: fp32 [36 = (ky*3+kx)*4+ci][cout]; block (cout/8, PIX) threads, each thread 8 output channels of one pixel.
+template <typename T, typename TIO>
+__global__ void conv_in_kernel(const TIO* __restrict__ x, int n_lat, int L, const float* __restrict__ w, const float* __restrict__ bias,
+                               int cout, T* __restrict__ out, int pix_per_block) {
+  extern __shared__ float sw[];  // [36][cout]
+  const int nthr = blockDim.x * blockDim.y, tid = threadIdx.y * blockDim.x + threadIdx.x;
+  for (int i = tid; i < 36 * cout; i += nthr) sw[i] = w[i];
+  __syncthreads();
+  const int row = blockIdx.y, lat = row % n_lat;
+  const int LL = L * L;
+  const TIO* xb = x + (int64_t)lat * 4 * LL;
+  const int co = threadIdx.x * 8;
+  for (int it = threadIdx.y; it < pix_per_block; it += blockDim.y) {
+    const int pix = blockIdx.x * pix_per_block + it;
+    if (pix >= LL) break;
+    const int oy = pix / L, ox = pix - oy * L;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias[co + j];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = oy + ky - 1, ix = ox + kx - 1;
+        if (iy < 0 || iy >= L || ix < 0 || ix >= L) continue;
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+          const float v = to_f32(xb[(int64_t)ci * LL + iy * L + ix]);
+          const float* wr = sw + ((ky * 3 + kx) * 4 + ci) * cout + co;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += v * wr[j];
+        }
+      }
+    T o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = from_f32<T>(acc[j]);
+    *reinterpret_cast<u32x4*>(out + ((int64_t)row * LL + pix) * cout + co) = *reinterpret_cast<u32x4*>(o);
+  }
+}
+
+// conv_out: x NHWC [rows][L*L][cin] (T) -> out NCHW [rows][4][L][L] (io type).  w: fp32 [9][cin][4].
+// one wave per output pixel; lanes stride over (tap, 8-channel vector) pairs, then a wave reduction.
+template <typename T, typename TIO>
+__global__ void __launch_bounds__(256) conv_out_kernel(const T* __restrict__ x, int L, int cin, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, TIO* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int LL = L * L;
+  const int pix = blockIdx.x * 4 + wid;
+  const int row = blockIdx.y;
+  if (pix >= LL) return;
+  const int oy = pix / L, ox = pix - oy * L;
+  const int nvec = cin >> 3;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int idx = lane; idx < 9 * nvec; idx += 64) {
+    const int tap = idx / nvec, v = idx - tap * nvec;
+    const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+    if (iy < 0 || iy >= L || ix < 0 || ix >= L) continue;
+    u32x4 raw = *reinterpret_cast<const u32x4*>(x + ((int64_t)row * LL + iy * L + ix) * cin + v * 8);
+    const T* e = reinterpret_cast<const T*>(&raw);
+    const float* wr = w + ((int64_t)tap * cin + v * 8) * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = to_f32(e[j]);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) acc[o] += f * wr[j * 4 + o];
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) acc[o] = wave_sum(acc[o]);
+  if (lane < 4) out[((int64_t)row * 4 + lane) * LL + pix] = from_f32<TIO>(acc[lane] + bias[lane]);
+}
+
+template <typename T>
+__global__ void time_embedding_kernel(const float* __restrict__ t, int rows, int dim, T* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * dim) return;
+  const int r = i / dim, c = i - r * dim, half = dim / 2;
+  const int k = c < half ? c : c - half;
+  const float freq = expf(-9.210340371976184f * (float)k / (float)half);  // ln(10000)
+  const float a = t[r] * freq;
+  out[i] = from_f32<T>(c < half ? cosf(a) : sinf(a));
+}
+
+template <typename T>
+__global__ void silu_kernel(const T* x, T* out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = from_f32<T>(silu_f(to_f32(x[i])));
+}
+
+// weight packing (fp32 diffusers layout -> engine layout), one thread per destination element
+//   mode 0: [rows][cols] copy/cast
+//   mode 1: conv OIHW [rows=O][cols=I*taps] -> [O][tap][I]
+//   mode 2: GEGLU row interleave of a [rows=8c][cols] matrix: physical row p <- logical row
+//           (p%64 < 32 ? (p/64)*32 + p%64 : rows/2 + (p/64)*32 + p%64 - 32)
+//   mode 3: conv_in  [O][4][3][3] -> fp32-style [tap*4+ci][O]            (rows = O, cols = 36)
+//   mode 4: conv_out [4][I][3][3] -> [tap][I][4]                         (rows = 4, cols = I*9)
+template <typename TD>
+__global__ void pack_weight_kernel(const float* __restrict__ src, TD* __restrict__ dst, int64_t rows, int64_t cols, int mode, int taps) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  int64_t s = i;
+  if (mode == 1) {
+    const int64_t o = i / cols, r = i - o * cols, cin = cols / taps;
+    const int64_t t = r / cin, ci = r - t * cin;
+    s = o * cols + ci * taps + t;
+  } else if (mode == 2) {
+    const int64_t p = i / cols, c = i - p * cols;
+    const int64_t blk = p / 64, within = p % 64;
+    const int64_t logical = within < 32 ? blk * 32 + within : rows / 2 + blk * 32 + within - 32;
+    s = logical * cols + c;
+  } else if (mode == 3) {
+    const int64_t k = i / rows, o = i - k * rows;  // dst [36][O]
+    const int64_t tap = k / 4, ci = k - tap * 4;
+    s = o * 36 + ci * 9 + tap;
+  } else if (mode == 4) {
+    const int64_t cin = cols / 9;                  // dst [9][cin][4]
+    const int64_t tap = i / (cin * 4), r = i - tap * cin * 4, ci = r / 4, o = r - ci * 4;
+    s = o * cols + ci * 9 + tap;
+  }
+  dst[i] = from_f32<TD>(src[s]);
+}
+
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = from_f32<TD>(to_f32(src[i]));
+}
+
+int launch_conv_in(const void* latent, int io_dtype, int n_lat, int rows, int L, const void* w, const float* bias, int cout,
+                   void* out, int dtype, hipStream_t s) {
+  ETAINV_CHECK(latent && w && bias && out && n_lat > 0 && rows > 0 && cout % 8 == 0, "bad arguments");
+  const int ppb = 48;
+  dim3 block(cout / 8, std::max(1, 256 / (cout / 8)));
+  dim3 grid(cdiv(L * L, ppb), rows);
+  const size_t lds = (size_t)36 * cout * sizeof(float);
+  ETAINV_DISPATCH_HALF(dtype, T, ETAINV_DISPATCH_DTYPE(io_dtype, TIO,
+      hipLaunchKernelGGL((conv_in_kernel<T, TIO>), grid, block, lds, s, (const TIO*)latent, n_lat, L, (const float*)w, bias, cout, (T*)out, ppb)));
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_conv_out(const void* x, int rows, int L, int cin, const void* w, const float* bias, void* out, int io_dtype, int dtype,
+                    hipStream_t s) {
+  ETAINV_CHECK(x && w && bias && out && cin % 8 == 0, "bad arguments");
+  dim3 grid(cdiv(L * L, 4), rows);
+  ETAINV_DISPATCH_HALF(dtype, T, ETAINV_DISPATCH_DTYPE(io_dtype, TIO,
+      hipLaunchKernelGGL((conv_out_kernel<T, TIO>), grid, dim3(256), 0, s, (const T*)x, L, cin, (const float*)w, bias, (TIO*)out)));
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_time_embedding(const float* t, int rows, int dim, void* out, int dtype, hipStream_t s) {
+  ETAINV_CHECK(t && out && dim % 2 == 0, "bad arguments");
+  ETAINV_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL(time_embedding_kernel<T>, dim3(cdiv(rows * dim, 256)), dim3(256), 0, s, t, rows, dim, (T*)out));
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_silu(const void* x, void* out, int64_t n, int dtype, hipStream_t s) {
+  ETAINV_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL(silu_kernel<T>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const T*)x, (T*)out, n));
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_pack_weight(const float* src, void* dst, int64_t rows, int64_t cols, int mode, int taps, int dtype, hipStream_t s) {
+  ETAINV_CHECK(src && dst && rows > 0 && cols > 0, "bad arguments");
+  const int64_t n = rows * cols;
+  ETAINV_DISPATCH_DTYPE(dtype, TD, hipLaunchKernelGGL(pack_weight_kernel<TD>, dim3(cdiv(n, 256)), dim3(256), 0, s, src, (TD*)dst, rows, cols, mode, taps));
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_cast_f32(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, hipStream_t s) {
+  ETAINV_DISPATCH_DTYPE(src_dtype, TS, ETAINV_DISPATCH_DTYPE(dst_dtype, TD,
+      hipLaunchKernelGGL((cast_kernel<TS, TD>), dim3(cdiv(n, 256)), dim3(256), 0, s, (const TS*)src, (TD*)dst, n)));
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace etainv

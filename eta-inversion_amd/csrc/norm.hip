@@ -1,0 +1,216 @@
+// GroupNorm(32)(+SiLU) and LayerNorm for NHWC activations -- HBM-bound kernels (SURVEY App. A.4:
+// 61 GroupNorms + 48 LayerNorms per UNet forward).  16-byte vector loads, wave64 shuffle reductions,
+// fixed-order partial sums (bitwise reproducible, no float atomics).
+//
+// GroupNorm runs as stats -> finalize -> apply.  The stats/apply kernels read up to two source tensors so
+// the decoder's torch.cat([x, skip], dim=1) is consumed in place; `apply` writes the concatenated,
+// normalised (and SiLU'd) tensor that feeds the following 3x3 convolution.
+#include "common.h"
+#include "kernels.h"
+
+namespace etainv {
+
+constexpr int GN_MAX_VEC_PER_LANE = 5;  // C <= 2560 -> 320 vectors of 8 channels -> 5 per lane
+
+template <typename T> struct Vec8;
+template <> struct Vec8<f16> { typedef f16x8 type; };
+template <> struct Vec8<bf16> { typedef bf16x8 type; };
+
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&v)[8]) {
+  typename Vec8<T>::type r = *reinterpret_cast<const typename Vec8<T>::type*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (float)r[j];
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float (&v)[8]) {
+  typename Vec8<T>::type r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (T)v[j];
+  *reinterpret_cast<typename Vec8<T>::type*>(p) = r;
+}
+
+// grid (chunks, B); 256 threads = 4 waves; wave w takes pixels beg+w, beg+w+4, ...; lane l owns channel
+// vectors l, l+64, ... so per-channel sums stay in registers across pixels.
+template <typename T>
+__global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x1, const T* __restrict__ x2, int c1, int c2, int hw,
+                                                       int groups, float* __restrict__ partial) {
+  const int C = c1 + c2, nvec = C >> 3, nv1 = c1 >> 3, cpg = C / groups;
+  const int b = blockIdx.y, chunks = gridDim.x;
+  const int per = (hw + chunks - 1) / chunks;
+  const int beg = blockIdx.x * per, end = min(hw, beg + per);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float s[GN_MAX_VEC_PER_LANE][8], q[GN_MAX_VEC_PER_LANE][8];
+#pragma unroll
+  for (int i = 0; i < GN_MAX_VEC_PER_LANE; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[i][j] = q[i][j] = 0.f;
+  for (int pix = beg + wid; pix < end; pix += 4) {
+    const int64_t row = (int64_t)b * hw + pix;
+#pragma unroll
+    for (int i = 0; i < GN_MAX_VEC_PER_LANE; ++i) {
+      const int v = lane + 64 * i;
+      if (v < nvec) {
+        float t[8];
+        if (v < nv1) load8(x1 + row * c1 + v * 8, t);
+        else load8(x2 + row * c2 + (v - nv1) * 8, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[i][j] += t[j]; q[i][j] += t[j] * t[j]; }
+      }
+    }
+  }
+  extern __shared__ float sm[];  // [4][C][2]
+#pragma unroll
+  for (int i = 0; i < GN_MAX_VEC_PER_LANE; ++i) {
+    const int v = lane + 64 * i;
+    if (v < nvec) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sm[((wid * C) + v * 8 + j) * 2 + 0] = s[i][j];
+        sm[((wid * C) + v * 8 + j) * 2 + 1] = q[i][j];
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < groups) {
+    const int g = threadIdx.x;
+    float a = 0.f, c = 0.f;
+    for (int w = 0; w < 4; ++w)
+      for (int ch = g * cpg; ch < (g + 1) * cpg; ++ch) {
+        a += sm[(w * C + ch) * 2 + 0];
+        c += sm[(w * C + ch) * 2 + 1];
+      }
+    float* p = partial + (((int64_t)b * chunks + blockIdx.x) * groups + g) * 2;
+    p[0] = a;
+    p[1] = c;
+  }
+}
+
+// grid B, block 64: (mean, rstd) per (b, group); partial -> stats [B][groups][2] placed after the partials
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, int chunks, int groups, float count, float eps,
+                                   float* __restrict__ stats) {
+  const int b = blockIdx.x, g = threadIdx.x;
+  if (g >= groups) return;
+  double a = 0.0, c = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    const float* p = partial + (((int64_t)b * chunks + k) * groups + g) * 2;
+    a += p[0];
+    c += p[1];
+  }
+  double mean = a / count;
+  double var = c / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[(b * groups + g) * 2 + 0] = (float)mean;
+  stats[(b * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x1, const T* __restrict__ x2, int c1, int c2, int hw,
+                                                       int groups, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int silu, T* __restrict__ out, int64_t total_vec) {
+  const int C = c1 + c2, nvec = C >> 3, nv1 = c1 >> 3, cpg = C / groups;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total_vec; i += stride) {
+    const int64_t row = i / nvec;
+    const int v = (int)(i - row * nvec);
+    const int b = (int)(row / hw);
+    float t[8];
+    if (v < nv1) load8(x1 + row * c1 + v * 8, t);
+    else load8(x2 + row * c2 + (v - nv1) * 8, t);
+    const float* st = stats + (int64_t)b * groups * 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = v * 8 + j;
+      const int g = ch / cpg;
+      float y = (t[j] - st[g * 2]) * st[g * 2 + 1] * gamma[ch] + beta[ch];
+      t[j] = silu ? silu_f(y) : y;
+    }
+    store8(out + row * C + v * 8, t);
+  }
+}
+
+// one wave per row, row kept in registers (C <= 1536), exact two-pass mean/variance
+template <typename T>
+__global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ out, int rows, int C,
+                                                        float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nvec = C >> 3;
+  float t[3][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int v = lane + 64 * i;
+    if (v < nvec) {
+      load8(x + (int64_t)row * C + v * 8, t[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += t[i][j];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int v = lane + 64 * i;
+    if (v < nvec) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float d = t[i][j] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int v = lane + 64 * i;
+    if (v < nvec) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (t[i][j] - mean) * rstd * gamma[v * 8 + j] + beta[v * 8 + j];
+      store8(out + (int64_t)row * C + v * 8, o);
+    }
+  }
+}
+
+int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float* gamma, const float* beta, void* out, int b,
+                     int hw, int groups, float eps, int silu, float* scratch, int dtype, hipStream_t s) {
+  const int C = c1 + c2;
+  ETAINV_CHECK(x1 && gamma && beta && out && scratch, "null pointer");
+  ETAINV_CHECK(c1 % 8 == 0 && c2 % 8 == 0 && C % groups == 0 && groups <= 64, "channel layout");
+  ETAINV_CHECK((C >> 3) <= 64 * GN_MAX_VEC_PER_LANE, "C too large");
+  ETAINV_CHECK(c2 == 0 || x2, "second source missing");
+  int chunks = std::min(GN_MAX_CHUNKS, std::max(1, std::min(hw / 8, 1024 / std::max(1, b))));
+  float* partial = scratch;
+  float* stats = scratch + (int64_t)b * GN_MAX_CHUNKS * groups * 2;
+  const size_t lds = (size_t)4 * C * 2 * sizeof(float);
+  const int64_t total_vec = (int64_t)b * hw * (C >> 3);
+  const int grid_apply = (int)std::min<int64_t>(cdiv(total_vec, 256), 8192);
+  ETAINV_DISPATCH_HALF(
+      dtype, T,
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_stats_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2560 * 2 * 4);
+        attr = true;
+      }
+      hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks, b), dim3(256), lds, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups, partial);
+      hipLaunchKernelGGL(gn_finalize_kernel, dim3(b), dim3(64), 0, s, partial, chunks, groups, (float)hw * (float)(C / groups), eps, stats);
+      hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(grid_apply), dim3(256), 0, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups, stats,
+                         gamma, beta, silu, (T*)out, total_vec));
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_layernorm(const void* x, const float* gamma, const float* beta, void* out, int rows, int c, float eps, int dtype,
+                     hipStream_t s) {
+  ETAINV_CHECK(x && gamma && beta && out, "null pointer");
+  ETAINV_CHECK(c % 8 == 0 && (c >> 3) <= 192, "LayerNorm width must be a multiple of 8 and <= 1536");
+  ETAINV_DISPATCH_HALF(dtype, T,
+                       hipLaunchKernelGGL(layernorm_kernel<T>, dim3(cdiv(rows, 4)), dim3(256), 0, s, (const T*)x, gamma, beta,
+                                          (T*)out, rows, c, eps));
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace etainv

@@ -1,0 +1,178 @@
+/* etainv.h -- C ABI of the MI355X-native Eta-Inversion engine (libetainv_hip.so).
+ *
+ * This is the drop-in boundary for the hot path named by BASELINE.json `north_star`: the
+ * forward (DDIM inversion) / backward (eta-sampling) loop of furiosa-ai/eta-inversion's `etainv`
+ * with the simple / prompt-to-prompt / MasaCtrl editors on an SD1.x UNet.  Every entry point
+ * cites the reference interface it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / C++ types.  All tensor pointers are DEVICE pointers
+ *     unless the parameter is documented as host.  Tensors are contiguous, NCHW where spatial.
+ *   - `stream` is a hipStream_t passed as void* (e.g. torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued on it, no hidden synchronisation, no per-call allocation.
+ *   - ownership: the caller owns every buffer it passes; the library never frees or retains it
+ *     past the call.  The engine handle owns its weights, workspace and attention-map store.
+ *   - errors: every function returns 0 on success, non-zero otherwise; a thread-local message
+ *     is available from etainv_last_error().  No C++ exception crosses the ABI.
+ *   - threading: a handle is not thread-safe (the reference is single-threaded, one stream).
+ *   - batch layout for B image pairs ("n_img"):  latents of the backward pass are 2*B rows
+ *     [src_0..src_{B-1}, tgt_0..tgt_{B-1}]; UNet rows / contexts are 4*B rows
+ *     [u_src x B, u_tgt x B, c_src x B, c_tgt x B].  With B = 1 this is exactly the reference's
+ *     [u_s, u_t, c_s, c_t] (modules/inversion/diffusion_inversion.py:462-479).
+ */
+#ifndef ETAINV_H
+#define ETAINV_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ETAINV_ABI_VERSION 1
+#define ETAINV_MAX_WORDS 77
+
+enum etainv_dtype { ETAINV_F32 = 0, ETAINV_F16 = 1, ETAINV_BF16 = 2 };
+
+int etainv_abi_version(void);
+const char* etainv_last_error(void);
+
+/* ---------------------------------------------------------------- elementwise step kernels
+ * (usable without an engine handle; io_dtype is the element type of every tensor argument) */
+
+/* eps = eps_u + g * (eps_c - eps_u).  Replaces the CFG combine of EtaInversion.predict_noise
+ * (modules/inversion/eta_inversion.py:328). n = element count. */
+int etainv_cfg_combine(const void* eps_u, const void* eps_c, float g, void* out, int64_t n,
+                       int io_dtype, void* stream);
+
+/* x' = sqrt(a_to) * (x - sqrt(1-a_from) eps)/sqrt(a_from) + sqrt(1-a_to) eps.
+ * Replaces DDIMInverseScheduler.ddim_step (modules/inverse_schedulers/scheduling_ddim_inverse.py:71-100);
+ * a_from/a_to are the alphas_cumprod the host looked up (clamp/negative rule :85-92). */
+int etainv_ddim_step(const void* x, const void* eps, float a_from, float a_to, void* out, int64_t n,
+                     int io_dtype, void* stream);
+
+/* Fused backward step of EtaInversion.predict_step_backward (modules/inversion/eta_inversion.py:207-273)
+ * for n_img independent (src,tgt) pairs, everything after the UNet call:
+ *   CFG combine (:328) -> best-of-n variance noise on the source row (:330-375, argmin on device, NaN counts
+ *   as minimal like torch.argmin) -> per-pixel eta = 1[mask_map > thres] * eta (:159-205,:236-243) ->
+ *   DDIM-eta update of both rows ([3P] DDIMScheduler.step as called at :245) -> source row replay
+ *   x_src += (x_prev_src - x_src) (:247-249; exact assignment when use_mask == 0, :260-261).
+ * x        [2*n_img][chw]   current latents (rows src.., tgt..)
+ * eps_all  [4*n_img][chw]   UNet output rows [u_s.., u_t.., c_s.., c_t..]
+ * x_prev_src [n_img][chw]   stored inversion latent latents[-(k+2)] (:291)
+ * noise    [n_cand][chw]    candidates drawn by sample_variance_noise (:145-156), shared by all images
+ * mask_map [n_img][hw]      forward-pass mean attention map of the source edit word (may be NULL if !use_mask)
+ * a_t, a_p, var             alphas_cumprod[t], alphas_cumprod[t-Delta] (or final), _get_variance(t, t-Delta)
+ * out_x    [2*n_img][chw]   new latents;  out_eps [2*n_img][chw] guided noise (may be NULL)
+ * best_idx [n_img] int32, losses [n_img][n_cand] float (device, may be NULL); scratch: >= n_img*16*64 floats */
+int etainv_eta_backward_step(const void* x, const void* eps_all, float g, const void* x_prev_src,
+                             const void* noise, int n_cand, float eta, const void* mask_map, float mask_thres,
+                             int use_mask, float a_t, float a_p, float var, int n_img, int c, int hw,
+                             void* out_x, void* out_eps, int32_t* best_idx, float* losses, float* scratch,
+                             int io_dtype, void* stream);
+
+/* ---------------------------------------------------------------- engine */
+typedef struct etainv_engine etainv_engine_t;
+
+typedef struct etainv_engine_config {
+  int compute_dtype;      /* ETAINV_F16 or ETAINV_BF16: MFMA operand type (fp32 accumulate)            */
+  int max_unet_batch;     /* largest number of UNet rows per call (4 * n_img for the backward pass)      */
+  int latent_size;        /* L: 64 for 512x512, 96 for 768x768; multiple of 8                           */
+  int max_img;            /* largest n_img (attention-map store is sized for it)                        */
+  int reserved[4];
+} etainv_engine_config;
+
+int etainv_engine_create(const etainv_engine_config* cfg, etainv_engine_t** out);
+int etainv_engine_destroy(etainv_engine_t* e);
+
+/* Weights: the engine enumerates the SD1.x UNet parameters under their diffusers state-dict names
+ * (what `model.unet` holds in the reference, modules/models/__init__.py:135).  The caller uploads each as a
+ * contiguous fp32 DEVICE buffer in diffusers layout; the engine converts / re-lays-out on `stream`. */
+int etainv_engine_num_weights(etainv_engine_t* e);
+int etainv_engine_weight_info(etainv_engine_t* e, int i, char* name, int name_cap, int64_t shape[4], int* ndim);
+int etainv_engine_set_weight(etainv_engine_t* e, const char* name, const float* data, int64_t numel, void* stream);
+int etainv_engine_weights_ready(etainv_engine_t* e); /* 1 when every parameter has been set */
+
+/* Declarative attention control for one UNet call: replaces the per-layer Python callbacks installed by
+ * register_attention_control (modules/utils/ptp_utils.py:196-302) and register_attention_editor_diffusers
+ * (modules/utils/masactrl_utils.py:74-153).  Device pointers; per-image tables have n_img rows. */
+enum etainv_attn_mode { ETAINV_ATTN_PLAIN = 0, ETAINV_ATTN_STORE = 1, ETAINV_ATTN_PTP = 2, ETAINV_ATTN_MASA = 3 };
+
+typedef struct etainv_attn_ctrl {
+  int mode;
+  int n_img;
+  /* STORE / PTP: accumulate the cond-half cross-attention probabilities of the (L/4)^2-token layers
+   * (AttentionStore, modules/utils/ptp.py:143-183) into the engine's map store. */
+  int store_maps;
+  /* PTP cross edit (AttentionControlEdit.forward, modules/utils/ptp.py:205-218; Refine :245-258; Reweight
+   * :261-274; Replace :234-242).  cross_alpha is the row of cross_replace_alpha for the current step. */
+  const int32_t* mapper;      /* [n_img][77] or NULL */
+  const float* alphas;        /* [n_img][77] or NULL */
+  const float* replace_mat;   /* [n_img][77][77] or NULL (AttentionReplace) */
+  const float* equalizer;     /* [n_img][77] or NULL */
+  const float* cross_alpha;   /* [n_img][77] */
+  /* PTP self edit: target probabilities := source probabilities when active and N <= self_max_tokens */
+  int self_replace_active;
+  int self_max_tokens;        /* 32^2 at L = 64 (modules/utils/ptp.py:226) */
+  /* MASA: mutual self-attention active for transformer blocks >= masa_first_block (cur_att_layer // 2) */
+  int masa_active;
+  int masa_first_block;
+  int reserved[4];
+} etainv_attn_ctrl;
+
+/* eps = UNet(latent, t, ctx).  Replaces `self.unet(latent_input, t, encoder_hidden_states=context)["sample"]`
+ * (modules/inversion/eta_inversion.py:321).
+ * latent  [n_lat][4][L][L]  io_dtype; UNet row r reads latent row r % n_lat (torch.cat([latent]*2), :320)
+ * t_host  [n_rows] int64 HOST timesteps (one per UNet row)
+ * ctx     [n_rows][77][768] io_dtype
+ * out     [n_rows][4][L][L] io_dtype */
+int etainv_unet_forward(etainv_engine_t* e, const void* latent, int n_lat, const int64_t* t_host, const void* ctx,
+                        int n_rows, const etainv_attn_ctrl* ctrl, void* out, int io_dtype, void* stream);
+
+/* Attention-map store (AttentionStore.attention_store restricted to what the default path reads:
+ * the five (L/4)^2 cross layers; modules/utils/ptp.py:37-39, 288-303). */
+int etainv_maps_reset(etainv_engine_t* e, void* stream);
+
+/* Forward-pass word maps (ControllerAttentionStorePerStep.end_step, modules/inversion/eta_inversion.py:44-49;
+ * get_attention_map, modules/editing/ptp_editor.py:43-85): for each image and each of n_tok token indices,
+ * mean over the 40 head-layers of (store / steps_done), / max, bicubic -> LxL, clamp[0,1].
+ * tokens [n_img][n_tok] int32 device.  out [n_img][n_tok][L][L] float: written (accumulate == 0) or
+ * accumulated with weight `scale` (accumulate == 1; scale = 1/S gives the "fwd_mean" map, :392-396). */
+int etainv_maps_word_maps(etainv_engine_t* e, int n_img, const int32_t* tokens, int n_tok, int steps_done,
+                          float* out, int accumulate, float scale, void* stream);
+
+/* LocalBlend (modules/utils/ptp.py:18-47) on the backward latents x [2*n_img][4][L][L] (in place, fp32):
+ * blend_alpha [n_img][2][77] selects the blend-word tokens of (source, target) prompt. */
+int etainv_local_blend(etainv_engine_t* e, float* x, int n_img, const float* blend_alpha, float thres, void* stream);
+
+/* Workspace statistics for DESIGN.md / bench (bytes). */
+int64_t etainv_engine_workspace_bytes(etainv_engine_t* e);
+int64_t etainv_engine_weight_bytes(etainv_engine_t* e);
+
+/* Per-op entry points used by the parity tests (tests/test_kernels_gpu.py) -- the same launchers the
+ * executor uses, exposed so every kernel is checked against a plain fp32 reference in isolation.
+ * Activations NHWC in the compute dtype; weights in the engine layouts described in DESIGN.md. */
+int etainv_op_gemm(const void* a, const void* w, const void* bias, const void* residual, void* out,
+                   int m, int n, int k, int geglu, int dtype, void* stream);
+int etainv_op_conv3x3(const void* x_nhwc, const void* x2_nhwc, int c1, int c2, const void* w_okkc, const void* bias,
+                      const float* rowvec, const void* residual, void* out, int b, int h, int wd, int cout,
+                      int stride, int upsample, int taps, int dtype, void* stream);
+int etainv_op_groupnorm(const void* x_nhwc, const void* x2_nhwc, int c1, int c2, const float* gamma,
+                        const float* beta, void* out, int b, int hw, int groups, float eps, int silu,
+                        float* scratch, int dtype, void* stream);
+int etainv_op_layernorm(const void* x, const float* gamma, const float* beta, void* out, int rows, int c,
+                        float eps, int dtype, void* stream);
+/* mode 0 plain, 1 ptp self-replace, 2 masactrl (modes 1/2: b == 4*n_img rows [u_s,u_t,c_s,c_t]) */
+int etainv_op_self_attention(const void* qkv, void* out, int b, int n, int heads, int d, int mode, int n_img,
+                             int dtype, void* stream);
+int etainv_op_cross_attention(const void* q, const void* kv, void* out, int b, int n, int heads, int d,
+                              int n_ctx, const etainv_attn_ctrl* ctrl, int map_layer, int n_img_cap,
+                              float* maps_acc, int dtype, void* stream);
+int etainv_op_word_maps(const float* maps_acc, int n_layers, int n_img_cap, int heads, int res, int L, int n_img,
+                        const int32_t* tokens, int n_tok, int steps_done, float* out, int accumulate, float scale,
+                        void* stream);
+int etainv_op_local_blend(const float* maps_acc, int n_layers, int n_img_cap, int heads, int res, int L, float* x,
+                          int n_img, const float* blend_alpha, float thres, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ETAINV_H */

@@ -1,0 +1,401 @@
+"""Per-kernel parity on a real MI355X: every HIP kernel, called through the C ABI (libetainv_hip.so), against a
+plain PyTorch fp32 reference of the same op / the CPU oracle / the golden vectors.
+Tolerances: relative L2 error <= 2e-3 for fp16 operands, <= 1.2e-2 for bf16 (8 significant bits), both with
+fp32 accumulation; elementwise step kernels run in fp32 and must match to 1e-5."""
+import ctypes as C
+import json
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.bfloat16]
+TOL = {torch.float16: 2e-3, torch.bfloat16: 1.2e-2}
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from etainv import _capi
+    _capi.load()
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return _capi
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+
+
+# ----------------------------------------------------------------------------------------- step kernels
+def test_cfg_and_ddim_step(capi):
+    from oracle import schedule as sch
+    lib = capi.load()
+    n = 2 * 4 * 64 * 64
+    u, c = rnd(n, seed=1), rnd(n, seed=2)
+    out = torch.empty_like(u)
+    capi.check(lib.etainv_cfg_combine(capi.ptr(u), capi.ptr(c), 7.5, capi.ptr(out), n, capi.F32, capi.stream_ptr()))
+    torch.testing.assert_close(out, u + 7.5 * (c - u), rtol=1e-6, atol=1e-6)
+    ac = sch.alphas_cumprod()
+    for t in (0, 20, 500, 980):
+        a_from, a_to = sch.ddim_inverse_coeffs(ac, t, 50)
+        capi.check(lib.etainv_ddim_step(capi.ptr(u), capi.ptr(c), a_from, a_to, capi.ptr(out), n, capi.F32, capi.stream_ptr()))
+        ref = sch.ddim_step(u.cpu().double(), c.cpu().double(), a_from, a_to)
+        torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+    # empty input is a no-op
+    capi.check(lib.etainv_cfg_combine(capi.ptr(u), capi.ptr(c), 7.5, capi.ptr(out), 0, capi.F32, capi.stream_ptr()))
+    # fp16 io
+    uh, ch = u.half(), c.half()
+    oh = torch.empty_like(uh)
+    capi.check(lib.etainv_cfg_combine(capi.ptr(uh), capi.ptr(ch), 7.5, capi.ptr(oh), n, capi.F16, capi.stream_ptr()))
+    torch.testing.assert_close(oh.float(), uh.float() + 7.5 * (ch.float() - uh.float()), rtol=2e-3, atol=2e-3)
+
+
+def _eta_step(capi, x, eps_all, g, x_prev, noise, eta, mask_map, use_mask, ac, t, S, n_img):
+    from oracle import schedule as sch
+    lib = capi.load()
+    p = t - 1000 // S
+    a_t = float(ac[t])
+    a_p = float(ac[p]) if p >= 0 else float(ac[0])
+    var = sch.variance(ac, t, S)
+    c, hw = x.shape[1], x.shape[2] * x.shape[3]
+    out_x, out_eps = torch.empty_like(x), torch.empty_like(x)
+    best = torch.zeros(n_img, dtype=torch.int32, device="cuda")
+    losses = torch.zeros(n_img, noise.shape[0], dtype=torch.float32, device="cuda")
+    scratch = torch.zeros(n_img * 16 * 64, dtype=torch.float32, device="cuda")
+    capi.check(lib.etainv_eta_backward_step(capi.ptr(x), capi.ptr(eps_all), g, capi.ptr(x_prev), capi.ptr(noise), noise.shape[0],
+                                            eta, capi.ptr(mask_map) if mask_map is not None else None, 0.2, int(use_mask), a_t, a_p,
+                                            var, n_img, c, hw, capi.ptr(out_x), capi.ptr(out_eps), capi.ptr(best), capi.ptr(losses),
+                                            capi.ptr(scratch), capi.dtype_code(x.dtype), capi.stream_ptr()))
+    return out_x, out_eps, best, losses
+
+
+@pytest.mark.parametrize("name", ["lin_t980", "lin_t0", "paper_t600", "paper_t620", "paper_t980", "paper_t980_nomask"])
+def test_eta_backward_step_vs_reference_golden(capi, golden, name):
+    """Same seeded inputs the reference's predict_step_backward was run on (tests/golden/make_golden.py)."""
+    from oracle import schedule as sch
+    from tests.golden import recipes
+    g = golden("eta_step")
+    eta_spec, t, fp16, use_mask = recipes.ETA_CASES[name]
+    inp = recipes.eta_case_inputs(name)
+    assert [recipes.crc(inp[k]) for k in ("latent", "unet_out", "src_prev", "mask_map", "noise")] == list(g[f"{name}/crc"])
+    eta = float(sch.eta_table(eta_spec)[t])
+    x = inp["latent"].float().cuda()
+    out_x, out_eps, best, losses = _eta_step(capi, x, inp["unet_out"].float().cuda(), 7.5, inp["src_prev"].float().cuda(),
+                                             inp["noise"].float().reshape(10, 4, 64, 64).cuda(), eta,
+                                             inp["mask_map"].float().cuda(), use_mask, sch.alphas_cumprod(), t, 50, 1)
+    assert int(best[0]) == int(g[f"{name}/best"])
+    gl = g[f"{name}/losses"]
+    if np.isfinite(gl).all():
+        np.testing.assert_allclose(losses[0].cpu().numpy(), gl, rtol=2e-4)
+    np.testing.assert_allclose(out_x.cpu().numpy(), g[f"{name}/new"], rtol=1e-4, atol=5e-5)
+
+
+def test_eta_backward_step_batched_images(capi):
+    """n_img = 3 pairs in the [src.., tgt..] / [u_s.., u_t.., c_s.., c_t..] layout == three B=1 calls."""
+    from oracle import schedule as sch
+    ac = sch.alphas_cumprod()
+    B, L = 3, 32
+    x = rnd(2 * B, 4, L, L, seed=3)
+    eps = rnd(4 * B, 4, L, L, seed=4)
+    xp = rnd(B, 4, L, L, seed=5)
+    noise = rnd(10, 4, L, L, seed=6)
+    mask = torch.rand(B, L, L, generator=torch.Generator().manual_seed(7)).cuda()
+    ox, oe, best, _ = _eta_step(capi, x, eps, 7.5, xp, noise, 0.3, mask, True, ac, 500, 50, B)
+    for i in range(B):
+        xi = torch.stack([x[i], x[B + i]])
+        ei = torch.stack([eps[i], eps[B + i], eps[2 * B + i], eps[3 * B + i]])
+        o1, e1, b1, _ = _eta_step(capi, xi, ei, 7.5, xp[i:i + 1].contiguous(), noise, 0.3, mask[i:i + 1].contiguous(), True, ac, 500, 50, 1)
+        assert int(b1[0]) == int(best[i])
+        assert torch.equal(o1[0], ox[i]) and torch.equal(o1[1], ox[B + i])
+
+
+# ----------------------------------------------------------------------------------------- GEMM / conv
+def pack_geglu(w):
+    """row interleave used by the GEGLU epilogue (csrc/misc.hip pack mode 2)."""
+    rows = w.shape[0]
+    p = torch.arange(rows)
+    blk, within = p // 64, p % 64
+    logical = torch.where(within < 32, blk * 32 + within, rows // 2 + blk * 32 + within - 32)
+    return w[logical]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,n,k", [(4096, 320, 320), (154, 640, 768), (8192, 960, 320), (64, 1280, 1280), (2, 1280, 320),
+                                   (1024, 1280, 5120), (300, 2560, 1280)])
+def test_gemm(capi, dtype, m, n, k):
+    lib = capi.load()
+    a, w = rnd(m, k, seed=1, dtype=dtype), rnd(n, k, seed=2, scale=k ** -0.5, dtype=dtype)
+    bias, res = rnd(n, seed=3), rnd(m, n, seed=4, dtype=dtype)
+    out = torch.empty(m, n, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_gemm(capi.ptr(a), capi.ptr(w), capi.ptr(bias), capi.ptr(res), capi.ptr(out), m, n, k, 0,
+                                  capi.dtype_code(dtype), capi.stream_ptr()))
+    ref = a.float() @ w.float().t() + bias + res.float()
+    assert relerr(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_geglu(capi, dtype):
+    lib = capi.load()
+    m, c = 1024, 320
+    a, w = rnd(m, c, seed=1, dtype=dtype), rnd(8 * c, c, seed=2, scale=c ** -0.5, dtype=dtype)
+    bias = rnd(8 * c, seed=3)
+    out = torch.empty(m, 4 * c, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_gemm(capi.ptr(a), capi.ptr(pack_geglu(w.cpu()).cuda().contiguous()), capi.ptr(pack_geglu(bias.cpu()).cuda().contiguous()),
+                                  None, capi.ptr(out), m, 8 * c, c, 1, capi.dtype_code(dtype), capi.stream_ptr()))
+    h = a.float() @ w.float().t() + bias
+    ref = h[:, :4 * c] * F.gelu(h[:, 4 * c:])
+    assert relerr(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [dict(b=2, h=32, c1=320, c2=0, cout=320, stride=1, ups=0),
+                                 dict(b=2, h=16, c1=640, c2=0, cout=640, stride=2, ups=0),
+                                 dict(b=1, h=16, c1=640, c2=0, cout=640, stride=1, ups=1),
+                                 dict(b=2, h=16, c1=640, c2=320, cout=320, stride=1, ups=0),
+                                 dict(b=3, h=8, c1=1280, c2=1280, cout=1280, stride=1, ups=0),
+                                 dict(b=1, h=12, c1=320, c2=0, cout=64, stride=1, ups=0)])
+def test_conv3x3(capi, dtype, cfg):
+    lib = capi.load()
+    b, h, c1, c2, cout = cfg["b"], cfg["h"], cfg["c1"], cfg["c2"], cfg["cout"]
+    cin = c1 + c2
+    x = rnd(b, cin, h, h, seed=1, dtype=dtype)                              # NCHW reference input
+    w = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5, dtype=dtype)
+    bias = rnd(cout, seed=3)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if cfg["ups"] else x.float()
+    ref = F.conv2d(xin, w.float(), bias, stride=cfg["stride"], padding=1)
+    ho = ref.shape[-1]
+    rowvec = rnd(b, cout, seed=5)
+    res = rnd(b, ho, ho, cout, seed=6, dtype=dtype)
+    ref = ref + rowvec[:, :, None, None] + res.float().permute(0, 3, 1, 2)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    x1 = x_nhwc[..., :c1].contiguous()
+    x2 = x_nhwc[..., c1:].contiguous() if c2 else None
+    w_p = w.permute(0, 2, 3, 1).contiguous()                                 # [O][ky][kx][I]
+    out = torch.empty(b, ho, ho, cout, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_conv3x3(capi.ptr(x1), capi.ptr(x2), c1, c2, capi.ptr(w_p), capi.ptr(bias), capi.ptr(rowvec), capi.ptr(res),
+                                     capi.ptr(out), b, h, h, cout, cfg["stride"], cfg["ups"], 9, capi.dtype_code(dtype), capi.stream_ptr()))
+    assert relerr(out.permute(0, 3, 1, 2), ref) < TOL[dtype]
+
+
+# ----------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,hw,c1,c2,silu", [(2, 1024, 320, 0, 1), (3, 256, 1280, 640, 1), (1, 4096, 640, 320, 1), (2, 64, 1280, 1280, 1),
+                                             (2, 256, 640, 0, 0), (1, 144, 320, 0, 1)])
+def test_groupnorm(capi, dtype, b, hw, c1, c2, silu):
+    lib = capi.load()
+    C_ = c1 + c2
+    x = (rnd(b, hw, C_, seed=1) * 1.5 + 0.3).to(dtype)
+    gamma, beta = rnd(C_, seed=2) * 0.1 + 1, rnd(C_, seed=3) * 0.1
+    x1 = x[..., :c1].contiguous()
+    x2 = x[..., c1:].contiguous() if c2 else None
+    out = torch.empty(b, hw, C_, dtype=dtype, device="cuda")
+    scratch = torch.zeros(b * 65 * 32 * 2, dtype=torch.float32, device="cuda")
+    eps = 1e-5 if silu else 1e-6
+    capi.check(lib.etainv_op_groupnorm(capi.ptr(x1), capi.ptr(x2), c1, c2, capi.ptr(gamma), capi.ptr(beta), capi.ptr(out), b, hw, 32, eps,
+                                       silu, capi.ptr(scratch), capi.dtype_code(dtype), capi.stream_ptr()))
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    assert relerr(out, ref.permute(0, 2, 1)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,c", [(4096, 320), (1023, 640), (130, 1280)])
+def test_layernorm(capi, dtype, rows, c):
+    lib = capi.load()
+    x = (rnd(rows, c, seed=1) * 2 + 0.5).to(dtype)
+    gamma, beta = rnd(c, seed=2) * 0.1 + 1, rnd(c, seed=3) * 0.1
+    out = torch.empty_like(x)
+    capi.check(lib.etainv_op_layernorm(capi.ptr(x), capi.ptr(gamma), capi.ptr(beta), capi.ptr(out), rows, c, 1e-5, capi.dtype_code(dtype),
+                                       capi.stream_ptr()))
+    assert relerr(out, F.layer_norm(x.float(), (c,), gamma, beta, 1e-5)) < TOL[dtype]
+
+
+# ----------------------------------------------------------------------------------------- attention
+def ref_self_attention(qkv, heads, qmap=None, kmap=None, vmap=None):
+    b, n, c3 = qkv.shape
+    c = c3 // 3
+    d = c // heads
+    q, k, v = qkv.float().split(c, dim=-1)
+    idx = torch.arange(b)
+    q = q[idx if qmap is None else qmap]
+    k = k[idx if kmap is None else kmap]
+    v = v[idx if vmap is None else vmap]
+    sp = lambda t: t.reshape(b, n, heads, d).permute(0, 2, 1, 3)
+    a = (sp(q) @ sp(k).transpose(-1, -2) * d ** -0.5).softmax(-1)
+    return (a @ sp(v)).permute(0, 2, 1, 3).reshape(b, n, c)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,d", [(4096, 40), (1024, 80), (256, 160), (64, 160), (144, 160), (576, 80)])
+def test_self_attention_plain(capi, dtype, n, d):
+    lib = capi.load()
+    b, heads = 2, 8
+    qkv = rnd(b, n, 3 * heads * d, seed=1, dtype=dtype)
+    out = torch.empty(b, n, heads * d, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_self_attention(capi.ptr(qkv), capi.ptr(out), b, n, heads, d, 0, 1, capi.dtype_code(dtype), capi.stream_ptr()))
+    assert relerr(out, ref_self_attention(qkv, heads)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_self_attention_remaps(capi, mode):
+    """mode 1 = prompt-to-prompt self-replace (ptp.py:194-199), mode 2 = MasaCtrl (masactrl.py:56-72), n_img = 2."""
+    lib = capi.load()
+    n_img, heads, n, d, dtype = 2, 8, 256, 80, torch.float16
+    b = 4 * n_img
+    qkv = rnd(b, n, 3 * heads * d, seed=2, dtype=dtype)
+    out = torch.empty(b, n, heads * d, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_self_attention(capi.ptr(qkv), capi.ptr(out), b, n, heads, d, mode, n_img, capi.F16, capi.stream_ptr()))
+    ident = torch.arange(b)
+    qm, km, vm = ident.clone(), ident.clone(), ident.clone()
+    for img in range(n_img):
+        u_s, u_t, c_s, c_t = img, n_img + img, 2 * n_img + img, 3 * n_img + img
+        if mode == 1:
+            qm[c_t] = c_s
+            km[c_t] = c_s
+        else:
+            km[u_t], vm[u_t] = u_s, u_s
+            km[c_t], vm[c_t] = c_s, c_s
+    assert relerr(out, ref_self_attention(qkv, heads, qm, km, vm)) < TOL[dtype]
+
+
+def test_masactrl_vs_reference_golden(capi, golden):
+    """The reference's MutualSelfAttentionControl outputs (tests/golden/masactrl.npz, head_dim 8) cannot be fed to the
+    d in {40,80,160} kernels directly; the oracle's MasaCtrl (pinned by that fixture) is used at d = 40 instead."""
+    from oracle import loop as oloop
+    lib = capi.load()
+    heads, n, d = 8, 64, 40
+    qkv = rnd(4, n, 3 * heads * d, seed=9, dtype=torch.float16)
+    out = torch.empty(4, n, heads * d, dtype=torch.float16, device="cuda")
+    capi.check(lib.etainv_op_self_attention(capi.ptr(qkv), capi.ptr(out), 4, n, heads, d, 2, 1, capi.F16, capi.stream_ptr()))
+    q, k, v = qkv.float().cpu().split(heads * d, dim=-1)
+    hb = lambda t: t.reshape(4, n, heads, d).permute(0, 2, 1, 3).reshape(4 * heads, n, d)
+    m = oloop.MasaCtrl(4, 10)
+    m.cur_step, m.cur_att_layer = 4, 20
+    ref = m(False, 20, "up", hb(q), hb(k), hb(v), d ** -0.5, heads)
+    assert relerr(out.cpu(), ref) < TOL[torch.float16]
+
+
+def _ptp_tables(n_img):
+    from oracle import ptp as optp
+    pairs = json.load(open(__file__.rsplit("/", 1)[0] + "/golden/prompt_pairs.json"))
+    tok = optp.WordTokenizer()
+    mp, al, eq, ca = [], [], [], []
+    for i in range(n_img):
+        src, tgt = pairs[i % 4]
+        m, a = optp.refinement_mapper(src, tgt, tok)
+        mp.append(m)
+        al.append(a)
+        eq.append(optp.equalizer(tgt, (tgt.split(" ")[1],), (2.0,), tok))
+        ca.append(optp.time_words_alpha([src, tgt], 10, {"default_": 0.4}, tok)[0, 0])
+    T = lambda x, dt: torch.tensor(np.stack(x), dtype=dt).cuda()
+    return T(mp, torch.int32), T(al, torch.float32), T(eq, torch.float32), T(ca, torch.float32)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,d", [(256, 160), (1024, 80), (4096, 40), (64, 160)])
+def test_cross_attention_ptp_edit_and_store(capi, dtype, n, d):
+    """Cross-attention with the fused Refine + Reweight edit on the cond target rows and AttentionStore accumulation,
+    against the oracle's controller algebra (pinned by tests/golden/ptp_algebra.npz) on materialised probabilities."""
+    from oracle import ptp as optp
+    lib = capi.load()
+    n_img, heads = 2, 8
+    b = 4 * n_img
+    c = heads * d
+    q = rnd(b, n, c, seed=1, dtype=dtype)
+    kv = rnd(b, 77, 2 * c, seed=2, dtype=dtype)
+    mapper, alphas, eq, ca = _ptp_tables(n_img)
+    out = torch.empty(b, n, c, dtype=dtype, device="cuda")
+    store = n == 256
+    maps = torch.zeros(5, n_img, 2, heads, n, 77, dtype=torch.float32, device="cuda") if store else None
+    ctrl = capi.AttnCtrl(mode=capi.ATTN_PTP, n_img=n_img, store_maps=int(store), mapper=capi.ptr(mapper), alphas=capi.ptr(alphas),
+                         equalizer=capi.ptr(eq), cross_alpha=capi.ptr(ca))
+    for _ in range(2):  # two "steps" so accumulation is exercised
+        capi.check(lib.etainv_op_cross_attention(capi.ptr(q), capi.ptr(kv), capi.ptr(out), b, n, heads, d, 77, C.byref(ctrl), 3, n_img,
+                                                 capi.ptr(maps), capi.dtype_code(dtype), capi.stream_ptr()))
+    # reference: probabilities -> oracle controller (one per image, rows [u_s,u_t,c_s,c_t]) -> P @ V
+    k, v = kv.float().split(c, dim=-1)
+    sp = lambda t, L_: t.float().reshape(b, L_, heads, d).permute(0, 2, 1, 3)
+    probs = (sp(q, n) @ sp(k, 77).transpose(-1, -2) * d ** -0.5).softmax(-1).cpu()       # (b, heads, n, 77)
+    ref_maps = torch.zeros(n_img, 2, heads, n, 77)
+    for img in range(n_img):
+        rows = [img, n_img + img, 2 * n_img + img, 3 * n_img + img]
+        ctl = optp.AttentionEdit(10, ca[img].cpu().numpy()[None, None].repeat(11, 0), 0.6, mapper=mapper[img].cpu().numpy().astype(np.int64),
+                                 alphas=alphas[img].cpu().numpy(), equalizer=eq[img].cpu().numpy(), num_att_layers=1)
+        attn = probs[rows].reshape(4 * heads, n, 77).clone()
+        attn = ctl(attn, True, "up")
+        probs[rows] = attn.reshape(4, heads, n, 77)
+        ref_maps[img, 0] = probs[rows[2]]
+        ref_maps[img, 1] = probs[rows[3]]
+    ref = (probs.cuda() @ sp(v, 77)).permute(0, 2, 1, 3).reshape(b, n, c)
+    assert relerr(out, ref) < TOL[dtype]
+    if store:
+        assert relerr(maps[3].cpu(), 2 * ref_maps) < 1e-3
+        assert float(maps[0].abs().max()) == 0.0
+
+
+def test_cross_attention_store_layout_forward(capi):
+    """forward-pass layout [u x B, c x B]: only cond rows are stored, role 0."""
+    lib = capi.load()
+    n_img, heads, n, d = 2, 8, 256, 160
+    for rows in (2 * n_img, n_img):
+        q = rnd(rows, n, heads * d, seed=1, dtype=torch.float16)
+        kv = rnd(rows, 77, 2 * heads * d, seed=2, dtype=torch.float16)
+        out = torch.empty_like(q)
+        maps = torch.zeros(5, n_img, 2, heads, n, 77, dtype=torch.float32, device="cuda")
+        ctrl = capi.AttnCtrl(mode=capi.ATTN_STORE, n_img=n_img, store_maps=1)
+        capi.check(lib.etainv_op_cross_attention(capi.ptr(q), capi.ptr(kv), capi.ptr(out), rows, n, heads, d, 77, C.byref(ctrl), 0, n_img,
+                                                 capi.ptr(maps), capi.F16, capi.stream_ptr()))
+        k = kv.float()[..., :heads * d]
+        sp = lambda t, L_: t.float().reshape(rows, L_, heads, d).permute(0, 2, 1, 3)
+        probs = (sp(q, n) @ sp(k, 77).transpose(-1, -2) * d ** -0.5).softmax(-1)
+        cond = probs[rows - n_img:]
+        assert relerr(maps[0, :, 0], cond) < 1e-3
+        assert float(maps[0, :, 1].abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------------------- map consumers
+def test_word_maps_and_local_blend_vs_oracle(capi):
+    from oracle import ptp as optp
+    lib = capi.load()
+    n_img, heads, res, L = 2, 8, 16, 64
+    g = torch.Generator().manual_seed(5)
+    acc = torch.rand(5, n_img, 2, heads, res * res, 77, generator=g) ** 4 * 3.0       # "sums over 3 steps"
+    acc_d = acc.cuda()
+    tokens = torch.tensor([[1, 2, 5], [3, 1, 4]], dtype=torch.int32).cuda()
+    out = torch.zeros(n_img, 3, L, L, device="cuda")
+    capi.check(lib.etainv_op_word_maps(capi.ptr(acc_d), 5, n_img, heads, res, L, n_img, capi.ptr(tokens), 3, 3, capi.ptr(out), 0, 1.0,
+                                       capi.stream_ptr()))
+    for img in range(n_img):
+        st = optp.AttentionStore()
+        st.cur_step = 3
+        lay = [acc[l, img, 0].clone() for l in range(5)]                              # role 0 = forward-pass cond rows
+        st.attention_store = {"down_cross": lay[:2], "up_cross": lay[2:], "mid_cross": [], "down_self": [], "mid_self": [], "up_self": []}
+        for j in range(3):
+            ref = optp.attention_map(st, int(tokens[img, j]), res=16, resize=64)
+            torch.testing.assert_close(out[img, j].cpu(), ref[0], rtol=1e-4, atol=1e-5)
+    # LocalBlend
+    x = torch.randn(2 * n_img, 4, L, L, generator=g)
+    alpha = torch.zeros(n_img, 2, 77)
+    alpha[0, 0, 2] = alpha[0, 1, 2] = 1
+    alpha[1, 0, 3] = alpha[1, 1, 4] = 1
+    xd = x.clone().cuda()
+    ad = alpha.cuda()
+    capi.check(lib.etainv_op_local_blend(capi.ptr(acc_d), 5, n_img, heads, res, L, capi.ptr(xd), n_img, capi.ptr(ad), 0.3, capi.stream_ptr()))
+    for img in range(n_img):
+        lb = optp.LocalBlend(alpha[img].numpy(), 10, res=16)
+        lb.counter = 100
+        lay = [acc[l, img].reshape(2 * heads, res * res, 77) for l in range(5)]
+        store = {"down_cross": [None, None, lay[0], lay[1]], "up_cross": lay[2:]}
+        ref = lb(torch.stack([x[img], x[n_img + img]]), store)
+        torch.testing.assert_close(xd[img].cpu(), ref[0], rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(xd[n_img + img].cpu(), ref[1], rtol=1e-6, atol=1e-6)
