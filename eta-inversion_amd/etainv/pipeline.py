@@ -1,0 +1,168 @@
+"""Batched forward (inversion) / backward (eta-sampling) loops on the native engine.
+
+Host logic only: timestep tables, per-step scalar coefficients and the order of C-ABI calls.  All tensors stay on
+the device; nothing in the loops synchronises with the host (the best-of-n argmin runs in the eta-step kernel).
+
+Replaces, for B independent (source, target) pairs at once (the reference handles exactly one, SURVEY E-6):
+  DiffusionInversion.diffusion_forward / predict_step_forward   reference modules/inversion/diffusion_inversion.py:314-418
+  EtaInversion.invert (per-step word maps + mean)               reference modules/inversion/eta_inversion.py:36-49,378-404
+  EtaInversion.diffusion_backward / predict_step_backward       reference modules/inversion/eta_inversion.py:207-294
+  DiffusionInversion.sample batch layout                        reference modules/inversion/diffusion_inversion.py:462-528
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from .engine import AttnControl
+
+NUM_TRAIN = 1000
+
+
+def alphas_cumprod() -> np.ndarray:
+    """scaled_linear 0.00085..0.012, fp32 cumprod (reference modules/models/__init__.py:134)."""
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, NUM_TRAIN, dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, dim=0).numpy().astype(np.float64)
+
+
+def eta_table(eta=(0.0, 0.4)) -> np.ndarray:
+    """etas[1000] by raw timestep (reference modules/inversion/eta_inversion.py:52-58,121-139), without eval()."""
+    if not isinstance(eta, (tuple, list)):
+        eta = (eta, eta)
+    ts = np.linspace(0, 1, NUM_TRAIN)
+    if len(eta) == 3 or isinstance(eta[0], (tuple, list)):
+        (x1, y1), (x2, y2) = eta[0], eta[1]
+        p = eta[2] if len(eta) == 3 else 1
+        a = (y2 - y1) / (x2 - x1) ** p
+        etas = a * (np.clip(ts, x1, x2) - x1) ** p + y1
+    else:
+        etas = np.linspace(eta[0], eta[1], NUM_TRAIN)
+    return np.clip(etas, 0, None)
+
+
+class EtaLoop:
+    def __init__(self, engine, S=50, guidance_scale_bwd=7.5, guidance_scale_fwd=1.0, eta=(0.0, 0.4), noise_sample_count=10,
+                 use_mask=True, mask_thres=0.2, skip_uncond_fwd=True, steps_offset=0):
+        self.e, self.S, self.L = engine, S, engine.L
+        self.g_bwd, self.g_fwd = float(guidance_scale_bwd), float(guidance_scale_fwd)
+        self.ac = alphas_cumprod()
+        self.delta = NUM_TRAIN // S
+        self.t_bwd = ((np.arange(S) * self.delta)[::-1] + steps_offset).astype(np.int64)
+        self.t_fwd = self.t_bwd[::-1].copy()
+        self.etas = eta_table(eta)
+        self.n_cand = noise_sample_count
+        self.use_mask, self.mask_thres = use_mask, mask_thres
+        # u + 1*(c - u) == c up to rounding: the uncond half of the forward pass is dead work when g_fwd == 1
+        self.skip_uncond_fwd = skip_uncond_fwd and self.g_fwd == 1.0
+        self.lib = engine.lib
+
+    def _alpha(self, tau):
+        tau = min(int(tau), NUM_TRAIN - 1)
+        return float(self.ac[tau]) if tau >= 0 else float(self.ac[0])
+
+    # ---------------------------------------------------------------- forward / inversion
+    def invert(self, z0, ctx_src, tokens=None):
+        """z0 (B,4,L,L) fp32; ctx_src (B,2,77,768) = [uncond, cond] per image; tokens (B,W) int32 token index of each
+        whitespace word (first occurrence + 1).  Returns latents (S+1,B,4,L,L) and the mean word maps (B,W,L,L)."""
+        e, S, L = self.e, self.S, self.L
+        B = z0.shape[0]
+        dev = z0.device
+        lat = torch.empty(S + 1, B, 4, L, L, dtype=torch.float32, device=dev)
+        lat[0].copy_(z0)
+        if self.skip_uncond_fwd:
+            ctx = ctx_src[:, 1].contiguous().float()
+        else:
+            ctx = torch.cat([ctx_src[:, 0], ctx_src[:, 1]]).contiguous().float()
+        rows = ctx.shape[0]
+        eps_all = torch.empty(rows, 4, L, L, dtype=torch.float32, device=dev)
+        eps = eps_all if self.skip_uncond_fwd else torch.empty(B, 4, L, L, dtype=torch.float32, device=dev)
+        maps_mean = None
+        ctrl = None
+        if self.use_mask:
+            assert tokens is not None
+            maps_mean = torch.zeros(B, tokens.shape[1], L, L, dtype=torch.float32, device=dev)
+            ctrl = AttnControl(mode=_capi.ATTN_STORE, n_img=B, store_maps=True)
+            e.maps_reset()
+        n = B * 4 * L * L
+        st = _capi.stream_ptr()
+        for j, t in enumerate(self.t_fwd):
+            e.unet(lat[j], int(t), ctx, ctrl, out=eps_all)
+            if not self.skip_uncond_fwd:
+                _capi.check(self.lib.etainv_cfg_combine(_capi.ptr(eps_all[:B]), _capi.ptr(eps_all[B:]), self.g_fwd, _capi.ptr(eps), n,
+                                                        _capi.F32, st))
+            a_from, a_to = self._alpha(int(t) - self.delta), self._alpha(int(t))   # "sameshift" (scheduling_ddim_inverse.py:127-131)
+            _capi.check(self.lib.etainv_ddim_step(_capi.ptr(lat[j]), _capi.ptr(eps), a_from, a_to, _capi.ptr(lat[j + 1]), n, _capi.F32, st))
+            if self.use_mask:
+                e.word_maps(B, tokens, j + 1, maps_mean, accumulate=True, scale=1.0 / S)
+        return {"latents": lat, "maps_mean": maps_mean}
+
+    # ---------------------------------------------------------------- backward / eta sampling
+    def sample(self, inv, ctx_src, ctx_tgt, noise, edit_word=None, ptp=None, masactrl=None, trace=None):
+        """noise (S,n_cand,4,L,L) fp32: the candidates of every step (reference draws them from a generator reseeded
+        per image, eta_inversion.py:156,276, so all images share the table).  edit_word (B,) index into the word maps.
+        ptp: PtpTables or None; masactrl: (start_step, first_block) or None.  Returns latents (2B,4,L,L) [src.., tgt..]."""
+        e, S, L = self.e, self.S, self.L
+        lat_inv = inv["latents"]
+        B = lat_inv.shape[1]
+        dev = lat_inv.device
+        ctx = torch.cat([ctx_src[:, 0], ctx_tgt[:, 0], ctx_src[:, 1], ctx_tgt[:, 1]]).contiguous().float()   # [u_s,u_t,c_s,c_t] x B
+        x = torch.cat([lat_inv[S], lat_inv[S]]).contiguous()
+        x_new = torch.empty_like(x)
+        eps_all = torch.empty(4 * B, 4, L, L, dtype=torch.float32, device=dev)
+        best = torch.zeros(B, dtype=torch.int32, device=dev)
+        scratch = torch.empty(B * 16 * 64, dtype=torch.float32, device=dev)
+        mask_map = None
+        if self.use_mask:
+            idx = edit_word.to(dev).long().reshape(B, 1, 1, 1).expand(B, 1, L, L)
+            mask_map = inv["maps_mean"].gather(1, idx).reshape(B, L, L).contiguous()
+        if ptp is not None:
+            e.maps_reset()
+        st = _capi.stream_ptr()
+        for i, t in enumerate(self.t_bwd):
+            t = int(t)
+            ctrl = None
+            if ptp is not None:
+                ctrl = AttnControl(mode=_capi.ATTN_PTP, n_img=B, store_maps=True, mapper=ptp.mapper, alphas=ptp.alphas,
+                                   replace_mat=ptp.replace_mat, equalizer=ptp.equalizer, cross_alpha=ptp.cross_alpha[i],
+                                   self_replace_active=ptp.self_lo <= i < ptp.self_hi, self_max_tokens=(L // 2) ** 2)
+            elif masactrl is not None:
+                ctrl = AttnControl(mode=_capi.ATTN_MASA, n_img=B, masa_active=masactrl[0] <= i < 50, masa_first_block=masactrl[1])
+            e.unet(x, t, ctx, ctrl, out=eps_all)
+            p = t - self.delta
+            a_t, a_p = float(self.ac[t]), (float(self.ac[p]) if p >= 0 else float(self.ac[0]))
+            var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
+            _capi.check(self.lib.etainv_eta_backward_step(
+                _capi.ptr(x), _capi.ptr(eps_all), self.g_bwd, _capi.ptr(lat_inv[S - 1 - i]), _capi.ptr(noise[i]), self.n_cand,
+                float(self.etas[t]), _capi.ptr(mask_map), self.mask_thres, int(self.use_mask), a_t, a_p, var, B, 4, L * L,
+                _capi.ptr(x_new), None, _capi.ptr(best), None, _capi.ptr(scratch), _capi.F32, st))
+            x, x_new = x_new, x
+            if ptp is not None and ptp.blend_alpha is not None and (i + 1) > int(0.2 * S):
+                e.local_blend(x, B, ptp.blend_alpha, 0.3)                       # LocalBlend, reference ptp.py:31-47
+            if trace is not None:
+                trace.append({"t": t, "latent": x.clone(), "best": best.clone(), "eps_all": eps_all.clone()})
+        return x
+
+
+class PtpTables:
+    """Device tables of one prompt-to-prompt edit per image (what ptp.make_controller builds on the host,
+    reference modules/utils/ptp.py:306-320)."""
+
+    def __init__(self, mapper, alphas, cross_alpha, self_replace_steps, S, equalizer=None, blend_alpha=None, replace_mat=None,
+                 device="cuda"):
+        T = lambda a, dt: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(device).contiguous()
+        self.mapper = T(mapper, torch.int32)              # (B,77)
+        self.alphas = T(alphas, torch.float32)            # (B,77)
+        self.equalizer = T(equalizer, torch.float32)      # (B,77)
+        self.replace_mat = T(replace_mat, torch.float32)  # (B,77,77)
+        self.blend_alpha = T(blend_alpha, torch.float32)  # (B,2,77)
+        self.cross_alpha = T(cross_alpha, torch.float32)  # (S+1,B,77)
+        if isinstance(self_replace_steps, float):
+            self_replace_steps = (0, self_replace_steps)
+        self.self_lo, self.self_hi = int(S * self_replace_steps[0]), int(S * self_replace_steps[1])
+
+
+def noise_table(S, n, L, seed=0, device="cuda"):
+    """CPU torch generator, reseeded per image like the reference (eta_inversion.py:276): one table for all images."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.stack([torch.randn((n, 1, 4, L, L), generator=g) for _ in range(S)]).reshape(S, n, 4, L, L).to(device)

@@ -1,0 +1,108 @@
+"""End-to-end etainv + {simple, ptp, masactrl} on MI355X (native loops, B = 2 image pairs per batch) vs the CPU
+oracle (fp32, one pair at a time) with the same SD1.x-width synthetic UNet, contexts, noise table and edit tables.
+Free-running S-step trajectories of a random-weight UNet amplify rounding, so tolerances are on relative L2."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+L, S, B = 16, 4, 2
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from oracle.unet import build_unet
+    from etainv.engine import Engine
+    unet = build_unet(0)
+    eng = Engine(dtype=torch.float16, max_unet_batch=4 * B, latent_size=L, max_img=B)
+    eng.load_synthetic(0)
+    yield unet, eng
+    eng.close()
+
+
+def _inputs():
+    g = torch.Generator().manual_seed(77)
+    pairs = json.load(open(__file__.rsplit("/", 1)[0] + "/golden/prompt_pairs.json"))
+    pairs = [pairs[0], pairs[3]]
+    z0 = 0.8 * torch.randn(B, 4, L, L, generator=g)
+    ctx_src = torch.randn(B, 2, 77, 768, generator=g)
+    ctx_tgt = torch.randn(B, 2, 77, 768, generator=g)
+    ctx_tgt[:, 0] = ctx_src[:, 0]            # same "" uncond embedding for both prompts
+    return pairs, z0, ctx_src, ctx_tgt
+
+
+def relerr(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm()).item()
+
+
+PTP_CFG = dict(is_replace_controller=False, cross_replace_steps={"default_": .4}, self_replace_steps=.6)
+
+
+@pytest.mark.parametrize("editor", ["simple", "ptp", "masactrl"])
+def test_edit_vs_oracle(setup, editor):
+    from oracle import loop as oloop, ptp as optp
+    from etainv.pipeline import EtaLoop, PtpTables, noise_table
+    unet, eng = setup
+    pairs, z0, ctx_src, ctx_tgt = _inputs()
+    eta = [[0.6, 0], [1, 0.7]] if editor == "ptp" else (0.0, 0.4)
+    tok = optp.WordTokenizer()
+    noise = oloop.noise_table(S, 10, L, seed=0)
+    edit_word = [1, 1]
+
+    # ---------------- oracle, one pair at a time
+    ref_inv, ref_out, ref_maps = [], [], []
+    with torch.no_grad():
+        for i, (src, tgt) in enumerate(pairs):
+            o = oloop.EtaInversionOracle(unet, S=S, eta=eta, L=L)
+            inv = o.invert(z0[i:i + 1], ctx_src[i], src)
+            controller = masa = None
+            if editor == "ptp":
+                bw, tw = src.split(" ")[edit_word[i]], tgt.split(" ")[edit_word[i]]
+                controller = optp.make_edit_controller(src, tgt, S, tok, blend_words=((bw,), (tw,)),
+                                                       equilizer_params={"words": (tw,), "values": (2,)}, res=L // 4,
+                                                       thres_n=(L // 2) ** 2, **PTP_CFG)
+            elif editor == "masactrl":
+                masa = oloop.MasaCtrl(1, 10)
+            z = o.sample(inv, ctx_src[i], ctx_tgt[i], noise, edit_word_idx=(edit_word[i], edit_word[i]), controller=controller, masactrl=masa)
+            ref_inv.append(torch.cat(inv["latents"]))
+            ref_maps.append(torch.stack(inv["attn_maps_mean"])[edit_word[i]])
+            ref_out.append(z)
+    ref_inv = torch.stack(ref_inv, 1)                     # (S+1, B, 4, L, L)
+    ref_out = torch.cat([torch.stack([r[0] for r in ref_out]), torch.stack([r[1] for r in ref_out])])   # [src.., tgt..]
+
+    # ---------------- native
+    W = max(len(s.split(" ")) for s, _ in pairs)
+    tokens = torch.ones(B, W, dtype=torch.int32)
+    for i, (src, _) in enumerate(pairs):
+        ws = src.split(" ")
+        tokens[i, :len(ws)] = torch.tensor([ws.index(w) + 1 for w in ws], dtype=torch.int32)
+    loop = EtaLoop(eng, S=S, eta=eta)
+    inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
+    ptp = masa = None
+    if editor == "ptp":
+        mp, al, eq, ba, ca = [], [], [], [], []
+        for i, (src, tgt) in enumerate(pairs):
+            bw, tw = src.split(" ")[edit_word[i]], tgt.split(" ")[edit_word[i]]
+            m, a = optp.refinement_mapper(src, tgt, tok)
+            mp.append(m)
+            al.append(a)
+            eq.append(optp.equalizer(tgt, (tw,), (2,), tok))
+            ba.append(optp.blend_alpha_layers([src, tgt], ((bw,), (tw,)), tok))
+            ca.append(optp.time_words_alpha([src, tgt], S, {"default_": .4}, tok)[:, 0])
+        ptp = PtpTables(np.stack(mp), np.stack(al), np.stack(ca, 1), 0.6, S, equalizer=np.stack(eq), blend_alpha=np.stack(ba))
+    elif editor == "masactrl":
+        masa = (1, 10)
+    out = loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), noise.reshape(S, 10, 4, L, L).cuda(), edit_word=torch.tensor(edit_word),
+                      ptp=ptp, masactrl=masa)
+    torch.cuda.synchronize()
+
+    e_inv = relerr(inv["latents"].cpu(), ref_inv)
+    e_map = relerr(torch.stack([inv["maps_mean"][i, edit_word[i]] for i in range(B)]).cpu(), torch.stack(ref_maps)[:, 0])
+    e_src = relerr(out[:B].cpu(), ref_out[:B])
+    e_tgt = relerr(out[B:].cpu(), ref_out[B:])
+    print(f"{editor}: inversion traj {e_inv:.2e}, word map {e_map:.2e}, latent_inv {e_src:.2e}, latent {e_tgt:.2e}")
+    assert e_inv < 5e-3 and e_map < 2e-2
+    assert e_src < 5e-3          # source row replays the stored inversion trajectory (eta_inversion.py:247-249)
+    assert e_tgt < 3e-2
