@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of SD1.5-shaped 512x512, 50-step `etainv + ptp` (forward DDIM inversion +
+eta-scheduled backward edit with prompt-to-prompt attention control), batch-sharded over N GPUs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype fp16|bf16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = the whole hot path over one batch of B synthetic image pairs per GPU: 50 forward UNet calls (B rows:
+the uncond half is skipped because guidance_scale_fwd == 1 multiplies it out) + 50 backward UNet calls (4B rows) +
+the fused eta / CFG / best-of-n step, word-map and LocalBlend kernels.  250 sample-forwards = 200.8 TFLOP per image
+(SURVEY.md 8d).  Inputs (latents, contexts, noise table, edit tables, synthetic SD1.x-shaped weights) are resident
+in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (ROOT, ROOT / "eta-inversion_amd"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+S_STEPS = 50
+L = 64
+F_UNET_TFLOP = 0.8033           # per sample-forward at L = 64
+FWD_PER_IMAGE = 250             # 50 x 1 (forward, cond only) + 50 x 4 (backward)
+MFMA_PEAK_TFLOPS = 2500.0       # dense fp16/bf16 (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def ptp_tables(B, S):
+    """Synthetic PIE-style edit: identity alignment with token 2 replaced, equalizer 2.0 on it, blend word =
+    the same token, cross_replace_steps 0.4, self_replace_steps 0.6, edit_word_idx = (1, 1)."""
+    from etainv.pipeline import PtpTables
+    mapper = np.tile(np.arange(77, dtype=np.int32), (B, 1))
+    alphas = np.ones((B, 77), np.float32)
+    mapper[:, 2], alphas[:, 2] = -1, 0.0
+    eq = np.ones((B, 77), np.float32)
+    eq[:, 2] = 2.0
+    blend = np.zeros((B, 2, 77), np.float32)
+    blend[:, :, 2] = 1.0
+    ca = np.zeros((S + 1, B, 77), np.float32)
+    ca[: int(0.4 * (S + 1))] = 1.0
+    return PtpTables(mapper, alphas, ca, 0.6, S, equalizer=eq, blend_alpha=blend)
+
+
+def make_inputs(B, rank, dev):
+    g = torch.Generator().manual_seed(1000 + rank)
+    z0 = (0.18215 * 5.0 * torch.randn(B, 4, L, L, generator=g)).to(dev)
+    ctx_src = torch.randn(B, 2, 77, 768, generator=g).to(dev)
+    ctx_tgt = torch.randn(B, 2, 77, 768, generator=g).to(dev)
+    ctx_tgt[:, 0] = ctx_src[:, 0]
+    tokens = torch.arange(1, 9, dtype=torch.int32).repeat(B, 1).to(dev)     # 8-word prompts
+    edit_word = torch.ones(B, dtype=torch.int64)
+    return z0, ctx_src, ctx_tgt, tokens, edit_word
+
+
+def cpu_baseline(S_cpu=2):
+    """The CPU oracle (fp32 PyTorch restatement, kind "port") on the same workload shape: 1 image, etainv + ptp, L = 64,
+    S_cpu of the 50 steps; per-step cost is constant, so images/s = 1 / (t * 50 / S_cpu)."""
+    from oracle.unet import build_unet
+    from oracle import loop as oloop, ptp as optp
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    unet = build_unet(0)
+    g = torch.Generator().manual_seed(1000)
+    z0 = 0.18215 * 5.0 * torch.randn(1, 4, L, L, generator=g)
+    ctx_s, ctx_t = torch.randn(2, 77, 768, generator=g), torch.randn(2, 77, 768, generator=g)
+    src, tgt = "a b c d e f g h", "a x c d e f g h"
+    tok = optp.WordTokenizer()
+    noise = oloop.noise_table(S_cpu, 10, L, seed=0)
+    with torch.no_grad():
+        unet(z0, torch.tensor(1), encoder_hidden_states=ctx_s[:1])     # warm-up
+        t0 = time.time()
+        o = oloop.EtaInversionOracle(unet, S=S_cpu, eta=[[0.6, 0], [1, 0.7]], L=L)
+        inv = o.invert(z0, ctx_s, src)
+        ctrl = optp.make_edit_controller(src, tgt, S_cpu, tok, cross_replace_steps={"default_": .4}, self_replace_steps=.6,
+                                         blend_words=(("b",), ("x",)), equilizer_params={"words": ("x",), "values": (2,)})
+        o.sample(inv, ctx_s, ctx_t, noise, edit_word_idx=(1, 1), controller=ctrl)
+        dt = time.time() - t0
+    return {"value": 1.0 / (dt * S_STEPS / S_cpu), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 image, etainv+ptp 512x512, {S_cpu} of 50 DDIM steps on the CPU oracle (fp32, reference call pattern: "
+                      f"{6 * S_cpu} UNet sample-forwards) in {dt:.1f} s, extrapolated linearly to 50 steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("ETAINV_BENCH_BATCH", 32)), help="image pairs per GPU per step")
+    ap.add_argument("--dtype", default=os.environ.get("ETAINV_BENCH_DTYPE", "bf16"), choices=["fp16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+
+    from etainv import _capi
+    from etainv.engine import Engine
+    from etainv.pipeline import EtaLoop, noise_table
+    lib = _capi.load()
+    B = a.batch
+    dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[a.dtype]
+    eng = Engine(dtype=dtype, max_unet_batch=4 * B, latent_size=L, max_img=B, device=str(dev))
+    eng.load_default(0)
+    loop = EtaLoop(eng, S=S_STEPS, eta=[[0.6, 0], [1, 0.7]], noise_sample_count=10)
+    z0, ctx_src, ctx_tgt, tokens, edit_word = make_inputs(B, rank, dev)
+    noise = noise_table(S_STEPS, 10, L, seed=0, device=dev)
+    tables = ptp_tables(B, S_STEPS)
+
+    def one_step():
+        inv = loop.invert(z0, ctx_src, tokens)
+        out = loop.sample(inv, ctx_src, ctx_tgt, noise, edit_word=edit_word, ptp=tables)
+        if dist is not None:       # the path's only exchange: final gather of the edited latents (32 KiB / image)
+            gathered = [torch.empty_like(out) for _ in range(world)]
+            dist.all_gather(gathered, out)
+        return out
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_step()
+    barrier()
+    lib.etainv_prof_reset()
+    lib.etainv_prof_enable(1)
+    t0 = time.time()
+    for _ in range(a.steps):
+        out = one_step()
+    barrier()
+    dt = time.time() - t0
+    lib.etainv_prof_enable(0)
+    assert torch.isfinite(out).all(), "non-finite edited latents"
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    def prof(cls):
+        ms, work, n = C.c_double(), C.c_double(), C.c_int64()
+        _capi.check(lib.etainv_prof_read(cls, C.byref(ms), C.byref(work), C.byref(n)))
+        return ms.value, work.value, n.value
+
+    ig_ms, ig_flop, ig_n = prof(0)
+    sa_ms, sa_flop, sa_n = prof(1)
+    ca_ms, ca_flop, ca_n = prof(2)
+    gn_ms, gn_bytes, gn_n = prof(3)
+    ln_ms, ln_bytes, ln_n = prof(4)
+    images = B * world * a.steps
+    value = images / dt
+    if rank == 0:
+        achieved = ig_flop / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
+        line = {
+            "metric": "images/sec SD1.5 512^2 50-step etainv+ptp", "value": value, "unit": "images/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"etainv+ptp, SD1.5-shaped UNet (seeded synthetic weights), 512x512 (64x64 latents), 50 DDIM steps, "
+                                   f"{B} image pairs per GPU per step, eta [[0.6,0],[1,0.7]], n=10 noise candidates, cfg 7.5/1",
+                       "images_per_gpu": B, "unet_sample_forwards_per_image": FWD_PER_IMAGE,
+                       "tflop_per_image": FWD_PER_IMAGE * F_UNET_TFLOP, "sharding": f"batch-shard x{world}, final all_gather of latents"},
+            "end_to_end_mfma_frac": value / world * FWD_PER_IMAGE * F_UNET_TFLOP / MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv3x3 / conv1x1 / linear)", "achieved": achieved,
+                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches": ig_n, "avg_launch_ms": ig_ms / max(ig_n, 1), "share_of_wall": ig_ms * 1e-3 / dt},
+            "other_kernels": {
+                "self_attention": {"tflops": sa_flop / max(sa_ms, 1e-9) / 1e9, "share_of_wall": sa_ms * 1e-3 / dt, "launches": sa_n},
+                "cross_attention": {"tflops": ca_flop / max(ca_ms, 1e-9) / 1e9, "share_of_wall": ca_ms * 1e-3 / dt, "launches": ca_n},
+                "groupnorm": {"gbs": gn_bytes / max(gn_ms, 1e-9) / 1e6, "frac_hbm": gn_bytes / max(gn_ms, 1e-9) / 1e6 / HBM_PEAK_GBS,
+                              "share_of_wall": gn_ms * 1e-3 / dt, "launches": gn_n},
+                "layernorm": {"gbs": ln_bytes / max(ln_ms, 1e-9) / 1e6, "frac_hbm": ln_bytes / max(ln_ms, 1e-9) / 1e6 / HBM_PEAK_GBS,
+                              "share_of_wall": ln_ms * 1e-3 / dt, "launches": ln_n}},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -454,6 +454,7 @@ static int launch_self_t(const void* qkv, void* out, int b, int n, int heads, in
   constexpr int DP = (D + 31) / 32 * 32, DT = (D + 15) / 16;
   const size_t lds = (size_t)(64 * (DP + 8) + DT * 16 * (64 + 8)) * sizeof(T);
   const float scale_log2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+  ProfScope prof(PROF_SELF_ATTN, 4.0 * (double)b * heads * (double)n * (double)n * D, s);
   hipLaunchKernelGGL((self_attn_kernel<T, D, QT>), dim3(cdiv(n, 64 * QT), heads, b), dim3(256), lds, s, (const T*)qkv, (T*)out, n,
                      heads, scale_log2, mode, n_img);
   ETAINV_LAUNCH_CHECK();
@@ -483,6 +484,7 @@ static int launch_cross_t(const void* q, const void* kv, void* out, int b, const
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn_kernel<T, D, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
+  ProfScope prof(PROF_CROSS_ATTN, 4.0 * (double)b * p.heads * (double)p.N * (double)p.n_ctx * D, s);
   hipLaunchKernelGGL((cross_attn_kernel<T, D, QT>), dim3(cdiv(p.N, 64 * QT), p.heads, b), dim3(256), lds, s, (const T*)q,
                      (const T*)kv, (T*)out, p);
   ETAINV_LAUNCH_CHECK();

@@ -69,6 +69,19 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// ---- opt-in per-kernel-class timing with HIP events on the launch stream (bench.py roofline numbers).
+// Off by default: the launchers then do nothing extra.  work = algorithmic FLOPs (MFMA kernels) or bytes (HBM-bound).
+enum ProfClass { PROF_IGEMM = 0, PROF_SELF_ATTN = 1, PROF_CROSS_ATTN = 2, PROF_GROUPNORM = 3, PROF_LAYERNORM = 4, PROF_OTHER = 5, PROF_NCLASS = 6 };
+bool prof_enabled();
+void prof_begin(int cls, double work, hipStream_t s);
+void prof_end(hipStream_t s);
+struct ProfScope {
+  hipStream_t s;
+  bool on;
+  ProfScope(int cls, double work, hipStream_t st) : s(st), on(prof_enabled()) { if (on) prof_begin(cls, work, s); }
+  ~ProfScope() { if (on) prof_end(s); }
+};
+
 // dispatch a generic lambda over the three element types
 #define ETAINV_DISPATCH_DTYPE(dt, T, ...)                          \
   switch (dt) {                                                    \

@@ -24,6 +24,26 @@ namespace etainv {
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 
+// ---- profiler
+struct ProfRec { int cls; double work; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+static size_t g_prof_used = 0;
+bool prof_enabled() { return g_prof_on; }
+void prof_begin(int cls, double work, hipStream_t s) {
+  if (g_prof_used == g_prof_pool.size()) {
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    g_prof_pool.emplace_back(a, b);
+  }
+  auto& ev = g_prof_pool[g_prof_used++];
+  g_prof.push_back({cls, work, ev.first, ev.second});
+  (void)hipEventRecord(ev.first, s);
+}
+void prof_end(hipStream_t s) { (void)hipEventRecord(g_prof.back().b, s); }
+
 enum PackMode { PK_PLAIN = 0, PK_CONV = 1, PK_GEGLU = 2, PK_CONV_IN = 3, PK_CONV_OUT = 4 };
 
 struct WeightSlot {
@@ -655,6 +675,36 @@ extern "C" int etainv_local_blend(etainv_engine_t* e, float* x, int n_img, const
   ETAINV_CHECK(e && n_img >= 1 && n_img <= e->max_img, "bad arguments");
   return launch_local_blend(e->maps_acc, 5, e->max_img, etainv_engine::kHeads, e->L / 4, e->L, x, n_img, blend_alpha, thres,
                             (hipStream_t)stream);
+}
+
+extern "C" int etainv_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return 0;
+}
+extern "C" int etainv_prof_reset(void) {
+  g_prof.clear();
+  g_prof_used = 0;
+  return 0;
+}
+/* Sum of event-timed durations (ms), work (FLOPs or bytes) and launch count of one kernel class since the last reset.
+ * Synchronises the device (diagnostic call, never used inside the loops). */
+extern "C" int etainv_prof_read(int cls, double* ms, double* work, int64_t* launches) {
+  ETAINV_CHECK(cls >= 0 && cls < PROF_NCLASS && ms && work && launches, "bad arguments");
+  ETAINV_HIP(hipDeviceSynchronize());
+  double t = 0, w = 0;
+  int64_t n = 0;
+  for (auto& r : g_prof)
+    if (r.cls == cls) {
+      float f = 0.f;
+      ETAINV_HIP(hipEventElapsedTime(&f, r.a, r.b));
+      t += f;
+      w += r.work;
+      ++n;
+    }
+  *ms = t;
+  *work = w;
+  *launches = n;
+  return 0;
 }
 
 // ---- per-op entry points for the parity tests

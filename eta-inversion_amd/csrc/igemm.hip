@@ -212,6 +212,7 @@ static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s);
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(tiles), dim3(256), lds, s, p);
   ETAINV_LAUNCH_CHECK();
   return 0;

@@ -104,30 +104,53 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, int chunks
   stats[(b * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// grid (chunks, B), 4 waves; same pixel / vector ownership as gn_stats_kernel, so the per-channel scale and shift
+// (rstd*gamma, beta - mean*rstd*gamma) are computed once per lane and reused for every pixel: no integer
+// division and 2 FMAs per element in the streaming loop.
 template <typename T>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x1, const T* __restrict__ x2, int c1, int c2, int hw,
                                                        int groups, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       int silu, T* __restrict__ out, int64_t total_vec) {
+                                                       int silu, T* __restrict__ out) {
   const int C = c1 + c2, nvec = C >> 3, nv1 = c1 >> 3, cpg = C / groups;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < total_vec; i += stride) {
-    const int64_t row = i / nvec;
-    const int v = (int)(i - row * nvec);
-    const int b = (int)(row / hw);
-    float t[8];
-    if (v < nv1) load8(x1 + row * c1 + v * 8, t);
-    else load8(x2 + row * c2 + (v - nv1) * 8, t);
-    const float* st = stats + (int64_t)b * groups * 2;
+  const int b = blockIdx.y, chunks = gridDim.x;
+  const int per = (hw + chunks - 1) / chunks;
+  const int beg = blockIdx.x * per, end = min(hw, beg + per);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const float* st = stats + (int64_t)b * groups * 2;
+  float sc[GN_MAX_VEC_PER_LANE][8], sh[GN_MAX_VEC_PER_LANE][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ch = v * 8 + j;
-      const int g = ch / cpg;
-      float y = (t[j] - st[g * 2]) * st[g * 2 + 1] * gamma[ch] + beta[ch];
-      t[j] = silu ? silu_f(y) : y;
+  for (int i = 0; i < GN_MAX_VEC_PER_LANE; ++i) {
+    const int v = lane + 64 * i;
+    if (v < nvec) {
+      int g = (v * 8) / cpg, rem = v * 8 - g * cpg;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ch = v * 8 + j;
+        const float a = st[g * 2 + 1] * gamma[ch];
+        sc[i][j] = a;
+        sh[i][j] = beta[ch] - st[g * 2] * a;
+        if (++rem == cpg) { rem = 0; ++g; }
+      }
     }
-    store8(out + row * C + v * 8, t);
+  }
+  for (int pix = beg + wid; pix < end; pix += 4) {
+    const int64_t row = (int64_t)b * hw + pix;
+#pragma unroll
+    for (int i = 0; i < GN_MAX_VEC_PER_LANE; ++i) {
+      const int v = lane + 64 * i;
+      if (v < nvec) {
+        float t[8];
+        if (v < nv1) load8(x1 + row * c1 + v * 8, t);
+        else load8(x2 + row * c2 + (v - nv1) * 8, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float y = t[j] * sc[i][j] + sh[i][j];
+          t[j] = silu ? silu_f(y) : y;
+        }
+        store8(out + row * C + v * 8, t);
+      }
+    }
   }
 }
 
@@ -185,8 +208,9 @@ int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float
   float* partial = scratch;
   float* stats = scratch + (int64_t)b * GN_MAX_CHUNKS * groups * 2;
   const size_t lds = (size_t)4 * C * 2 * sizeof(float);
-  const int64_t total_vec = (int64_t)b * hw * (C >> 3);
-  const int grid_apply = (int)std::min<int64_t>(cdiv(total_vec, 256), 8192);
+  // the apply pass has no cross-block reduction: use more, smaller chunks to fill the chip
+  const int chunks_apply = std::max(1, std::min(hw / 4, std::max(chunks, 4096 / std::max(1, b))));
+  ProfScope prof(PROF_GROUPNORM, 2.0 * 2.0 * (double)b * hw * C, s);  // algorithmic bytes: read + write once, 2-byte elements
   ETAINV_DISPATCH_HALF(
       dtype, T,
       static bool attr = false;
@@ -196,8 +220,8 @@ int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float
       }
       hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks, b), dim3(256), lds, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups, partial);
       hipLaunchKernelGGL(gn_finalize_kernel, dim3(b), dim3(64), 0, s, partial, chunks, groups, (float)hw * (float)(C / groups), eps, stats);
-      hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(grid_apply), dim3(256), 0, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups, stats,
-                         gamma, beta, silu, (T*)out, total_vec));
+      hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(chunks_apply, b), dim3(256), 0, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups, stats,
+                         gamma, beta, silu, (T*)out));
   ETAINV_LAUNCH_CHECK();
   return 0;
 }
@@ -206,6 +230,7 @@ int launch_layernorm(const void* x, const float* gamma, const float* beta, void*
                      hipStream_t s) {
   ETAINV_CHECK(x && gamma && beta && out, "null pointer");
   ETAINV_CHECK(c % 8 == 0 && (c >> 3) <= 192, "LayerNorm width must be a multiple of 8 and <= 1536");
+  ProfScope prof(PROF_LAYERNORM, 2.0 * 2.0 * (double)rows * c, s);
   ETAINV_DISPATCH_HALF(dtype, T,
                        hipLaunchKernelGGL(layernorm_kernel<T>, dim3(cdiv(rows, 4)), dim3(256), 0, s, (const T*)x, gamma, beta,
                                           (T*)out, rows, c, eps));

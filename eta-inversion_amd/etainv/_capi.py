@@ -48,6 +48,9 @@ SIGNATURES = {
     "etainv_local_blend": [_p, _p, _i, _p, _f, _p],
     "etainv_engine_workspace_bytes": [_p],
     "etainv_engine_weight_bytes": [_p],
+    "etainv_prof_enable": [_i],
+    "etainv_prof_reset": [],
+    "etainv_prof_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)],
     "etainv_op_gemm": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "etainv_op_conv3x3": [_p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "etainv_op_groupnorm": [_p, _p, _i, _i, _p, _p, _p, _i, _i, _i, _f, _i, _p, _i, _p],

@@ -147,6 +147,13 @@ int etainv_local_blend(etainv_engine_t* e, float* x, int n_img, const float* ble
 int64_t etainv_engine_workspace_bytes(etainv_engine_t* e);
 int64_t etainv_engine_weight_bytes(etainv_engine_t* e);
 
+/* Opt-in per-kernel-class timing (HIP events recorded on the launch stream around every launch of the class).
+ * Classes: 0 implicit-GEMM (conv/linear, work = FLOPs), 1 self-attention (FLOPs), 2 cross-attention (FLOPs),
+ * 3 GroupNorm (bytes), 4 LayerNorm (bytes).  etainv_prof_read synchronises the device. */
+int etainv_prof_enable(int on);
+int etainv_prof_reset(void);
+int etainv_prof_read(int cls, double* ms, double* work, int64_t* launches);
+
 /* Per-op entry points used by the parity tests (tests/test_kernels_gpu.py) -- the same launchers the
  * executor uses, exposed so every kernel is checked against a plain fp32 reference in isolation.
  * Activations NHWC in the compute dtype; weights in the engine layouts described in DESIGN.md. */
