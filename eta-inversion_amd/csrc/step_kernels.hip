@@ -141,9 +141,43 @@ __global__ void __launch_bounds__(256) eta_update_kernel(const T* __restrict__ x
   }
 }
 
+// generic [3P] DDIMScheduler.step restatement (eps prediction): x' = sqrt(a_p) x0 + sqrt(1-a_p-(eta_px s)^2) eps + eta_px s z
+// eta_px = eta * (mask ? mask[row % n_mask][pixel] : 1); z = noise[element] (shared by rows) or 0
+template <typename T>
+__global__ void ddim_eta_step_kernel(const T* __restrict__ x, const T* __restrict__ eps, float eta, const T* __restrict__ mask, int n_mask,
+                                     const T* __restrict__ noise, float sa_t, float s1m_t, float sa_p, float a_p, float var, int rows,
+                                     int chw, int hw, T* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * chw) return;
+  const int row = (int)(i / chw), e = (int)(i - (int64_t)row * chw);
+  float eta_px = eta;
+  if (mask) eta_px *= to_f32(mask[(int64_t)(row % n_mask) * hw + (e % hw)]);
+  const float std_t = eta_px * sqrtf(var);
+  const float ep = to_f32(eps[i]);
+  const float x0 = (to_f32(x[i]) - s1m_t * ep) / sa_t;
+  float xn = sa_p * x0 + sqrtf(1.f - a_p - std_t * std_t) * ep;
+  if (noise) xn += std_t * to_f32(noise[e]);
+  out[i] = from_f32<T>(xn);
+}
+
 }  // namespace etainv
 
 using namespace etainv;
+
+extern "C" int etainv_ddim_eta_step(const void* x, const void* eps, float eta, const void* eta_mask, int n_mask, const void* noise,
+                                    float a_t, float a_p, float var, int rows, int c, int hw, void* out, int io_dtype, void* stream) {
+  ETAINV_CHECK(x && eps && out && rows >= 1 && c >= 1 && hw >= 1, "bad arguments");
+  ETAINV_CHECK(!eta_mask || n_mask >= 1, "n_mask");
+  ETAINV_CHECK(a_t > 0.f && a_t < 1.f && a_p > 0.f && a_p <= 1.f, "alphas_cumprod out of range");
+  const int chw = c * hw;
+  const int64_t n = (int64_t)rows * chw;
+  ETAINV_DISPATCH_DTYPE(io_dtype, T,
+                        hipLaunchKernelGGL(ddim_eta_step_kernel<T>, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                                           (const T*)eps, eta, (const T*)eta_mask, n_mask, (const T*)noise, (float)sqrt((double)a_t),
+                                           (float)sqrt(1.0 - (double)a_t), (float)sqrt((double)a_p), a_p, var, rows, chw, hw, (T*)out));
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int etainv_cfg_combine(const void* eps_u, const void* eps_c, float g, void* out, int64_t n, int io_dtype, void* stream) {
   ETAINV_CHECK(eps_u && eps_c && out && n >= 0, "null pointer or negative size");

@@ -35,6 +35,7 @@ SIGNATURES = {
     "etainv_last_error": [],
     "etainv_cfg_combine": [_p, _p, _f, _p, _i64, _i, _p],
     "etainv_ddim_step": [_p, _p, _f, _f, _p, _i64, _i, _p],
+    "etainv_ddim_eta_step": [_p, _p, _f, _p, _i, _p, _f, _f, _f, _i, _i, _i, _p, _i, _p],
     "etainv_eta_backward_step": [_p, _p, _f, _p, _p, _i, _f, _p, _f, _i, _f, _f, _f, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
     "etainv_engine_create": [C.POINTER(EngineConfig), C.POINTER(_p)],
     "etainv_engine_destroy": [_p],

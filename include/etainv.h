@@ -49,6 +49,13 @@ int etainv_cfg_combine(const void* eps_u, const void* eps_c, float g, void* out,
 int etainv_ddim_step(const void* x, const void* eps, float a_from, float a_to, void* out, int64_t n,
                      int io_dtype, void* stream);
 
+/* x' = DDIMScheduler.step(eps, t, x, eta, variance_noise) for `rows` latents ([3P] diffusers scheduler as called by
+ * DiffusionInversion.step_backward, modules/inversion/diffusion_inversion.py:301-312, and with a per-pixel eta by
+ * modules/inversion/eta_inversion.py:245).  eta_px = eta * eta_mask[row % n_mask][pixel] (eta_mask may be NULL);
+ * noise [c*hw] is shared by all rows (may be NULL = no noise term). */
+int etainv_ddim_eta_step(const void* x, const void* eps, float eta, const void* eta_mask, int n_mask, const void* noise,
+                         float a_t, float a_p, float var, int rows, int c, int hw, void* out, int io_dtype, void* stream);
+
 /* Fused backward step of EtaInversion.predict_step_backward (modules/inversion/eta_inversion.py:207-273)
  * for n_img independent (src,tgt) pairs, everything after the UNet call:
  *   CFG combine (:328) -> best-of-n variance noise on the source row (:330-375, argmin on device, NaN counts

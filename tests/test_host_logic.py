@@ -1,0 +1,154 @@
+"""CPU-only checks of the product's host side: prompt tables vs the reference goldens, schedule tables, the C-ABI
+library (loads, exports every symbol include/etainv.h declares), the plugin registries, loud failure without a GPU,
+and the world_size-2 shard / gather path on gloo."""
+import ctypes
+import json
+import os
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+PAIRS = json.load(open(ROOT / "tests" / "golden" / "prompt_pairs.json"))
+
+
+def test_prompt_tables_match_reference_goldens(golden):
+    from modules.utils import seq_aligner, ptp_utils, ptp
+    from modules.utils.tokenizer import WordLevelTokenizer
+    g = golden("ptp_tables")
+    tok = WordLevelTokenizer()
+
+    class M:
+        tokenizer = tok
+    for i, (a, b) in enumerate(PAIRS):
+        np.testing.assert_array_equal(np.array(tok.encode(b)), g[f"p{i}/ids_b"])
+        mapper, alphas = seq_aligner.get_refinement_mapper([a, b], tok)
+        np.testing.assert_array_equal(mapper.numpy(), g[f"p{i}/mapper"])
+        np.testing.assert_array_equal(alphas.numpy(), g[f"p{i}/alphas"])
+        for S in (10, 50):
+            np.testing.assert_array_equal(ptp_utils.get_time_words_attention_alpha([a, b], S, {"default_": 0.4}, tok).numpy(), g[f"p{i}/ctw_{S}"])
+        w = b.split(" ")[1]
+        np.testing.assert_array_equal(
+            ptp_utils.get_time_words_attention_alpha([a, b], 50, {"default_": 0.8, w: (0.1, 0.5)}, tok).numpy(), g[f"p{i}/ctw_word"])
+        np.testing.assert_array_equal(ptp.get_equalizer(M, b, (w,), (2,)).numpy(), g[f"p{i}/eq"])
+        np.testing.assert_array_equal(ptp_utils.get_word_inds(b, w, tok), g[f"p{i}/inds_w1"])
+        if f"p{i}/replace" in g.files:
+            np.testing.assert_array_equal(seq_aligner.get_replacement_mapper([a, b], tok).numpy(), g[f"p{i}/replace"])
+    with pytest.raises(ValueError):
+        seq_aligner.get_replacement_mapper(["a cat", "a very big cat"], tok)
+
+
+def test_schedule_tables_match_reference_goldens(golden):
+    from etainv.pipeline import alphas_cumprod, eta_table, EtaLoop
+    from modules.schedulers import DDIMScheduler
+    from modules.inverse_schedulers import DDIMInverseScheduler
+    g = golden("schedule")
+    np.testing.assert_array_equal(alphas_cumprod().astype(np.float32), g["alphas_cumprod"])
+    for key, eta in {"lin": (0.0, 0.4), "paper": [[0.6, 0], [1, 0.7]], "paper2": [[0.3, 0], [1, 0.2]],
+                     "pow3": [[0.2, 0.1], [0.9, 0.8], 3], "const": 0.25}.items():
+        np.testing.assert_allclose(eta_table(eta), g[f"etas_{key}"], rtol=1e-12, atol=1e-15)
+    for S in (10, 50, 100):
+        s = DDIMScheduler()
+        s.set_timesteps(S)
+        np.testing.assert_array_equal(s.timesteps.numpy(), g[f"t_bwd_{S}"])
+        inv = DDIMInverseScheduler.from_scheduler(s)
+        inv.set_timesteps(S)
+        np.testing.assert_array_equal(inv.timesteps.numpy(), g[f"t_fwd_{S}"])
+        var = np.array([s._get_variance(int(t), int(t) - 1000 // S) for t in s.timesteps])
+        np.testing.assert_allclose(var, g[f"var_{S}"], rtol=5e-5)
+
+        class E:
+            L = 64
+            lib = None
+        lp = EtaLoop(E(), S=S)
+        np.testing.assert_array_equal(lp.t_bwd, g[f"t_bwd_{S}"])
+        np.testing.assert_array_equal(lp.t_fwd, g[f"t_fwd_{S}"])
+    assert float(DDIMScheduler().final_alpha_cumprod) == float(g["final_alpha_cumprod"])
+
+
+def test_capi_exports_every_declared_symbol():
+    from etainv import _capi
+    header = (ROOT / "include" / "etainv.h").read_text()
+    declared = set(re.findall(r"\b(etainv_[a-z0-9_]+)\s*\(", header))
+    declared -= {"etainv_engine", "etainv_engine_config", "etainv_attn_ctrl"}
+    assert len(declared) >= 29
+    lib = _capi.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/etainv.h but not exported by libetainv_hip.so"
+        assert name in _capi.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_capi.SIGNATURES) <= declared
+    assert lib.etainv_abi_version() == 1
+    # struct layouts agree with the header (sizes are part of the ABI)
+    assert ctypes.sizeof(_capi.EngineConfig) == 8 * 4
+    assert ctypes.sizeof(_capi.AttnCtrl) == 3 * 4 + 4 + 5 * 8 + 4 * 4 + 4 * 4
+
+
+def test_argument_errors_are_reported_not_crashed():
+    from etainv import _capi
+    lib = _capi.load()
+    assert lib.etainv_cfg_combine(None, None, 1.0, None, 4, _capi.F32, None) != 0
+    assert b"null" in lib.etainv_last_error()
+    with pytest.raises(_capi.EtainvError):
+        _capi.check(lib.etainv_ddim_step(None, None, 0.5, 0.5, None, 4, _capi.F32, None))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_engine_fails_loudly_without_gpu():
+    from etainv import _capi
+    from etainv.engine import Engine
+    with pytest.raises(_capi.EtainvError):
+        Engine()
+
+
+def test_registries_and_not_built_methods():
+    import modules
+    assert {"etainv", "diffinv"} <= set(modules.get_inversion_methods())
+    assert {"simple", "ptp", "masactrl"} <= set(modules.get_edit_methods())
+    with pytest.raises(NotImplementedError):
+        modules.load_inverter("nti", model=None)
+    with pytest.raises(NotImplementedError):
+        modules.load_editor("pnp", inverter=None)
+    modules.register_editor("custom", modules.SimpleEditor)
+    assert "custom" in modules.get_edit_methods()
+    assert modules.DiffusionInversion.get_available_schedulers() == ["ddim", "ddpm", "dpm"]
+
+
+def test_shard_indices_cover_all_images():
+    from etainv.shard import shard_indices
+    for n, w in ((700, 8), (5, 2), (3, 4), (0, 2)):
+        seen = sorted(i for r in range(w) for i in shard_indices(n, r, w))
+        assert seen == list(range(n))
+    assert len(shard_indices(700, 0, 8)) == 88 and len(shard_indices(700, 7, 8)) == 87
+
+
+def _gloo_worker(rank, world, port, n_items, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from etainv.shard import shard_indices, gather_latents
+    idx = shard_indices(n_items, rank, world)
+    local = torch.stack([torch.full((4, 8, 8), float(i)) for i in idx]) if idx else torch.zeros(0, 4, 8, 8)
+    out = gather_latents(local, n_items, rank, world)
+    q.put((rank, out[:, 0, 0, 0].tolist()))
+    dist.destroy_process_group()
+
+
+def test_gather_latents_world_size_2_gloo():
+    import sys
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    for p in (str(ROOT), str(ROOT / "eta-inversion_amd")):
+        os.environ["PYTHONPATH"] = p + os.pathsep + os.environ.get("PYTHONPATH", "")
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for _, vals in res:
+        assert vals == [0.0, 1.0, 2.0, 3.0, 4.0]

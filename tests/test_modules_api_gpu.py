@@ -1,0 +1,112 @@
+"""The reference's plugin surface on MI355X: load_diffusion_model / load_inverter / load_editor / Editor.edit and the
+edit_image.py command line, at a 128x128 image (16x16 latents) with synthetic weights and the stand-in VAE / text encoder."""
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+SRC, TGT = "a cat sitting next to a mirror", "a tiger sitting next to a mirror"
+PTP_CFG = dict(is_replace_controller=False, prompts=[SRC, TGT], cross_replace_steps={"default_": .4}, self_replace_steps=0.6,
+               blend_words=(("cat",), ("tiger",)), equilizer_params={"words": ("tiger",), "values": (2,)})
+
+
+@pytest.fixture(scope="module")
+def pipe():
+    import modules
+    p, (pre, post) = modules.load_diffusion_model("sd15", "cuda", variant="fp16", latent_size=16)
+    yield p, pre, post
+    p.engine.close()
+
+
+def _image():
+    g = torch.Generator().manual_seed(3)
+    return (torch.rand(1, 3, 128, 128, generator=g) * 2 - 1).cuda()
+
+
+@pytest.mark.parametrize("editor_name,cfg", [("simple", None), ("ptp", PTP_CFG), ("masactrl", None)])
+def test_editor_edit_matches_direct_loop(pipe, editor_name, cfg):
+    import modules
+    from etainv.pipeline import EtaLoop, PtpTables, noise_table
+    p, pre, post = pipe
+    S = 6
+    inverter = modules.load_inverter("etainv", model=p, scheduler="ddim", num_inference_steps=S, eta=[[0.6, 0], [1, 0.7]])
+    editor = modules.load_editor(editor_name, inverter=inverter)
+    image = _image()
+    res = editor.edit(image, SRC, TGT, cfg=None if cfg is None else {**cfg}, inv_cfg=dict(edit_word_idx=(1, 1)))
+    assert set(res) == {"image_inv", "image", "latent_inv", "latent"}
+    assert res["latent"].shape == (1, 4, 16, 16) and res["image"].shape == (1, 3, 128, 128)
+    assert torch.isfinite(res["latent"]).all()
+    # same computation through the batched loop API directly
+    loop = EtaLoop(p.engine, S=S, eta=[[0.6, 0], [1, 0.7]])
+    z0 = inverter.encode(image).float()
+    ctx_s, ctx_t = inverter.create_context(SRC)[None], inverter.create_context(TGT)[None]
+    words = SRC.split(" ")
+    tokens = torch.tensor([[words.index(w) + 1 for w in words]], dtype=torch.int32).cuda()
+    inv = loop.invert(z0, ctx_s, tokens)
+    ptp = masa = None
+    if editor_name == "ptp":
+        from modules.utils import ptp as ptp_mod
+        t = ptp_mod.make_controller(p, [SRC, TGT], **{k: v for k, v in cfg.items() if k != "prompts"}).tables()
+        ptp = PtpTables(t["mapper"][None], t["alphas"][None], t["cross_alpha"][:, None], 0.6, S, equalizer=t["equalizer"][None],
+                        blend_alpha=t["blend_alpha"][None])
+    elif editor_name == "masactrl":
+        masa = (4, 10)
+    out = loop.sample(inv, ctx_s, ctx_t, noise_table(S, 10, 16, seed=0), edit_word=torch.tensor([1]), ptp=ptp, masactrl=masa)
+    assert torch.equal(out[1:2], res["latent"]) and torch.equal(out[0:1], res["latent_inv"])
+    # the source row replays the inversion trajectory: latent_inv == z0 up to rounding of a + (b - a)
+    torch.testing.assert_close(res["latent_inv"], z0, rtol=1e-5, atol=1e-5)
+    img = post(res["image"])
+    assert img.dtype == np.uint8 and img.shape == (128, 128, 3)
+
+
+def test_per_step_plugin_path_matches_fast_path(pipe):
+    """A user-defined controller (unknown to the engine) forces the callback-per-step path of the reference API
+    (predict_step_backward + begin_step / end_step); with an identity controller it must agree with the fused loop."""
+    import modules
+    from modules.editing.controller import ControllerBase
+    p, pre, post = pipe
+    S = 4
+    inverter = modules.load_inverter("etainv", model=p, scheduler="ddim", num_inference_steps=S)
+    image = _image()
+    ctx_s, ctx_t = inverter.create_context(SRC), inverter.create_context(TGT)
+    inv_res = inverter.invert(image, prompt=SRC, context=ctx_s, inv_cfg=dict(edit_word_idx=(1, 1)))
+    fast = inverter.sample(inv_res, context=[ctx_s, ctx_t])["latent"]
+
+    class Custom(ControllerBase):
+        calls = 0
+
+        def end_step(self, latent, noise_pred=None, t=None):
+            Custom.calls += 1
+            return latent
+    with inverter.use_controller(Custom()):
+        slow = inverter.sample(inv_res, context=[ctx_s, ctx_t])["latent"]
+    assert Custom.calls == S
+    torch.testing.assert_close(slow, fast, rtol=1e-4, atol=1e-4)
+    # granular forward API: predict_noise + step_forward == stored inversion trajectory
+    lat = inv_res["latents"][0]
+    t0 = inverter.get_timesteps_forward()[0]
+    eps = inverter.predict_noise(lat, t0, ctx_s, 1, is_fwd=True)
+    nxt = inverter.step_forward(eps, t0, lat).prev_sample
+    torch.testing.assert_close(nxt, inv_res["latents"][1], rtol=1e-4, atol=1e-4)
+    # unsupported input -> None like the reference (eta_inversion.py:385-386)
+    assert inverter.invert(image, prompt=SRC, context=ctx_s, inv_cfg=dict(edit_word_idx=(None, None))) is None
+
+
+def test_edit_image_cli(tmp_path):
+    from PIL import Image
+    src = tmp_path / "in.png"
+    Image.fromarray((np.random.default_rng(0).random((96, 96, 3)) * 255).astype(np.uint8)).save(src)
+    out = tmp_path / "out.png"
+    r = subprocess.run([sys.executable, str(ROOT / "eta-inversion_amd" / "edit_image.py"), "--input", str(src), "--source_prompt", SRC,
+                        "--target_prompt", TGT, "--output", str(out), "--inv_method", "etainv", "--edit_method", "ptp", "--steps", "3",
+                        "--prec", "fp16"], capture_output=True, text=True, timeout=900,
+                       env={**__import__("os").environ, "PYTHONPATH": str(ROOT / "eta-inversion_amd")})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Saved result to" in r.stdout and "Took" in r.stdout
+    assert out.exists() and (tmp_path / "out_inv.png").exists()
+    assert Image.open(out).size == (512, 512)
