@@ -14,6 +14,8 @@
 // online-softmax rescale is lane-local, and the S^T accumulator registers are already the B operand of the
 // PV product (keys of a 32-key step are taken in the order the accumulators hold them; V^T is read in that
 // same order), so P never touches LDS.  Output: 4 consecutive head channels per lane -> 8-byte stores.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -32,6 +34,10 @@ template <> struct Frag<bf16> {
 };
 
 constexpr float NEG_BIG = -1.0e30f;
+#ifndef ETAINV_QT40
+#define ETAINV_QT40 4
+#endif
+constexpr int SELF_QT(int d) { return d == 40 ? ETAINV_QT40 : 2; }
 
 // batch-row roles for the backward layout [u_s x B, u_t x B, c_s x B, c_t x B]
 __device__ __forceinline__ void row_roles(int b, int n_img, int& half, int& role, int& img) {
@@ -56,10 +62,14 @@ __global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qk
   constexpr int KSTR = DP + 8;
   constexpr int VSTR = KV + 8;
   constexpr int NLD = (KV * NCH + 255) / 256;
+  constexpr int KBUF = KV * KSTR, VBUF = DT * 16 * VSTR;
+  // When D is not a multiple of 16 the padded V^T rows are free MFMA work: row D is all ones, so O^T row D = sum_k p
+  // (the softmax denominator, rescaled with the same alpha as O) and the per-element VALU add disappears.
+  constexpr bool ONES_ROW = (DT * 16 > D);
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* sK = reinterpret_cast<T*>(smem);      // [KV][KSTR]
-  T* sVt = sK + KV * KSTR;                 // [DT*16][VSTR]
+  T* sK = reinterpret_cast<T*>(smem);      // [2][KV][KSTR]
+  T* sVt = sK + 2 * KBUF;                  // [2][DT*16][VSTR]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, q4 = lane >> 4;
@@ -74,12 +84,20 @@ __global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qk
   }
   const int q_base = blockIdx.x * (64 * QT) + wid * (16 * QT);
 
-  // zero the K padding columns once (Q pad is zero too, but 0 * garbage could be NaN)
+  // one-time LDS init (both buffers): zero K padding columns (0 * garbage could be NaN), V^T padding rows (ones row)
   if (DP > D) {
     constexpr int PCH = (DP - D) / 8;
-    for (int idx = tid; idx < KV * PCH; idx += 256) {
-      int key = idx / PCH, ch = idx % PCH;
-      *reinterpret_cast<u32x4*>(sK + key * KSTR + D + ch * 8) = (u32x4){0u, 0u, 0u, 0u};
+    for (int idx = tid; idx < 2 * KV * PCH; idx += 256) {
+      const int bufi = idx / (KV * PCH), r = idx % (KV * PCH);
+      const int key = r / PCH, ch = r % PCH;
+      *reinterpret_cast<u32x4*>(sK + bufi * KBUF + key * KSTR + D + ch * 8) = (u32x4){0u, 0u, 0u, 0u};
+    }
+  }
+  if (ONES_ROW) {
+    for (int idx = tid; idx < 2 * (DT * 16 - D) * KV; idx += 256) {
+      const int bufi = idx / ((DT * 16 - D) * KV), r = idx % ((DT * 16 - D) * KV);
+      const int row = D + r / KV, key = r % KV;
+      sVt[bufi * VBUF + row * VSTR + key] = (T)(row == D ? 1.0f : 0.0f);
     }
   }
 
@@ -121,25 +139,28 @@ __global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qk
       rv[i] = c;
     }
   };
-  auto store_kv = [&]() {
+  auto store_kv = [&](int bufi) {
+    T* dK = sK + bufi * KBUF;
+    T* dV = sVt + bufi * VBUF;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = tid + 256 * i;
       if (idx < KV * NCH) {
         {
           const int key = idx / NCH, ch = idx % NCH;
-          *reinterpret_cast<u32x4*>(sK + key * KSTR + ch * 8) = rk[i];
+          *reinterpret_cast<u32x4*>(dK + key * KSTR + ch * 8) = rk[i];
         }
         {
           const int key = idx % KV, ch = idx / KV;
           const T* e = reinterpret_cast<const T*>(&rv[i]);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) sVt[(ch * 8 + j) * VSTR + key] = e[j];
+          for (int j = 0; j < 8; ++j) dV[(ch * 8 + j) * VSTR + key] = e[j];
         }
       }
     }
   };
 
+  // running max of the RAW scores (scale folded into the exponent: p = exp2(s*c - m*c), one FMA + one v_exp per element)
   float m_run[QT], l_run[QT];
   f32x4 acc[QT][DT];
 #pragma unroll
@@ -152,13 +173,15 @@ __global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qk
 
   const int ntiles = (N + KV - 1) / KV;
   load_kv(0);
-  __syncthreads();  // pad zeroing done
-  store_kv();
+  store_kv(0);
   __syncthreads();
 
-  for (int j = 0; j < ntiles; ++j) {
-    const int kv0 = j * KV;
+  auto tile_body = [&](int j, auto ragged_tag) {
+    constexpr bool RAGGED = decltype(ragged_tag)::value;
+    const int kv0 = j * KV, cur = j & 1;
     if (j + 1 < ntiles) load_kv(kv0 + KV);
+    const T* tK = sK + cur * KBUF;
+    const T* tV = sVt + cur * VBUF;
 
     // ---- S^T = K Q^T : s[qt][kt] holds keys kt*16 + q4*4 + r for query fr
     f32x4 s[QT][4];
@@ -170,40 +193,43 @@ __global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qk
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        v8 kf = *reinterpret_cast<const v8*>(sK + (kt * 16 + fr) * KSTR + ks * 32 + q4 * 8);
+        v8 kf = *reinterpret_cast<const v8*>(tK + (kt * 16 + fr) * KSTR + ks * 32 + q4 * 8);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) s[qt][kt] = Frag<T>::mfma(kf, qf[qt][ks], s[qt][kt]);
       }
+    if constexpr (RAGGED) {   // only the last tile of a sequence that is not a multiple of 64 keys
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kv0 + kt * 16 + q4 * 4 + r >= N) s[qt][kt][r] = NEG_BIG;
+    }
 
     // ---- online softmax per query (lane-local + 2 shuffles), P packed straight into PV operands
     v8 pf[QT][2];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-      float mx = NEG_BIG;
+      float mx = fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), fmaxf(s[qt][0][2], s[qt][0][3]));
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = s[qt][kt][r] * scale_log2;
-          if (kv0 + kt * 16 + q4 * 4 + r >= N) v = NEG_BIG;
-          s[qt][kt][r] = v;
-          mx = fmaxf(mx, v);
-        }
+      for (int kt = 1; kt < 4; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(s[qt][kt][0], s[qt][kt][1])), fmaxf(s[qt][kt][2], s[qt][kt][3]));
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[qt], mx);
-      const float alpha = exp2f(m_run[qt] - m_new);
+      const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * scale_log2);
       m_run[qt] = m_new;
+      const float nm = -m_new * scale_log2;
       float rs = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float p = exp2f(s[qt][kt][r] - m_new);
-          rs += p;
-          pf[qt][kt >> 1][(kt & 1) * 4 + r] = (T)p;
+          const float pv = __builtin_amdgcn_exp2f(fmaf(s[qt][kt][r], scale_log2, nm));
+          if (!ONES_ROW) rs += pv;
+          pf[qt][kt >> 1][(kt & 1) * 4 + r] = (T)pv;
         }
-      l_run[qt] = l_run[qt] * alpha + rs;
+      if (!ONES_ROW) l_run[qt] = l_run[qt] * alpha + rs;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) acc[qt][dt] *= alpha;
     }
@@ -213,7 +239,7 @@ __global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qk
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const T* vp = sVt + (dt * 16 + fr) * VSTR + ks * 32 + q4 * 4;
+        const T* vp = tV + (dt * 16 + fr) * VSTR + ks * 32 + q4 * 4;
         v4 lo = *reinterpret_cast<const v4*>(vp);
         v4 hi = *reinterpret_cast<const v4*>(vp + 16);
         v8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -221,19 +247,25 @@ __global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qk
         for (int qt = 0; qt < QT; ++qt) acc[qt][dt] = Frag<T>::mfma(vf, pf[qt][ks], acc[qt][dt]);
       }
 
+    if (j + 1 < ntiles) store_kv(cur ^ 1);   // buffer cur^1 was last read in iteration j-1, a barrier ago
     __syncthreads();
-    if (j + 1 < ntiles) {
-      store_kv();
-      __syncthreads();
-    }
-  }
+  };
+  const int nfull = N / KV;
+  for (int j = 0; j < nfull; ++j) tile_body(j, std::false_type{});
+  if (nfull < ntiles) tile_body(nfull, std::true_type{});
 
   // ---- normalise and store: lane holds channels dt*16 + q4*4 + r of query fr
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    float l = l_run[qt];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    float l;
+    if (ONES_ROW) {
+      // denominator = O^T row D: tile DT-1, lane group q4 = (D % 16) / 4, register (D % 4) == 0
+      l = __shfl(acc[qt][DT - 1][D % 4], fr + 16 * ((D % 16) / 4), 64);
+    } else {
+      l = l_run[qt];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
     const float inv = 1.f / l;
     const int query = q_base + qt * 16 + fr;
     if (query >= N) continue;
@@ -450,9 +482,14 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
 
 template <typename T, int D>
 static int launch_self_t(const void* qkv, void* out, int b, int n, int heads, int mode, int n_img, hipStream_t s) {
-  constexpr int QT = 2;
+  constexpr int QT = SELF_QT(D);
   constexpr int DP = (D + 31) / 32 * 32, DT = (D + 15) / 16;
-  const size_t lds = (size_t)(64 * (DP + 8) + DT * 16 * (64 + 8)) * sizeof(T);
+  const size_t lds = (size_t)2 * (64 * (DP + 8) + DT * 16 * (64 + 8)) * sizeof(T);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_kernel<T, D, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
   const float scale_log2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
   ProfScope prof(PROF_SELF_ATTN, 4.0 * (double)b * heads * (double)n * (double)n * D, s);
   hipLaunchKernelGGL((self_attn_kernel<T, D, QT>), dim3(cdiv(n, 64 * QT), heads, b), dim3(256), lds, s, (const T*)qkv, (T*)out, n,

@@ -8,7 +8,11 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 pids=()
 for f in step_kernels igemm norm attention misc maps; do
   if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/kernels.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/etainv.h" -nt "$HERE/obj/$f.o" ]; then
-    hipcc $FLAGS -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" &
+    EXTRA=""
+    # attention: keep MFMA results in VGPRs (the softmax consumes them on the VALU: no v_accvgpr moves) and drop the
+    # NaN-canonicalising v_max the compiler inserts in front of every fmaxf on MFMA outputs
+    if [ "$f" = "attention" ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans"; fi
+    hipcc $FLAGS $EXTRA -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" &
     pids+=($!)
   fi
 done

@@ -9,8 +9,11 @@
 // The weight tile is fed as the MFMA A operand and the activation tile as B, so an accumulator holds
 // 4 consecutive OUTPUT CHANNELS of one pixel per lane -> 8-byte NHWC stores, lane-local GEGLU pairing.
 // LDS image: [rows][8 x 16B chunks], physical chunk = chunk ^ (row & 7): conflict-free ds_read_b128
-// (bank analysis in DESIGN.md).  Double-buffered LDS, global loads for tile k+1 in flight during the MFMAs
-// of tile k, one barrier per K tile.
+// (16 lanes of a ds_read_b128 group hit 16 distinct (128-B half, 16-B slot) pairs).  Staging is direct-to-LDS
+// (global_load_lds_dwordx4, no VGPR round trip, no ds_write): the LDS image of one wave-instruction is lane-linear
+// (8 rows x 128 B), so the XOR swizzle is applied to the per-lane SOURCE chunk; zero padding of the 3x3 halo reads
+// a 16-byte zero page.  Double-buffered LDS: the DMA of tile k+1 is in flight during the MFMAs of tile k, one
+// vmcnt(0) + barrier per K tile.
 // Epilogue (fused): + bias[n] + rowvec[batch][n] (time-embedding projection) + residual[m][n], or GEGLU
 // a * gelu_erf(g) with (a, g) columns interleaved per 32-column group at weight-pack time.
 #include "common.h"
@@ -61,8 +64,9 @@ __global__ void __launch_bounds__(256) igemm_kernel(IGemmParams p) {
   const int HWo = p.Ho * p.Wo;
   const int Hin = p.ups ? p.H * 2 : p.H, Win = p.ups ? p.W * 2 : p.W;
 
-  // per-thread staging geometry: row = (tid >> 3) + 32 * i, 16-byte chunk = tid & 7
-  const int chunk = tid & 7;
+  // per-thread staging geometry: row = (tid >> 3) + 32 * i; the lane's LDS slot is chunk (tid & 7) of that row (lane-linear
+  // DMA image), which must hold LOGICAL chunk (tid & 7) ^ (row & 7); row & 7 == (tid >> 3) & 7 for every i.
+  const int lchunk = (tid & 7) ^ ((tid >> 3) & 7);
   int a_b[A_LOADS], a_y[A_LOADS], a_x[A_LOADS];
 #pragma unroll
   for (int i = 0; i < A_LOADS; ++i) {
@@ -79,41 +83,33 @@ __global__ void __launch_bounds__(256) igemm_kernel(IGemmParams p) {
   for (int i = 0; i < B_LOADS; ++i) {
     int n = n0 + (tid >> 3) + 32 * i;
     n = n < p.N ? n : p.N - 1;
-    w_row[i] = reinterpret_cast<const T*>(p.w) + (int64_t)n * (p.taps * cin) + chunk * 8;
+    w_row[i] = reinterpret_cast<const T*>(p.w) + (int64_t)n * (p.taps * cin) + lchunk * 8;
   }
+  const T* zero_page = reinterpret_cast<const T*>(p.zeros);
+  const int wrow0 = __builtin_amdgcn_readfirstlane(wid) * 8;   // first LDS row of this wave's 1-KiB DMA piece
 
-  u32x4 ra[A_LOADS], rb[B_LOADS];
-
-  auto load_tile = [&](int kt) {
+  auto issue_tile = [&](int kt, int buf) {
     const int tap = kt / kc, c0 = (kt - tap * kc) * BK;
     const int ky = (p.taps == 9) ? tap / 3 : 0, kx = (p.taps == 9) ? tap - ky * 3 : 0;
     const bool second = c0 >= p.c1;
     const T* src = reinterpret_cast<const T*>(second ? p.a2 : p.a1);
     const int cs = second ? p.c2 : p.c1;
-    const int coff = (second ? c0 - p.c1 : c0) + chunk * 8;
+    const int coff = (second ? c0 - p.c1 : c0) + lchunk * 8;
+    T* dA = sA + buf * BM * BK;
+    T* dB = sB + buf * BN * BK;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       int iy = a_y[i] + ky, ix = a_x[i] + kx;
-      bool ok = (iy >= 0) & (iy < Hin) & (ix >= 0) & (ix < Win);
+      const bool ok = (iy >= 0) & (iy < Hin) & (ix >= 0) & (ix < Win);
       if (p.ups) { iy >>= 1; ix >>= 1; }
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) v = *reinterpret_cast<const u32x4*>(src + ((int64_t)(a_b[i] * p.H + iy) * p.W + ix) * cs + coff);
-      ra[i] = v;
+      const T* g = ok ? src + ((int64_t)(a_b[i] * p.H + iy) * p.W + ix) * cs + coff : zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(dA + (wrow0 + 32 * i) * BK), 16, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) rb[i] = *reinterpret_cast<const u32x4*>(w_row[i] + (int64_t)kt * BK);
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-      int row = (tid >> 3) + 32 * i;
-      *reinterpret_cast<u32x4*>(sA + buf * BM * BK + row * BK + ((chunk ^ (row & 7)) << 3)) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      int row = (tid >> 3) + 32 * i;
-      *reinterpret_cast<u32x4*>(sB + buf * BN * BK + row * BK + ((chunk ^ (row & 7)) << 3)) = rb[i];
-    }
+    for (int i = 0; i < B_LOADS; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_row[i] + (int64_t)kt * BK),
+                                       (__attribute__((address_space(3))) void*)(dB + (wrow0 + 32 * i) * BK), 16, 0, 0);
   };
 
   f32x4 acc[MT][NT];
@@ -122,14 +118,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(IGemmParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  load_tile(0);
-  store_tile(0);
+  issue_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+    if (kt + 1 < nk) issue_tile(kt + 1, cur ^ 1);
     const T* tA = sA + cur * BM * BK;
     const T* tB = sB + cur * BN * BK;
 #pragma unroll
@@ -150,7 +146,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(IGemmParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = Mfma<T>::run(fb[j], fa[i], acc[i][j]);
     }
-    if (kt + 1 < nk) store_tile(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
@@ -218,7 +214,14 @@ static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
   return 0;
 }
 
-int launch_igemm(const IGemmParams& p, int dtype, hipStream_t s) {
+int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
+  static void* zero_page = nullptr;   // 256 zero bytes read by the halo lanes of the 3x3 taps (one-time allocation)
+  if (!zero_page) {
+    ETAINV_HIP(hipMalloc(&zero_page, 256));
+    ETAINV_HIP(hipMemset(zero_page, 0, 256));
+  }
+  IGemmParams p = p_in;
+  p.zeros = zero_page;
   ETAINV_CHECK(p.a1 && p.w && p.out, "null pointer");
   ETAINV_CHECK(p.M > 0 && p.N > 0 && (p.N % 4) == 0, "N must be a positive multiple of 4");
   ETAINV_CHECK(p.c1 % BK == 0 && p.c2 % BK == 0 && (p.c1 + p.c2) > 0, "channel counts must be multiples of 64");

@@ -15,6 +15,7 @@ struct IGemmParams {
   int out_f32 = 0;                  // store fp32 instead of T (time-embedding projections)
   const void* residual = nullptr;   // [M][N]
   void* out = nullptr;              // [M][N]  (or [M][N/2] with geglu)
+  const void* zeros = nullptr;      // filled in by launch_igemm
   int M = 0, N = 0;
   int c1 = 0, c2 = 0;
   int H = 1, W = 1;           // source spatial dims (before the fused upsample)
