@@ -65,7 +65,15 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact (erf) GELU; erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, ~14 instructions instead of libm erff's ~40:
+// the GEGLU epilogue evaluates it 32 times per lane per output tile)
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

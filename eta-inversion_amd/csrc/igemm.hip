@@ -16,6 +16,8 @@
 // vmcnt(0) + barrier per K tile.
 // Epilogue (fused): + bias[n] + rowvec[batch][n] (time-embedding projection) + residual[m][n], or GEGLU
 // a * gelu_erf(g) with (a, g) columns interleaved per 32-column group at weight-pack time.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -33,12 +35,15 @@ template <> struct Mfma<bf16> {
 
 constexpr int BK = 64;  // K elements per LDS tile (8 chunks of 16 B per row)
 
-template <typename T, int BM, int BN>
-__global__ void __launch_bounds__(256) igemm_kernel(IGemmParams p) {
-  constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
+template <typename T, int BM, int BN, int WAVES_M>
+__global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) {
+  constexpr int NTHR = WAVES_M * 128;      // WAVES_M x 2 waves
+  constexpr int RP = NTHR / 8;             // LDS rows staged per pass (8 lanes x 16 B per 128-B row)
+  constexpr int WM = BM / WAVES_M, WN = BN / 2;  // wave tile
   constexpr int MT = WM / 16, NT = WN / 16;
-  constexpr int A_LOADS = BM * BK * 2 / (256 * 16);
-  constexpr int B_LOADS = BN * BK * 2 / (256 * 16);
+  constexpr int A_LOADS = BM / RP;
+  constexpr int B_LOADS = (BN + RP - 1) / RP;
+  static_assert(BM % RP == 0, "A tile rows must be a multiple of the rows per pass");
   typedef typename Mfma<T>::frag frag;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -48,14 +53,23 @@ __global__ void __launch_bounds__(256) igemm_kernel(IGemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
+  const int fr = lane & 15, fq = lane >> 4;
 
-  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
-  // contiguous run of tiles; n varies fastest so neighbours reuse the same activation panel from L2.
-  const int nblk = gridDim.x;
-  int bid = blockIdx.x;
-  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  // PERSISTENT blocks: block b owns output tiles b, b + G, b + 2G, ... and runs ONE flattened (tile, k-tile) pipeline, so
+  // the DMA of the next tile's first K tile is in flight during the epilogue of the current one (short-K GEMMs --
+  // K = 320 is only 5 K tiles -- otherwise pay a full memory latency + an unoverlapped epilogue per tile).
+  // XCD-aware order: virtual ids v and v + 8 share an XCD (round-robin dispatch, G % 8 == 0), so each XCD walks a
+  // contiguous run of tiles, n fastest: neighbours reuse the same activation panel from that XCD's L2.
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  const int total_tiles = ((p.M + BM - 1) / BM) * tiles_n;
+  const int G = gridDim.x;
+  const int my_tiles = (total_tiles - (int)blockIdx.x + G - 1) / G;
+  auto tile_origin = [&](int i, int& m0, int& n0) {
+    int v = blockIdx.x + i * G;
+    if ((total_tiles & 7) == 0) v = (v & 7) * (total_tiles >> 3) + (v >> 3);
+    m0 = (v / tiles_n) * BM;
+    n0 = (v - (v / tiles_n) * tiles_n) * BN;
+  };
 
   const int cin = p.c1 + p.c2;
   const int kc = cin / BK;            // K tiles per tap
@@ -68,23 +82,27 @@ __global__ void __launch_bounds__(256) igemm_kernel(IGemmParams p) {
   // DMA image), which must hold LOGICAL chunk (tid & 7) ^ (row & 7); row & 7 == (tid >> 3) & 7 for every i.
   const int lchunk = (tid & 7) ^ ((tid >> 3) & 7);
   int a_b[A_LOADS], a_y[A_LOADS], a_x[A_LOADS];
-#pragma unroll
-  for (int i = 0; i < A_LOADS; ++i) {
-    int m = m0 + (tid >> 3) + 32 * i;
-    m = m < p.M ? m : p.M - 1;
-    int b = m / HWo, r = m - b * HWo;
-    int oy = r / p.Wo, ox = r - oy * p.Wo;
-    a_b[i] = b;
-    a_y[i] = oy * p.stride - pad;
-    a_x[i] = ox * p.stride - pad;
-  }
   const T* w_row[B_LOADS];
+  auto setup_issue = [&](int i) {   // geometry of the tile whose K tiles are being prefetched
+    int m0, n0;
+    tile_origin(i, m0, n0);
 #pragma unroll
-  for (int i = 0; i < B_LOADS; ++i) {
-    int n = n0 + (tid >> 3) + 32 * i;
-    n = n < p.N ? n : p.N - 1;
-    w_row[i] = reinterpret_cast<const T*>(p.w) + (int64_t)n * (p.taps * cin) + lchunk * 8;
-  }
+    for (int q = 0; q < A_LOADS; ++q) {
+      int m = m0 + (tid >> 3) + RP * q;
+      m = m < p.M ? m : p.M - 1;
+      int b = m / HWo, r = m - b * HWo;
+      int oy = r / p.Wo, ox = r - oy * p.Wo;
+      a_b[q] = b;
+      a_y[q] = oy * p.stride - pad;
+      a_x[q] = ox * p.stride - pad;
+    }
+#pragma unroll
+    for (int q = 0; q < B_LOADS; ++q) {
+      int n = n0 + (tid >> 3) + RP * q;
+      n = n < p.N ? n : p.N - 1;
+      w_row[q] = reinterpret_cast<const T*>(p.w) + (int64_t)n * (p.taps * cin) + lchunk * 8;
+    }
+  };
   const T* zero_page = reinterpret_cast<const T*>(p.zeros);
   const int wrow0 = __builtin_amdgcn_readfirstlane(wid) * 8;   // first LDS row of this wave's 1-KiB DMA piece
 
@@ -104,12 +122,13 @@ __global__ void __launch_bounds__(256) igemm_kernel(IGemmParams p) {
       if (p.ups) { iy >>= 1; ix >>= 1; }
       const T* g = ok ? src + ((int64_t)(a_b[i] * p.H + iy) * p.W + ix) * cs + coff : zero_page;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(dA + (wrow0 + 32 * i) * BK), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dA + (wrow0 + RP * i) * BK), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_row[i] + (int64_t)kt * BK),
-                                       (__attribute__((address_space(3))) void*)(dB + (wrow0 + 32 * i) * BK), 16, 0, 0);
+      if (BN % RP == 0 || wrow0 + RP * i < BN)   // wave-uniform: a wave stages 8 whole rows
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_row[i] + (int64_t)kt * BK),
+                                         (__attribute__((address_space(3))) void*)(dB + (wrow0 + RP * i) * BK), 16, 0, 0);
   };
 
   f32x4 acc[MT][NT];
@@ -118,14 +137,78 @@ __global__ void __launch_bounds__(256) igemm_kernel(IGemmParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  T* out = reinterpret_cast<T*>(p.out);
+  const T* res = reinterpret_cast<const T*>(p.residual);
+  // ---- epilogue: lane holds out[m][n .. n+3], m = pixel (MFMA column), n = channel (MFMA row)
+  auto epilogue = [&](int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * WM + i * 16 + fr;
+      const bool m_ok = m < p.M;
+      const int batch = m / p.rows_per_batch;
+      if (!p.geglu) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = n0 + wn * WN + j * 16 + fq * 4;
+          f32x4 v = acc[i][j];
+          acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (!m_ok || n >= p.N) continue;
+          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+          if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)batch * p.rowvec_stride + n);
+          if (res) {
+            const T* r = res + (int64_t)m * p.N + n;
+            v[0] += to_f32(r[0]); v[1] += to_f32(r[1]); v[2] += to_f32(r[2]); v[3] += to_f32(r[3]);
+          }
+          if (p.out_f32) {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.N + n) = v;
+          } else {
+            T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+            *reinterpret_cast<u32x2*>(out + (int64_t)m * p.N + n) = *reinterpret_cast<u32x2*>(o);
+          }
+        }
+      } else {
+        // GEGLU: wave columns [0, WN/2) hold a, [WN/2, WN) hold the matching gate g (weight rows interleaved per
+        // WN-column group by pack mode 2); output width N/2.
+        const int No = p.N >> 1;
+#pragma unroll
+        for (int j = 0; j < NT / 2; ++j) {
+          const int n = n0 + wn * WN + j * 16 + fq * 4;            // physical column of a
+          const int no = ((n0 + wn * WN) >> 1) + j * 16 + fq * 4;  // output column
+          f32x4 a = acc[i][j], g = acc[i][j + NT / 2];
+          acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          acc[i][j + NT / 2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (!m_ok) continue;
+          if (p.bias) {
+            a += *reinterpret_cast<const f32x4*>(p.bias + n);
+            g += *reinterpret_cast<const f32x4*>(p.bias + n + WN / 2);
+          }
+          T o[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(a[q] * gelu_erf_f(g[q]));
+          *reinterpret_cast<u32x2*>(out + (int64_t)m * No + no) = *reinterpret_cast<u32x2*>(o);
+        }
+      }
+    }
+  };
+
+  if (my_tiles <= 0) return;
+  int it_tile = 0, it_kt = 0;          // (tile, k-tile) being issued, one step ahead of the compute
+  setup_issue(0);
   issue_tile(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  const int fr = lane & 15, fq = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) issue_tile(kt + 1, cur ^ 1);
+  const int total_steps = my_tiles * nk;
+  int ct_tile = 0, ct_kt = 0;          // (tile, k-tile) being computed
+  for (int sidx = 0; sidx < total_steps; ++sidx) {
+    const int cur = sidx & 1;
+    if (sidx + 1 < total_steps) {
+      if (++it_kt == nk) {
+        it_kt = 0;
+        setup_issue(++it_tile);
+      }
+      issue_tile(it_kt, cur ^ 1);
+    }
     const T* tA = sA + cur * BM * BK;
     const T* tB = sB + cur * BN * BK;
 #pragma unroll
@@ -146,70 +229,32 @@ __global__ void __launch_bounds__(256) igemm_kernel(IGemmParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = Mfma<T>::run(fb[j], fa[i], acc[i][j]);
     }
+    if (++ct_kt == nk) {
+      int m0, n0;
+      tile_origin(ct_tile, m0, n0);
+      epilogue(m0, n0);
+      ct_kt = 0;
+      ++ct_tile;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-
-  // ---- epilogue: lane holds out[m][n .. n+3], m = pixel (MFMA column), n = channel (MFMA row)
-  T* out = reinterpret_cast<T*>(p.out);
-  const T* res = reinterpret_cast<const T*>(p.residual);
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = m0 + wm * WM + i * 16 + fr;
-    if (m >= p.M) continue;
-    const int batch = m / p.rows_per_batch;
-    if (!p.geglu) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = n0 + wn * WN + j * 16 + fq * 4;
-        if (n >= p.N) continue;
-        f32x4 v = acc[i][j];
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-        if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)batch * p.rowvec_stride + n);
-        if (res) {
-          const T* r = res + (int64_t)m * p.N + n;
-          v[0] += to_f32(r[0]); v[1] += to_f32(r[1]); v[2] += to_f32(r[2]); v[3] += to_f32(r[3]);
-        }
-        if (p.out_f32) {
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.N + n) = v;
-        } else {
-          T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
-          *reinterpret_cast<u32x2*>(out + (int64_t)m * p.N + n) = *reinterpret_cast<u32x2*>(o);
-        }
-      }
-    } else {
-      // GEGLU: wave columns [0, WN/2) hold a, [WN/2, WN) hold the matching gate g (weight rows interleaved per
-      // WN-column group by pack_geglu_rows); output width N/2.
-      const int No = p.N >> 1;
-#pragma unroll
-      for (int j = 0; j < NT / 2; ++j) {
-        const int n = n0 + wn * WN + j * 16 + fq * 4;          // physical column of a
-        const int no = ((n0 + wn * WN) >> 1) + j * 16 + fq * 4;  // output column
-        f32x4 a = acc[i][j], g = acc[i][j + NT / 2];
-        if (p.bias) {
-          a += *reinterpret_cast<const f32x4*>(p.bias + n);
-          g += *reinterpret_cast<const f32x4*>(p.bias + n + WN / 2);
-        }
-        T o[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(a[q] * gelu_erf_f(g[q]));
-        *reinterpret_cast<u32x2*>(out + (int64_t)m * No + no) = *reinterpret_cast<u32x2*>(o);
-      }
-    }
-  }
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int WAVES_M>
 static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
   const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
   const size_t lds = 2 * (BM + BN) * BK * sizeof(T);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WAVES_M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  // persistent grid: as many blocks as are resident at once (LDS-limited: 160 KiB / lds per CU, 256 CUs), a multiple of 8
+  const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / lds)));
+  const int grid = std::min(tiles, 256 * per_cu);
   ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s);
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(tiles), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M>), dim3(grid), dim3(WAVES_M * 128), lds, s, p);
   ETAINV_LAUNCH_CHECK();
   return 0;
 }
@@ -233,10 +278,19 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
   // so the packing of a GEGLU weight fixes its tile: always 128 wide)
   const int64_t big_tiles = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128);
   const bool big = p.geglu || big_tiles >= 192;
-  if (big) {
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 128, 128>(p, s)));
+  const int64_t huge_tiles = (int64_t)cdiv(p.M, 256) * cdiv(p.N, 160);
+  if (!p.geglu && p.N % 160 == 0 && huge_tiles >= 256 && getenv("ETAINV_TILE256")) {
+    // experimental (opt-in): 256 x 160 x 64 tile, 8 waves, one resident block per CU (26 % fewer L2 -> LDS bytes per
+    // FLOP).  Measured equal to 128 x 160 with two resident blocks (1026 vs 1033 TFLOP/s on conv 1280->1280 @16x16)
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4>(p, s)));
+  } else if (big && !p.geglu && p.N % 160 == 0) {
+    // every channel count of SD1.x is a multiple of 320: 160-wide tiles leave no padded columns (N = 320 would waste
+    // 17 % of a 3 x 128 tiling) and a 64 x 80 wave tile does 20 MFMAs per 9 fragment reads
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 128, 160, 2>(p, s)));
+  } else if (big) {
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 128, 128, 2>(p, s)));
   } else {
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 64, 64>(p, s)));
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 64, 64, 2>(p, s)));
   }
   return 0;
 }
