@@ -35,7 +35,7 @@ template <> struct Mfma<bf16> {
 
 constexpr int BK = 64;  // K elements per LDS tile (8 chunks of 16 B per row)
 
-template <typename T, int BM, int BN, int WAVES_M>
+template <typename T, int BM, int BN, int WAVES_M, int STAGES>
 __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) {
   constexpr int NTHR = WAVES_M * 128;      // WAVES_M x 2 waves
   constexpr int RP = NTHR / 8;             // LDS rows staged per pass (8 lanes x 16 B per 128-B row)
@@ -47,8 +47,8 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   typedef typename Mfma<T>::frag frag;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* sA = reinterpret_cast<T*>(smem);                       // [2][BM*BK]
-  T* sB = reinterpret_cast<T*>(smem) + 2 * BM * BK;         // [2][BN*BK]
+  T* sA = reinterpret_cast<T*>(smem);                       // [STAGES][BM*BK]
+  T* sB = reinterpret_cast<T*>(smem) + STAGES * BM * BK;    // [STAGES][BN*BK]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -82,6 +82,8 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   // DMA image), which must hold LOGICAL chunk (tid & 7) ^ (row & 7); row & 7 == (tid >> 3) & 7 for every i.
   const int lchunk = (tid & 7) ^ ((tid >> 3) & 7);
   int a_b[A_LOADS], a_y[A_LOADS], a_x[A_LOADS];
+  // fast path (no upsample): element offset of tap (0,0) in source 1 / source 2 (lane chunk included) and 9-bit tap validity
+  int a_e1[A_LOADS], a_e2[A_LOADS], a_mask[A_LOADS];
   const T* w_row[B_LOADS];
   auto setup_issue = [&](int i) {   // geometry of the tile whose K tiles are being prefetched
     int m0, n0;
@@ -95,6 +97,16 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       a_b[q] = b;
       a_y[q] = oy * p.stride - pad;
       a_x[q] = ox * p.stride - pad;
+      const int pix0 = (b * p.H + a_y[q]) * p.W + a_x[q];
+      a_e1[q] = pix0 * p.c1 + lchunk * 8;
+      a_e2[q] = pix0 * p.c2 + lchunk * 8;
+      int mask = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = a_y[q] + t / 3, ix = a_x[q] + t % 3;
+        mask |= ((iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W)) << t;
+      }
+      a_mask[q] = p.taps == 9 ? mask : 1;
     }
 #pragma unroll
     for (int q = 0; q < B_LOADS; ++q) {
@@ -106,23 +118,38 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   const T* zero_page = reinterpret_cast<const T*>(p.zeros);
   const int wrow0 = __builtin_amdgcn_readfirstlane(wid) * 8;   // first LDS row of this wave's 1-KiB DMA piece
 
+  // position of the K tile being issued, advanced incrementally (no integer division in the loop)
+  int it_tap = 0, it_c0 = 0, it_ky = 0, it_kx = 0;
   auto issue_tile = [&](int kt, int buf) {
-    const int tap = kt / kc, c0 = (kt - tap * kc) * BK;
-    const int ky = (p.taps == 9) ? tap / 3 : 0, kx = (p.taps == 9) ? tap - ky * 3 : 0;
+    const int tap = it_tap, c0 = it_c0, ky = it_ky, kx = it_kx;
     const bool second = c0 >= p.c1;
     const T* src = reinterpret_cast<const T*>(second ? p.a2 : p.a1);
     const int cs = second ? p.c2 : p.c1;
     const int coff = (second ? c0 - p.c1 : c0) + lchunk * 8;
     T* dA = sA + buf * BM * BK;
     T* dB = sB + buf * BN * BK;
+    if (!p.ups) {
+      // per K tile and load: one add of a wave-uniform element offset, one shift-add onto the (scalar) base, a validity select
+      const int uoff = (ky * p.W + kx) * cs + (second ? c0 - p.c1 : c0);
 #pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-      int iy = a_y[i] + ky, ix = a_x[i] + kx;
-      const bool ok = (iy >= 0) & (iy < Hin) & (ix >= 0) & (ix < Win);
-      if (p.ups) { iy >>= 1; ix >>= 1; }
-      const T* g = ok ? src + ((int64_t)(a_b[i] * p.H + iy) * p.W + ix) * cs + coff : zero_page;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(dA + (wrow0 + RP * i) * BK), 16, 0, 0);
+      for (int i = 0; i < A_LOADS; ++i) {
+        const bool ok = (a_mask[i] >> tap) & 1;
+        const unsigned elem = (unsigned)((second ? a_e2[i] : a_e1[i]) + uoff);   // garbage for halo lanes, never dereferenced
+        const T* g = ok ? src + elem : zero_page;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(dA + (wrow0 + RP * i) * BK), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) {
+        int iy = a_y[i] + ky, ix = a_x[i] + kx;
+        const bool ok = (iy >= 0) & (iy < Hin) & (ix >= 0) & (ix < Win);
+        iy >>= 1;
+        ix >>= 1;
+        const T* g = ok ? src + ((int64_t)(a_b[i] * p.H + iy) * p.W + ix) * cs + coff : zero_page;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(dA + (wrow0 + RP * i) * BK), 16, 0, 0);
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i)
@@ -192,25 +219,25 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   };
 
   if (my_tiles <= 0) return;
-  int it_tile = 0, it_kt = 0;          // (tile, k-tile) being issued, one step ahead of the compute
-  setup_issue(0);
-  issue_tile(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
   const int total_steps = my_tiles * nk;
+  int it_tile = 0, it_kt = 0;          // (tile, k-tile) being issued, ahead of the compute
   int ct_tile = 0, ct_kt = 0;          // (tile, k-tile) being computed
-  for (int sidx = 0; sidx < total_steps; ++sidx) {
-    const int cur = sidx & 1;
-    if (sidx + 1 < total_steps) {
-      if (++it_kt == nk) {
-        it_kt = 0;
-        setup_issue(++it_tile);
-      }
-      issue_tile(it_kt, cur ^ 1);
+  auto advance_issue = [&]() {
+    it_c0 += BK;
+    if (it_c0 == cin) {
+      it_c0 = 0;
+      ++it_tap;
+      if (++it_kx == 3) { it_kx = 0; ++it_ky; }
     }
-    const T* tA = sA + cur * BM * BK;
-    const T* tB = sB + cur * BN * BK;
+    if (++it_kt == nk) {
+      it_kt = 0;
+      it_tap = it_ky = it_kx = 0;
+      setup_issue(++it_tile);
+    }
+  };
+  auto compute_stage = [&](int st) {
+    const T* tA = sA + st * BM * BK;
+    const T* tB = sB + st * BN * BK;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       frag fa[MT], fb[NT];
@@ -236,25 +263,118 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       ct_kt = 0;
       ++ct_tile;
     }
+  };
+
+  setup_issue(0);
+  if constexpr (STAGES == 2) {
+    // DMA of step s+1 in flight during the MFMAs of step s; vmcnt(0) + barrier per K tile
+    issue_tile(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    for (int sidx = 0; sidx < total_steps; ++sidx) {
+      const int cur = sidx & 1;
+      if (sidx + 1 < total_steps) {
+        advance_issue();
+        issue_tile(it_kt, cur ^ 1);
+      }
+      compute_stage(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    // 3-slot LDS ring, software-pipelined fragments, COUNTED vmcnt, raw s_barrier (HIP rendition of the "DMA in flight
+    // across the barrier" structure).  Step s (K tile s of the flattened tile stream, slot s % 3):
+    //     F1 <- ds_read(slot s, k-half 1)            F0 (k-half 0 of slot s) is already in registers
+    //     20 MFMAs on F0                              -> matrix pipe has ~320 cycles of queued work
+    //     lgkmcnt(0)   my reads of slot s are retired (slot s may be overwritten after the barrier)
+    //     vmcnt(n)     everything but the newest slot's DMA has landed -> slot s+1 is complete for this wave
+    //     s_barrier    ... and for every wave; the MFMAs queued above keep executing while waves rendezvous
+    //     issue DMA of step s+3 into slot s % 3      two full K tiles of latency slack
+    //     F0 <- ds_read(slot s+1, k-half 0)          latency hidden under the next MFMA cluster
+    //     20 MFMAs on F1;  epilogue if this was the tile's last K tile
+    constexpr int B_FULL = BN / RP;                                     // B passes every wave takes part in
+    const bool extra_b = (BN % RP != 0) && (wrow0 + RP * B_FULL < BN);   // this wave also issues the partial pass
+    auto read_frags = [&](int st, int kk, frag (&fa)[MT], frag (&fb)[NT]) {
+      const T* tA = sA + st * BM * BK;
+      const T* tB = sB + st * BN * BK;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        int row = wm * WM + i * 16 + fr;
+        fa[i] = *reinterpret_cast<const frag*>(tA + row * BK + (((kk * 4 + fq) ^ (row & 7)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        int row = wn * WN + j * 16 + fr;
+        fb[j] = *reinterpret_cast<const frag*>(tB + row * BK + (((kk * 4 + fq) ^ (row & 7)) << 3));
+      }
+    };
+    auto mfma_all = [&](frag (&fa)[MT], frag (&fb)[NT]) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = Mfma<T>::run(fb[j], fa[i], acc[i][j]);
+    };
+    auto wait_one_slot_in_flight = [&]() {
+      if (extra_b) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LOADS + B_FULL + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LOADS + B_FULL) : "memory");
+    };
+    auto wait_two_slots_in_flight = [&]() {
+      if (extra_b) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (A_LOADS + B_FULL + 1)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (A_LOADS + B_FULL)) : "memory");
+    };
+    issue_tile(0, 0);
+    if (total_steps > 1) { advance_issue(); issue_tile(it_kt, 1); }
+    if (total_steps > 2) { advance_issue(); issue_tile(it_kt, 2); }
+    if (total_steps > 2) wait_two_slots_in_flight();
+    else if (total_steps > 1) wait_one_slot_in_flight();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    frag fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+    read_frags(0, 0, fa0, fb0);
+    int slot = 0;
+    for (int sidx = 0; sidx < total_steps; ++sidx) {
+      const int nslot = slot == 2 ? 0 : slot + 1;
+      read_frags(slot, 1, fa1, fb1);
+      mfma_all(fa0, fb0);
+      if (sidx + 1 < total_steps) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (sidx + 2 < total_steps) wait_one_slot_in_flight();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (sidx + 3 < total_steps) {
+          advance_issue();
+          issue_tile(it_kt, slot);
+        }
+        read_frags(nslot, 0, fa0, fb0);
+      }
+      mfma_all(fa1, fb1);
+      if (++ct_kt == nk) {
+        int m0, n0;
+        tile_origin(ct_tile, m0, n0);
+        epilogue(m0, n0);
+        ct_kt = 0;
+        ++ct_tile;
+      }
+      slot = nslot;
+    }
   }
 }
 
-template <typename T, int BM, int BN, int WAVES_M>
+template <typename T, int BM, int BN, int WAVES_M, int STAGES = 2>
 static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
   const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
-  const size_t lds = 2 * (BM + BN) * BK * sizeof(T);
+  const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(T);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WAVES_M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WAVES_M, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   // persistent grid: as many blocks as are resident at once (LDS-limited: 160 KiB / lds per CU, 256 CUs), a multiple of 8
   const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / lds)));
   const int grid = std::min(tiles, 256 * per_cu);
   ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s);
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M>), dim3(grid), dim3(WAVES_M * 128), lds, s, p);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES>), dim3(grid), dim3(WAVES_M * 128), lds, s, p);
   ETAINV_LAUNCH_CHECK();
   return 0;
 }
@@ -279,10 +399,13 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
   const int64_t big_tiles = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128);
   const bool big = p.geglu || big_tiles >= 192;
   const int64_t huge_tiles = (int64_t)cdiv(p.M, 256) * cdiv(p.N, 160);
-  if (!p.geglu && p.N % 160 == 0 && huge_tiles >= 256 && getenv("ETAINV_TILE256")) {
+  if (!p.geglu && p.N % 160 == 0 && huge_tiles >= 256 && !getenv("ETAINV_NO_RING")) {
     // experimental (opt-in): 256 x 160 x 64 tile, 8 waves, one resident block per CU (26 % fewer L2 -> LDS bytes per
     // FLOP).  Measured equal to 128 x 160 with two resident blocks (1026 vs 1033 TFLOP/s on conv 1280->1280 @16x16)
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4>(p, s)));
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3>(p, s)));
+  } else if (p.geglu && p.c1 >= 640 && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 128) >= 256 && !getenv("ETAINV_NO_RING")) {
+    // (K = 320 is only 5 K tiles per output tile: the epilogue-bound case stays on two resident 128 x 128 blocks per CU)
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 128, 4, 3>(p, s)));
   } else if (big && !p.geglu && p.N % 160 == 0) {
     // every channel count of SD1.x is a multiple of 320: 160-wide tiles leave no padded columns (N = 320 would waste
     // 17 % of a 3 x 128 tiling) and a 64 x 80 wave tile does 20 MFMAs per 9 fragment reads
