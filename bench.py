@@ -172,6 +172,10 @@ def main():
     ca_ms, ca_flop, ca_n = prof(2)
     gn_ms, gn_bytes, gn_n = prof(3)
     ln_ms, ln_bytes, ln_n = prof(4)
+    traffic = None          # fabric-side bytes per igemm launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    tfile = ROOT / "profiles" / "r01c_pmc_traffic_rows128.json"   # (tools/unet_call.py --rows 128, tools/pmc_traffic.py)
+    if tfile.exists():
+        traffic = json.load(open(tfile))["igemm"]["hbm_bytes_per_launch"]
     images = B * world * a.steps
     value = images / dt
     if rank == 0:
@@ -186,7 +190,7 @@ def main():
                        "tflop_per_image": FWD_PER_IMAGE * F_UNET_TFLOP, "sharding": f"batch-shard x{world}, final all_gather of latents"},
             "end_to_end_mfma_frac": value / world * FWD_PER_IMAGE * F_UNET_TFLOP / MFMA_PEAK_TFLOPS,
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv3x3 / conv1x1 / linear)", "achieved": achieved,
-                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "launches": ig_n, "avg_launch_ms": ig_ms / max(ig_n, 1), "share_of_wall": ig_ms * 1e-3 / dt},
             "other_kernels": {
                 "self_attention": {"tflops": sa_flop / max(sa_ms, 1e-9) / 1e9, "share_of_wall": sa_ms * 1e-3 / dt, "launches": sa_n},

@@ -343,9 +343,11 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
   }
   __syncthreads();
 
-  const int q_base = blockIdx.x * (64 * QT) + wid * (16 * QT);
+  // a block stages K / V^T once and then walks several 64*QT-query blocks (grid.x < N / (64*QT) at large N)
+  for (int qb = blockIdx.x; qb * (64 * QT) < N; qb += gridDim.x)
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
+    const int q_base = qb * (64 * QT) + wid * (16 * QT);
     int query = q_base + qt * 16 + fr;
     const bool q_ok = query < N;
     query = q_ok ? query : N - 1;
@@ -386,7 +388,7 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float e = exp2f(s[kt][r] - mx);
+          float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
           s[kt][r] = e;
           rs += e;
         }
@@ -522,7 +524,9 @@ static int launch_cross_t(const void* q, const void* kv, void* out, int b, const
     attr = true;
   }
   ProfScope prof(PROF_CROSS_ATTN, 4.0 * (double)b * p.heads * (double)p.N * (double)p.n_ctx * D, s);
-  hipLaunchKernelGGL((cross_attn_kernel<T, D, QT>), dim3(cdiv(p.N, 64 * QT), p.heads, b), dim3(256), lds, s, (const T*)q,
+  const int nqb = cdiv(p.N, 64 * QT);
+  const int gx = std::max(1, std::min(nqb, cdiv(2048, b * p.heads)));   // ~2048+ blocks in flight, K/V staging amortised
+  hipLaunchKernelGGL((cross_attn_kernel<T, D, QT>), dim3(gx, p.heads, b), dim3(256), lds, s, (const T*)q,
                      (const T*)kv, (T*)out, p);
   ETAINV_LAUNCH_CHECK();
   return 0;

@@ -44,7 +44,7 @@ void prof_begin(int cls, double work, hipStream_t s) {
 }
 void prof_end(hipStream_t s) { (void)hipEventRecord(g_prof.back().b, s); }
 
-enum PackMode { PK_PLAIN = 0, PK_CONV = 1, PK_GEGLU = 2, PK_CONV_IN = 3, PK_CONV_OUT = 4 };
+enum PackMode { PK_PLAIN = 0, PK_CONV = 1, PK_GEGLU = 2, PK_CONV_IN = 3, PK_CONV_OUT = 4, PK_CONV_IN_GEMM = 5 };
 
 struct WeightSlot {
   std::string name;
@@ -246,8 +246,8 @@ int build_model(etainv_engine* e) {
   e->tb.reserve(16);
   const int ch[4] = {320, 640, 1280, 1280};
   // conv_in / conv_out keep fp32 weights in their own layouts
-  b.want(&e->conv_in_w, (size_t)36 * ch[0] * 4);
-  b.add_slot("conv_in.weight", {ch[0], 4, 3, 3}, &e->conv_in_w, 0, PK_CONV_IN, 9, ETAINV_F32);
+  b.want(&e->conv_in_w, (size_t)64 * ch[0] * 2);   // [320][64] compute dtype: conv_in runs as a K = 64 GEMM on an im2col buffer
+  b.add_slot("conv_in.weight", {ch[0], 4, 3, 3}, &e->conv_in_w, 0, PK_CONV_IN_GEMM, 9, e->dt);
   b.vec("conv_in.bias", &e->conv_in_b, ch[0]);
   b.linear("time_embedding.linear_1", e->time1, etainv_engine::kTemb, ch[0], true);
   b.linear("time_embedding.linear_2", e->time2, etainv_engine::kTemb, etainv_engine::kTemb, true);
@@ -285,8 +285,8 @@ int build_model(etainv_engine* e) {
     prev = cout;
   }
   b.norm("conv_norm_out", e->norm_out, ch[0]);
-  b.want(&e->conv_out_w, (size_t)9 * ch[0] * 4 * 4);
-  b.add_slot("conv_out.weight", {4, ch[0], 3, 3}, &e->conv_out_w, 0, PK_CONV_OUT, 9, ETAINV_F32);
+  b.want(&e->conv_out_w, (size_t)9 * ch[0] * 4 * 2);   // [4][9][320] compute dtype: conv_out is an N = 4 implicit GEMM
+  b.add_slot("conv_out.weight", {4, ch[0], 3, 3}, &e->conv_out_w, 0, PK_CONV, 9, e->dt);
   b.vec("conv_out.bias", &e->conv_out_b, 4);
   e->tproj.n = e->tproj_total;
   e->tproj.k = etainv_engine::kTemb;
@@ -590,7 +590,15 @@ extern "C" int etainv_unet_forward(etainv_engine_t* e, const void* latent, int n
   if (launch_cast_f32(ctx, io_dtype, e->ctxT, e->dt, (int64_t)n_rows * etainv_engine::kCtx * etainv_engine::kCtxDim, s)) return 1;
 
   // ---- down path
-  if (launch_conv_in(latent, io_dtype, n_lat, n_rows, L, e->conv_in_w, e->conv_in_b, etainv_engine::kCh0, e->skip[0], e->dt, s)) return 1;
+  if (launch_im2col_in(latent, io_dtype, n_lat, n_rows, L, e->gnbuf, e->dt, s)) return 1;
+  {
+    Lin cin_l;
+    cin_l.w = e->conv_in_w;
+    cin_l.b = e->conv_in_b;
+    cin_l.n = etainv_engine::kCh0;
+    cin_l.k = 64;
+    if (f.gemm(e->gnbuf, cin_l, e->skip[0], n_rows * L * L)) return 1;
+  }
   const int ch[4] = {320, 640, 1280, 1280};
   int ri = 0, ti = 0, si = 1, side = L;
   const void* h = e->skip[0];
@@ -655,7 +663,22 @@ extern "C" int etainv_unet_forward(etainv_engine_t* e, const void* latent, int n
   if (launch_groupnorm(h, nullptr, 320, 0, e->norm_out.g, e->norm_out.b, e->gnbuf, n_rows, L * L, etainv_engine::kGroups, 1e-5f, 1,
                        e->gn_scratch, e->dt, s))
     return 1;
-  return launch_conv_out(e->gnbuf, n_rows, L, 320, e->conv_out_w, e->conv_out_b, out, io_dtype, e->dt, s);
+  {
+    IGemmParams p;
+    p.a1 = e->gnbuf;
+    p.w = e->conv_out_w;
+    p.bias = e->conv_out_b;
+    p.out = out;
+    p.out_nchw = 1;
+    p.out_io_dtype = io_dtype;
+    p.c1 = 320;
+    p.H = p.W = p.Ho = p.Wo = L;
+    p.taps = 9;
+    p.M = n_rows * L * L;
+    p.N = 4;
+    p.rows_per_batch = L * L;
+    return launch_igemm(p, e->dt, s);
+  }
 }
 
 extern "C" int etainv_maps_reset(etainv_engine_t* e, void* stream) {

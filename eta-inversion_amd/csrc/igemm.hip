@@ -186,7 +186,16 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
             const T* r = res + (int64_t)m * p.N + n;
             v[0] += to_f32(r[0]); v[1] += to_f32(r[1]); v[2] += to_f32(r[2]); v[3] += to_f32(r[3]);
           }
-          if (p.out_f32) {
+          if (p.out_nchw) {   // conv_out: this lane holds the 4 output channels of pixel m
+            const int64_t base = ((int64_t)batch * 4) * p.rows_per_batch + (m - batch * p.rows_per_batch);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const int64_t o = base + (int64_t)c * p.rows_per_batch;
+              if (p.out_io_dtype == ETAINV_F32) reinterpret_cast<float*>(p.out)[o] = v[c];
+              else if (p.out_io_dtype == ETAINV_F16) reinterpret_cast<f16*>(p.out)[o] = (f16)v[c];
+              else reinterpret_cast<bf16*>(p.out)[o] = (bf16)v[c];
+            }
+          } else if (p.out_f32) {
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.N + n) = v;
           } else {
             T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
@@ -397,7 +406,8 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
   // tile choice: big tiles when they still fill the 256 CUs, else 64x64 (GEGLU pairing is per wave tile,
   // so the packing of a GEGLU weight fixes its tile: always 128 wide)
   const int64_t big_tiles = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128);
-  const bool big = p.geglu || big_tiles >= 192;
+  const bool big = p.geglu || (big_tiles >= 192 && p.N > 64);
+  ETAINV_CHECK(!p.out_nchw || p.N == 4, "out_nchw needs N == 4");
   const int64_t huge_tiles = (int64_t)cdiv(p.M, 256) * cdiv(p.N, 160);
   if (!p.geglu && p.N % 160 == 0 && huge_tiles >= 256 && !getenv("ETAINV_NO_RING")) {
     // experimental (opt-in): 256 x 160 x 64 tile, 8 waves, one resident block per CU (26 % fewer L2 -> LDS bytes per

@@ -13,6 +13,8 @@ struct IGemmParams {
   const float* rowvec = nullptr;    // [batch][rowvec_stride] fp32, added per batch row (time-embedding projection)
   int rowvec_stride = 0;
   int out_f32 = 0;                  // store fp32 instead of T (time-embedding projections)
+  int out_nchw = 0;                 // conv_out: N == 4, store fp32/io-dtype NCHW [batch][4][Ho*Wo]; out_io_dtype selects the type
+  int out_io_dtype = 0;
   const void* residual = nullptr;   // [M][N]
   void* out = nullptr;              // [M][N]  (or [M][N/2] with geglu)
   const void* zeros = nullptr;      // filled in by launch_igemm
@@ -62,6 +64,8 @@ int launch_cross_attention_p(const void* q, const void* kv, void* out, int b, in
 // conv_in: NCHW io-dtype latent [n_lat][4][L][L] (row r reads r % n_lat) -> NHWC T [rows][L*L][cout], 3x3 pad 1
 int launch_conv_in(const void* latent, int io_dtype, int n_lat, int rows, int L, const void* w, const float* bias, int cout,
                    void* out, int dtype, hipStream_t s);
+// im2col of the 3x3 / 4-channel input conv: NCHW io-dtype latent [n_lat][4][L][L] -> T [rows][L*L][64] (k = tap*4 + ci, 36..63 zero)
+int launch_im2col_in(const void* latent, int io_dtype, int n_lat, int rows, int L, void* out, int dtype, hipStream_t s);
 // conv_out: NHWC T [rows][L*L][cin] (already GroupNorm+SiLU'd) -> NCHW io-dtype [rows][4][L][L]
 int launch_conv_out(const void* x, int rows, int L, int cin, const void* w, const float* bias, void* out, int io_dtype, int dtype,
                     hipStream_t s);

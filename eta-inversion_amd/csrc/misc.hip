@@ -81,6 +81,31 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const T* __restrict__ x, 
   if (lane < 4) out[((int64_t)row * 4 + lane) * LL + pix] = from_f32<TIO>(acc[lane] + bias[lane]);
 }
 
+// one thread per (row, pixel): gathers the 3x3x4 patch (zero padded) into 64 contiguous K elements
+template <typename T, typename TIO>
+__global__ void im2col_in_kernel(const TIO* __restrict__ x, int n_lat, int L, int rows, T* __restrict__ out) {
+  const int LL = L * L;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * LL) return;
+  const int row = (int)(i / LL), pix = (int)(i - (int64_t)row * LL);
+  const int oy = pix / L, ox = pix - oy * L;
+  const TIO* xb = x + (int64_t)(row % n_lat) * 4 * LL;
+  T v[64];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) v[k] = (T)0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+    if (iy >= 0 && iy < L && ix >= 0 && ix < L) {
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) v[t * 4 + ci] = from_f32<T>(to_f32(xb[(int64_t)ci * LL + iy * L + ix]));
+    }
+  }
+  u32x4* o = reinterpret_cast<u32x4*>(out + i * 64);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) o[q] = reinterpret_cast<u32x4*>(v)[q];
+}
+
 template <typename T>
 __global__ void time_embedding_kernel(const float* __restrict__ t, int rows, int dim, T* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,9 +130,16 @@ __global__ void silu_kernel(const T* x, T* out, int64_t n) {
 //           (p%64 < 32 ? (p/64)*32 + p%64 : rows/2 + (p/64)*32 + p%64 - 32)
 //   mode 3: conv_in  [O][4][3][3] -> fp32-style [tap*4+ci][O]            (rows = O, cols = 36)
 //   mode 4: conv_out [4][I][3][3] -> [tap][I][4]                         (rows = 4, cols = I*9)
+//   mode 5: conv_in as a K = 64 GEMM: [O][4][3][3] -> [O][64], k = tap*4 + ci, k >= 36 zero   (rows = O, cols = 36)
 template <typename TD>
 __global__ void pack_weight_kernel(const float* __restrict__ src, TD* __restrict__ dst, int64_t rows, int64_t cols, int mode, int taps) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (mode == 5) {
+    if (i >= rows * 64) return;
+    const int64_t o = i / 64, k = i - o * 64, tap = k / 4, ci = k - tap * 4;
+    dst[i] = from_f32<TD>(k < 36 ? src[o * 36 + ci * 9 + tap] : 0.f);
+    return;
+  }
   if (i >= rows * cols) return;
   int64_t s = i;
   if (mode == 1) {
@@ -150,6 +182,15 @@ int launch_conv_in(const void* latent, int io_dtype, int n_lat, int rows, int L,
   return 0;
 }
 
+int launch_im2col_in(const void* latent, int io_dtype, int n_lat, int rows, int L, void* out, int dtype, hipStream_t s) {
+  ETAINV_CHECK(latent && out && n_lat > 0 && rows > 0, "bad arguments");
+  const int64_t n = (int64_t)rows * L * L;
+  ETAINV_DISPATCH_HALF(dtype, T, ETAINV_DISPATCH_DTYPE(io_dtype, TIO,
+      hipLaunchKernelGGL((im2col_in_kernel<T, TIO>), dim3(cdiv(n, 256)), dim3(256), 0, s, (const TIO*)latent, n_lat, L, rows, (T*)out)));
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_conv_out(const void* x, int rows, int L, int cin, const void* w, const float* bias, void* out, int io_dtype, int dtype,
                     hipStream_t s) {
   ETAINV_CHECK(x && w && bias && out && cin % 8 == 0, "bad arguments");
@@ -175,7 +216,7 @@ int launch_silu(const void* x, void* out, int64_t n, int dtype, hipStream_t s) {
 
 int launch_pack_weight(const float* src, void* dst, int64_t rows, int64_t cols, int mode, int taps, int dtype, hipStream_t s) {
   ETAINV_CHECK(src && dst && rows > 0 && cols > 0, "bad arguments");
-  const int64_t n = rows * cols;
+  const int64_t n = mode == 5 ? rows * 64 : rows * cols;
   ETAINV_DISPATCH_DTYPE(dtype, TD, hipLaunchKernelGGL(pack_weight_kernel<TD>, dim3(cdiv(n, 256)), dim3(256), 0, s, src, (TD*)dst, rows, cols, mode, taps));
   ETAINV_LAUNCH_CHECK();
   return 0;
