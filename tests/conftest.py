@@ -12,6 +12,10 @@ GOLDEN = ROOT / "tests" / "golden"
 
 
 def pytest_configure(config):
+    import os
+    import torch
+    # the CPU oracle's small PyTorch ops crawl when oversubscribed (256 hardware threads on the GPU box)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long CPU oracle replay")
 
