@@ -17,6 +17,7 @@
 // Epilogue (fused): + bias[n] + rowvec[batch][n] (time-embedding projection) + residual[m][n], or GEGLU
 // a * gelu_erf(g) with (a, g) columns interleaved per 32-column group at weight-pack time.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   // fast path (no upsample): element offset of tap (0,0) in source 1 / source 2 (lane chunk included) and 9-bit tap validity
   int a_e1[A_LOADS], a_e2[A_LOADS], a_mask[A_LOADS];
   const T* w_row[B_LOADS];
-  auto setup_issue = [&](int i) {   // geometry of the tile whose K tiles are being prefetched
+  auto setup_issue = [&](int i) __attribute__((always_inline)) {   // geometry of the tile whose K tiles are being prefetched
     int m0, n0;
     tile_origin(i, m0, n0);
 #pragma unroll
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
 
   // position of the K tile being issued, advanced incrementally (no integer division in the loop)
   int it_tap = 0, it_c0 = 0, it_ky = 0, it_kx = 0;
-  auto issue_tile = [&](int kt, int buf) {
+  auto issue_tile = [&](int kt, int buf) __attribute__((always_inline)) {
     const int tap = it_tap, c0 = it_c0, ky = it_ky, kx = it_kx;
     const bool second = c0 >= p.c1;
     const T* src = reinterpret_cast<const T*>(second ? p.a2 : p.a1);
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   T* out = reinterpret_cast<T*>(p.out);
   const T* res = reinterpret_cast<const T*>(p.residual);
   // ---- epilogue: lane holds out[m][n .. n+3], m = pixel (MFMA column), n = channel (MFMA row)
-  auto epilogue = [&](int m0, int n0) {
+  auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int m = m0 + wm * WM + i * 16 + fr;
@@ -231,7 +232,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   const int total_steps = my_tiles * nk;
   int it_tile = 0, it_kt = 0;          // (tile, k-tile) being issued, ahead of the compute
   int ct_tile = 0, ct_kt = 0;          // (tile, k-tile) being computed
-  auto advance_issue = [&]() {
+  auto advance_issue = [&]() __attribute__((always_inline)) {
     it_c0 += BK;
     if (it_c0 == cin) {
       it_c0 = 0;
@@ -303,61 +304,77 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     //     20 MFMAs on F1;  epilogue if this was the tile's last K tile
     constexpr int B_FULL = BN / RP;                                     // B passes every wave takes part in
     const bool extra_b = (BN % RP != 0) && (wrow0 + RP * B_FULL < BN);   // this wave also issues the partial pass
-    auto read_frags = [&](int st, int kk, frag (&fa)[MT], frag (&fb)[NT]) {
+    // fragments are kept as opaque 128-bit values (u32x4): arrays of bf16x8 passed by reference get unpacked / repacked
+    // element-wise by hipcc (20+ v_lshrrev / v_perm per cluster)
+    auto read_frags = [&](int st, int kk, u32x4 (&fa)[MT], u32x4 (&fb)[NT]) __attribute__((always_inline)) {
       const T* tA = sA + st * BM * BK;
       const T* tB = sB + st * BN * BK;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         int row = wm * WM + i * 16 + fr;
-        fa[i] = *reinterpret_cast<const frag*>(tA + row * BK + (((kk * 4 + fq) ^ (row & 7)) << 3));
+        fa[i] = *reinterpret_cast<const u32x4*>(tA + row * BK + (((kk * 4 + fq) ^ (row & 7)) << 3));
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         int row = wn * WN + j * 16 + fr;
-        fb[j] = *reinterpret_cast<const frag*>(tB + row * BK + (((kk * 4 + fq) ^ (row & 7)) << 3));
+        fb[j] = *reinterpret_cast<const u32x4*>(tB + row * BK + (((kk * 4 + fq) ^ (row & 7)) << 3));
       }
     };
-    auto mfma_all = [&](frag (&fa)[MT], frag (&fb)[NT]) {
+    auto mfma_all = [&](u32x4 (&fa)[MT], u32x4 (&fb)[NT]) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = Mfma<T>::run(fb[j], fa[i], acc[i][j]);
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = Mfma<T>::run(__builtin_bit_cast(frag, fb[j]), __builtin_bit_cast(frag, fa[i]), acc[i][j]);
     };
+    // waits are emitted with the s_waitcnt BUILTIN (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]):
+    // hipcc's own wait insertion does not see inside inline asm and would add a conservative lgkmcnt(0) in front of
+    // the first MFMA cluster, serialising the fragment reads with the matrix work (measured: exactly additive).
+#define ETAINV_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+#define ETAINV_LGKMCNT0() __builtin_amdgcn_s_waitcnt(0xC07F)
     auto wait_one_slot_in_flight = [&]() {
-      if (extra_b) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LOADS + B_FULL + 1) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LOADS + B_FULL) : "memory");
+      if (extra_b) ETAINV_VMCNT(A_LOADS + B_FULL + 1);
+      else ETAINV_VMCNT(A_LOADS + B_FULL);
     };
     auto wait_two_slots_in_flight = [&]() {
-      if (extra_b) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (A_LOADS + B_FULL + 1)) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (A_LOADS + B_FULL)) : "memory");
+      if (extra_b) ETAINV_VMCNT(2 * (A_LOADS + B_FULL + 1));
+      else ETAINV_VMCNT(2 * (A_LOADS + B_FULL));
     };
     issue_tile(0, 0);
     if (total_steps > 1) { advance_issue(); issue_tile(it_kt, 1); }
     if (total_steps > 2) { advance_issue(); issue_tile(it_kt, 2); }
     if (total_steps > 2) wait_two_slots_in_flight();
     else if (total_steps > 1) wait_one_slot_in_flight();
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else ETAINV_VMCNT(0);
     __builtin_amdgcn_s_barrier();
-    frag fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+    u32x4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
     read_frags(0, 0, fa0, fb0);
+    ETAINV_LGKMCNT0();
     int slot = 0;
-    for (int sidx = 0; sidx < total_steps; ++sidx) {
+    // one pipeline step; the steady-state instance (HAS_ISSUE) is branch-free between the fragment reads and the MFMA
+    // clusters -- a control-flow join there makes hipcc insert a conservative lgkmcnt(0) in front of the cluster
+    auto step = [&](int sidx, auto has_next_tag, auto has_issue_tag) __attribute__((always_inline)) {
+      constexpr bool HAS_NEXT = decltype(has_next_tag)::value, HAS_ISSUE = decltype(has_issue_tag)::value;
       const int nslot = slot == 2 ? 0 : slot + 1;
       read_frags(slot, 1, fa1, fb1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the 20 MFMAs on F0 ABOVE the waits below
       mfma_all(fa0, fb0);
-      if (sidx + 1 < total_steps) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (sidx + 2 < total_steps) wait_one_slot_in_flight();
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (HAS_NEXT) {
+        ETAINV_LGKMCNT0();                   // F1 landed (issued a whole MFMA cluster ago); slot may be recycled after the barrier
+        if (HAS_ISSUE || sidx + 2 < total_steps) wait_one_slot_in_flight();
+        else ETAINV_VMCNT(0);
         __builtin_amdgcn_s_barrier();
-        if (sidx + 3 < total_steps) {
+        if constexpr (HAS_ISSUE) {
           advance_issue();
-          issue_tile(it_kt, slot);
+          if (!(p.debug & 1)) issue_tile(it_kt, slot);
         }
         read_frags(nslot, 0, fa0, fb0);
       }
+      // no scheduling barrier here: the DMA issue (address VALU / SALU, M0 writes) and the F0 reads above are independent of
+      // the cluster below, so the scheduler may interleave them into the MFMA issue gaps
       mfma_all(fa1, fb1);
+      __builtin_amdgcn_sched_barrier(0);
       if (++ct_kt == nk) {
         int m0, n0;
         tile_origin(ct_tile, m0, n0);
@@ -365,8 +382,15 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         ct_kt = 0;
         ++ct_tile;
       }
+      if constexpr (HAS_NEXT) ETAINV_LGKMCNT0();   // F0 of the next step landed under the cluster above
       slot = nslot;
-    }
+    };
+    int sidx = 0;
+    for (; sidx + 3 < total_steps; ++sidx) step(sidx, std::true_type{}, std::true_type{});
+    for (; sidx + 1 < total_steps; ++sidx) step(sidx, std::true_type{}, std::false_type{});
+    step(sidx, std::false_type{}, std::false_type{});
+#undef ETAINV_VMCNT
+#undef ETAINV_LGKMCNT0
   }
 }
 
@@ -396,6 +420,7 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
   }
   IGemmParams p = p_in;
   p.zeros = zero_page;
+  if (const char* dbg = getenv("ETAINV_IGEMM_DEBUG")) p.debug = atoi(dbg);
   ETAINV_CHECK(p.a1 && p.w && p.out, "null pointer");
   ETAINV_CHECK(p.M > 0 && p.N > 0 && (p.N % 4) == 0, "N must be a positive multiple of 4");
   ETAINV_CHECK(p.c1 % BK == 0 && p.c2 % BK == 0 && (p.c1 + p.c2) > 0, "channel counts must be multiples of 64");

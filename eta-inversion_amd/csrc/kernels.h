@@ -18,6 +18,7 @@ struct IGemmParams {
   const void* residual = nullptr;   // [M][N]
   void* out = nullptr;              // [M][N]  (or [M][N/2] with geglu)
   const void* zeros = nullptr;      // filled in by launch_igemm
+  int debug = 0;                    // timing experiments only (ETAINV_IGEMM_DEBUG): 1 = no DMA in the loop, 2 = no MFMA
   int M = 0, N = 0;
   int c1 = 0, c2 = 0;
   int H = 1, W = 1;           // source spatial dims (before the fused upsample)
