@@ -111,11 +111,22 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:          # under torch.distributed.run (also with one rank: exercises the RCCL path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        # RCCL prints a version banner on STDOUT when the communicator is created; keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 
