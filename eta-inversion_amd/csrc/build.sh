@@ -6,7 +6,7 @@ OUT="$HERE/../etainv/lib"
 mkdir -p "$OUT" "$HERE/obj"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 pids=()
-for f in step_kernels igemm norm attention misc maps; do
+for f in step_kernels igemm norm attention misc maps aux_nets; do
   if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/kernels.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/etainv.h" -nt "$HERE/obj/$f.o" ]; then
     EXTRA=""
     # attention: keep MFMA results in VGPRs (the softmax consumes them on the VALU: no v_accvgpr moves) and drop the
@@ -19,5 +19,5 @@ done
 hipcc $FLAGS -x hip -c "$HERE/engine.cpp" -o "$HERE/obj/engine.o" &
 pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libetainv_hip.so" "$HERE"/obj/{step_kernels,igemm,norm,attention,misc,maps,engine}.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libetainv_hip.so" "$HERE"/obj/{step_kernels,igemm,norm,attention,misc,maps,aux_nets,engine}.o
 echo "built $OUT/libetainv_hip.so"

@@ -669,7 +669,7 @@ extern "C" int etainv_unet_forward(etainv_engine_t* e, const void* latent, int n
     p.w = e->conv_out_w;
     p.bias = e->conv_out_b;
     p.out = out;
-    p.out_nchw = 1;
+    p.out_nchw = 4;
     p.out_io_dtype = io_dtype;
     p.c1 = 320;
     p.H = p.W = p.Ho = p.Wo = L;
@@ -746,6 +746,32 @@ extern "C" int etainv_op_gemm(const void* a, const void* w, const void* bias, co
   p.Wo = m;
   p.geglu = geglu;
   p.rows_per_batch = m;
+  return launch_igemm(p, dtype, (hipStream_t)stream);
+}
+
+extern "C" int etainv_op_conv3x3_ex(const void* x_nhwc, const void* w_okkc, const void* bias, const void* residual, void* out, int b, int h,
+                                    int wd, int cin, int cout, int stride, int upsample, int pad0, int out_nchw, int out_io_dtype,
+                                    int dtype, void* stream) {
+  IGemmParams p;
+  p.a1 = x_nhwc;
+  p.w = w_okkc;
+  p.bias = (const float*)bias;
+  p.residual = residual;
+  p.out = out;
+  p.c1 = cin;
+  p.H = h;
+  p.W = wd;
+  p.Ho = upsample ? h * 2 : (stride == 2 ? h / 2 : h);
+  p.Wo = upsample ? wd * 2 : (stride == 2 ? wd / 2 : wd);
+  p.stride = stride;
+  p.ups = upsample;
+  p.taps = 9;
+  p.pad0 = pad0;
+  p.out_nchw = out_nchw;
+  p.out_io_dtype = out_io_dtype;
+  p.M = b * p.Ho * p.Wo;
+  p.N = cout;
+  p.rows_per_batch = p.Ho * p.Wo;
   return launch_igemm(p, dtype, (hipStream_t)stream);
 }
 

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   const int cin = p.c1 + p.c2;
   const int kc = cin / BK;            // K tiles per tap
   const int nk = p.taps * kc;
-  const int pad = (p.taps == 9) ? 1 : 0;
+  const int pad = (p.taps == 9 && !p.pad0) ? 1 : 0;
   const int HWo = p.Ho * p.Wo;
   const int Hin = p.ups ? p.H * 2 : p.H, Win = p.ups ? p.W * 2 : p.W;
 
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         const int iy = a_y[q] + t / 3, ix = a_x[q] + t % 3;
         mask |= ((iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W)) << t;
       }
-      a_mask[q] = p.taps == 9 ? mask : 1;
+      a_mask[q] = p.taps == 9 ? mask : 1;   // (with pad0 the a_y / a_x origin is the output pixel itself)
     }
 #pragma unroll
     for (int q = 0; q < B_LOADS; ++q) {
@@ -188,9 +188,10 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
             v[0] += to_f32(r[0]); v[1] += to_f32(r[1]); v[2] += to_f32(r[2]); v[3] += to_f32(r[3]);
           }
           if (p.out_nchw) {   // conv_out: this lane holds the 4 output channels of pixel m
-            const int64_t base = ((int64_t)batch * 4) * p.rows_per_batch + (m - batch * p.rows_per_batch);
+            const int64_t base = ((int64_t)batch * p.out_nchw) * p.rows_per_batch + (m - batch * p.rows_per_batch);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+              if (c >= p.out_nchw) break;
               const int64_t o = base + (int64_t)c * p.rows_per_batch;
               if (p.out_io_dtype == ETAINV_F32) reinterpret_cast<float*>(p.out)[o] = v[c];
               else if (p.out_io_dtype == ETAINV_F16) reinterpret_cast<f16*>(p.out)[o] = (f16)v[c];

@@ -13,7 +13,8 @@ struct IGemmParams {
   const float* rowvec = nullptr;    // [batch][rowvec_stride] fp32, added per batch row (time-embedding projection)
   int rowvec_stride = 0;
   int out_f32 = 0;                  // store fp32 instead of T (time-embedding projections)
-  int out_nchw = 0;                 // conv_out: N == 4, store fp32/io-dtype NCHW [batch][4][Ho*Wo]; out_io_dtype selects the type
+  int out_nchw = 0;                 // conv_out: N == 4, store the first out_nchw channels as io-dtype NCHW [batch][out_nchw][Ho*Wo]
+  int pad0 = 0;                     // 3x3 taps start at the output origin (VAE downsampler: F.pad(x,(0,1,0,1)) + stride-2 conv, no top/left pad)
   int out_io_dtype = 0;
   const void* residual = nullptr;   // [M][N]
   void* out = nullptr;              // [M][N]  (or [M][N/2] with geglu)

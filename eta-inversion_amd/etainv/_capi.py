@@ -54,6 +54,12 @@ SIGNATURES = {
     "etainv_prof_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)],
     "etainv_op_gemm": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "etainv_op_conv3x3": [_p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "etainv_op_conv3x3_ex": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "etainv_op_im2col3x3": [_p, _i, _i, _i, _i, _i, _p, _p, _i, _p],
+    "etainv_op_row_softmax": [_p, _i, _i, _f, _i, _p],
+    "etainv_op_quick_gelu": [_p, _p, _i64, _i, _p],
+    "etainv_op_embed": [_p, _p, _p, _i, _i, _i, _p, _i, _p],
+    "etainv_op_causal_attention": [_p, _p, _i, _i, _i, _i, _i, _p],
     "etainv_op_groupnorm": [_p, _p, _i, _i, _p, _p, _p, _i, _i, _i, _f, _i, _p, _i, _p],
     "etainv_op_layernorm": [_p, _p, _p, _p, _i, _i, _f, _i, _p],
     "etainv_op_self_attention": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -32,3 +32,26 @@ def load_snapshot(path) -> dict:
         if (root / cand).exists():
             return {k: v.float() for k, v in load_file(str(root / cand)).items()}
     raise FileNotFoundError(f"no UNet safetensors under {root}")
+
+
+_OLD_VAE_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+
+def load_component(path, sub) -> dict:
+    """state dict of `<path>/<sub>/*.safetensors` for sub in {"vae", "text_encoder"}; pre-0.18 diffusers VAE attention
+    names (query/key/value/proj_attn) are mapped to to_q/to_k/to_v/to_out.0."""
+    from safetensors.torch import load_file
+    root = Path(path) / sub
+    for cand in ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors", "model.safetensors", "model.fp16.safetensors"):
+        if (root / cand).exists():
+            sd = {}
+            for k, v in load_file(str(root / cand)).items():
+                parts = k.split(".")
+                if sub == "vae" and "attentions" in parts:
+                    k = ".".join(parts[:-2] + [_OLD_VAE_ATTN.get(parts[-2], parts[-2]), parts[-1]]) if parts[-2] in _OLD_VAE_ATTN else k
+                v = v.float()
+                if sub == "vae" and v.dim() == 4 and ".attentions." in k:     # old checkpoints keep 1x1 convs for q/k/v/out
+                    v = v.reshape(v.shape[0], v.shape[1])
+                sd[k] = v
+            return sd
+    raise FileNotFoundError(f"no safetensors under {root}")

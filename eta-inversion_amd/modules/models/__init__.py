@@ -1,16 +1,18 @@
 """Pipeline object + image pre/post-processing (reference modules/models/__init__.py:12-138).
 
 `load_diffusion_model` returns `(pipeline, (preproc, postproc))` like the reference.  The pipeline's `.unet` is the native
-MI355X engine.  The VAE and the CLIP text encoder are third-party networks outside the DDIM loop ("next"):
-when `ETAINV_SD_PATH` is not set, deterministic stand-ins are used so the plumbing (CLI, editors) runs end to end."""
+MI355X engine; `.vae` and `.text_encoder` (third-party networks outside the DDIM loop) run on the same
+kernels (etainv/nets.py).  `ETAINV_SD_PATH=<diffusers snapshot>` supplies real weights for all three; without it every
+network gets seeded synthetic weights (there is no network access to fetch checkpoints)."""
 import os
-import zlib
 from pathlib import Path
 
 import numpy as np
 import torch
 
 from etainv.engine import Engine
+from etainv.nets import NativeCLIPText, NativeVAE
+from etainv.weights import load_component
 from ..schedulers import DDIMScheduler
 from ..utils.tokenizer import load_tokenizer
 
@@ -32,41 +34,6 @@ class NativeUNet:
     forward = __call__
 
 
-class StandInTextEncoder:
-    """Deterministic embedding stand-in for CLIPTextModel: one seeded N(0,1) vector per token id plus a positional term."""
-    def __init__(self, device, dim=768):
-        self.device, self.dim, self._cache = device, dim, {}
-
-    def _vec(self, key, scale):
-        if key not in self._cache:
-            g = torch.Generator().manual_seed(zlib.crc32(repr(key).encode()))
-            self._cache[key] = scale * torch.randn(self.dim, generator=g)
-        return self._cache[key]
-
-    def __call__(self, input_ids):
-        ids = input_ids.cpu()
-        out = torch.stack([torch.stack([self._vec(("tok", int(t)), 1.0) + self._vec(("pos", p), 0.3) for p, t in enumerate(row)])
-                           for row in ids])
-        return (out.to(self.device),)
-
-
-class StandInVAE:
-    """Stand-in for AutoencoderKL (outside the hot loop): 8x8 average pooling to 4 channels (RGB + luma) and nearest
-    upsampling back; keeps the `(1,3,512,512) <-> (1,4,64,64)` contract of DiffusionInversion.encode/decode."""
-    dtype = torch.float32
-
-    def encode(self, image):
-        x = torch.nn.functional.avg_pool2d(image.float(), 8)
-        z = torch.cat([x, x.mean(1, keepdim=True)], 1) / 0.18215 * 0.5
-
-        class _D:
-            mean = z
-        return {"latent_dist": _D()}
-
-    def decode(self, z):
-        return {"sample": torch.nn.functional.interpolate(z[:, :3].float() * 0.18215 * 2.0, scale_factor=8.0, mode="nearest")}
-
-
 class EtaPipeline:
     def __init__(self, device="cuda", dtype=torch.float16, latent_size=64, max_img=1, seed=0):
         self.device = torch.device(device if device != "cuda" else "cuda:0")
@@ -76,13 +43,9 @@ class EtaPipeline:
         self.scheduler = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
                                        set_alpha_to_one=False)
         self.tokenizer = load_tokenizer()
-        self.text_encoder = StandInTextEncoder(self.device)
-        self.vae = StandInVAE()
         sd = os.environ.get("ETAINV_SD_PATH")
-        if sd and os.path.isdir(os.path.join(sd, "text_encoder")):
-            from transformers import CLIPTextModel
-            enc = CLIPTextModel.from_pretrained(os.path.join(sd, "text_encoder")).to(self.device).eval()
-            self.text_encoder = lambda ids: enc(ids)
+        self.text_encoder = NativeCLIPText(load_component(sd, "text_encoder") if sd else None, dtype, seed)
+        self.vae = NativeVAE(load_component(sd, "vae") if sd else None, dtype, seed)
 
 
 class StablePreprocess:

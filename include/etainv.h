@@ -169,6 +169,20 @@ int etainv_op_gemm(const void* a, const void* w, const void* bias, const void* r
 int etainv_op_conv3x3(const void* x_nhwc, const void* x2_nhwc, int c1, int c2, const void* w_okkc, const void* bias,
                       const float* rowvec, const void* residual, void* out, int b, int h, int wd, int cout,
                       int stride, int upsample, int taps, int dtype, void* stream);
+/* extended conv for the VAE: pad0 = taps start at the output origin (asymmetric (0,1,0,1) padding of its stride-2
+ * downsamplers); out_nchw = 1..4: cout must be 4 and the first out_nchw channels are written as io-dtype NCHW */
+int etainv_op_conv3x3_ex(const void* x_nhwc, const void* w_okkc, const void* bias, const void* residual, void* out, int b, int h,
+                         int wd, int cin, int cout, int stride, int upsample, int pad0, int out_nchw, int out_io_dtype, int dtype,
+                         void* stream);
+/* VAE / CLIP text-encoder helpers (third-party networks outside the DDIM loop; reference call sites
+ * modules/inversion/diffusion_inversion.py:183-247) */
+int etainv_op_im2col3x3(const void* x_nchw, int io_dtype, int cin, int h, int w, int rows, const float* premix, void* out,
+                        int dtype, void* stream);
+int etainv_op_row_softmax(void* x, int rows, int n, float scale, int dtype, void* stream);
+int etainv_op_quick_gelu(const void* x, void* out, int64_t n, int dtype, void* stream);
+int etainv_op_embed(const int64_t* ids, const void* tok, const void* pos, int b, int n_pos, int d, void* out, int dtype,
+                    void* stream);
+int etainv_op_causal_attention(const void* qkv, void* out, int b, int n, int heads, int d, int dtype, void* stream);
 int etainv_op_groupnorm(const void* x_nhwc, const void* x2_nhwc, int c1, int c2, const float* gamma,
                         const float* beta, void* out, int b, int hw, int groups, float eps, int silu,
                         float* scratch, int dtype, void* stream);

@@ -183,3 +183,25 @@ def test_e2e_loop_vs_reference(golden, toy_unet, name):
     np.testing.assert_allclose(torch.stack([t["latent"] for t in trace]).numpy(), g[f"{name}/bwd_latents"], rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(z[:1].numpy(), g[f"{name}/latent_inv"], rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(z[1:].numpy(), g[f"{name}/latent"], rtol=1e-3, atol=2e-4)
+
+
+def test_clip_oracle_matches_transformers():
+    """oracle/clip.py is pinned by the third-party implementation itself where it is importable: transformers'
+    CLIPTextModel (ViT-L/14 text config) loaded with the oracle's seeded weights gives the same hidden states."""
+    transformers = pytest.importorskip("transformers")
+    from oracle.clip import build_clip
+    cfg = transformers.CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                                      num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu")
+    hf = transformers.CLIPTextModel(cfg).eval()
+    ora = build_clip(0)
+    sd = {k: v for k, v in ora.state_dict().items()}
+    if not any(k.startswith("text_model.") for k in hf.state_dict()):       # newer transformers dropped the prefix
+        sd = {k[len("text_model."):]: v for k, v in sd.items()}
+    missing, unexpected = hf.load_state_dict(sd, strict=False)
+    assert not unexpected and all("position_ids" in m for m in missing), (missing, unexpected)
+    ids = torch.randint(0, 49408, (2, 77), generator=torch.Generator().manual_seed(0))
+    ids[:, 0], ids[:, 30:] = 49406, 49407
+    with torch.no_grad():
+        want = hf(ids)[0]
+        got = ora(ids)[0]
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
