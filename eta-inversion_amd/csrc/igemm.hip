@@ -50,6 +50,9 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* sA = reinterpret_cast<T*>(smem);                       // [STAGES][BM*BK]
   T* sB = reinterpret_cast<T*>(smem) + STAGES * BM * BK;    // [STAGES][BN*BK]
+  // bias of the tiles in flight: filled by LDS-DMA together with a tile's first K step, read by its epilogue (a global bias
+  // load in the epilogue waits behind every queued DMA: ~1.5 us per tile with the matrix pipe idle)
+  float* sBias = reinterpret_cast<float*>(smem + (size_t)STAGES * (BM + BN) * BK * sizeof(T));   // [4][BN]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -86,28 +89,45 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   // fast path (no upsample): element offset of tap (0,0) in source 1 / source 2 (lane chunk included) and 9-bit tap validity
   int a_e1[A_LOADS], a_e2[A_LOADS], a_mask[A_LOADS];
   const T* w_row[B_LOADS];
+  int it_n0 = 0, it_bias_buf = 0;
   auto setup_issue = [&](int i) __attribute__((always_inline)) {   // geometry of the tile whose K tiles are being prefetched
     int m0, n0;
     tile_origin(i, m0, n0);
+    it_n0 = n0;
+    it_bias_buf = i & 3;
+    if (p.taps == 1) {
+      // 1x1 / Linear: the source row IS the output row -- no (image, y, x) decomposition, no halo mask (a K = 320 tile is
+      // only five K steps long, so the ~500 VALU instructions of the general setup were ~20 % of its main loop)
 #pragma unroll
-    for (int q = 0; q < A_LOADS; ++q) {
-      int m = m0 + (tid >> 3) + RP * q;
-      m = m < p.M ? m : p.M - 1;
-      int b = m / HWo, r = m - b * HWo;
-      int oy = r / p.Wo, ox = r - oy * p.Wo;
-      a_b[q] = b;
-      a_y[q] = oy * p.stride - pad;
-      a_x[q] = ox * p.stride - pad;
-      const int pix0 = (b * p.H + a_y[q]) * p.W + a_x[q];
-      a_e1[q] = pix0 * p.c1 + lchunk * 8;
-      a_e2[q] = pix0 * p.c2 + lchunk * 8;
-      int mask = 0;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int iy = a_y[q] + t / 3, ix = a_x[q] + t % 3;
-        mask |= ((iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W)) << t;
+      for (int q = 0; q < A_LOADS; ++q) {
+        int m = m0 + (tid >> 3) + RP * q;
+        m = m < p.M ? m : p.M - 1;
+        a_b[q] = a_y[q] = a_x[q] = 0;
+        a_e1[q] = m * p.c1 + lchunk * 8;
+        a_e2[q] = m * p.c2 + lchunk * 8;
+        a_mask[q] = 1;
       }
-      a_mask[q] = p.taps == 9 ? mask : 1;   // (with pad0 the a_y / a_x origin is the output pixel itself)
+    } else {
+#pragma unroll
+      for (int q = 0; q < A_LOADS; ++q) {
+        int m = m0 + (tid >> 3) + RP * q;
+        m = m < p.M ? m : p.M - 1;
+        int b = m / HWo, r = m - b * HWo;
+        int oy = r / p.Wo, ox = r - oy * p.Wo;
+        a_b[q] = b;
+        a_y[q] = oy * p.stride - pad;
+        a_x[q] = ox * p.stride - pad;
+        const int pix0 = (b * p.H + a_y[q]) * p.W + a_x[q];
+        a_e1[q] = pix0 * p.c1 + lchunk * 8;
+        a_e2[q] = pix0 * p.c2 + lchunk * 8;
+        int mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = a_y[q] + t / 3, ix = a_x[q] + t % 3;
+          mask |= ((iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W)) << t;
+        }
+        a_mask[q] = mask;   // (with pad0 the a_y / a_x origin is the output pixel itself)
+      }
     }
 #pragma unroll
     for (int q = 0; q < B_LOADS; ++q) {
@@ -157,6 +177,14 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       if (BN % RP == 0 || wrow0 + RP * i < BN)   // wave-uniform: a wave stages 8 whole rows
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_row[i] + (int64_t)kt * BK),
                                          (__attribute__((address_space(3))) void*)(dB + (wrow0 + RP * i) * BK), 16, 0, 0);
+    if (kt == 0 && p.bias && wrow0 * 8 < BN) {   // waves 0 .. BN/64: 64 floats each (wrow0 = 8 * wave)
+      const int c = wrow0 * 8 + lane;
+      if (c < BN) {
+        const int n = it_n0 + c < p.N ? it_n0 + c : p.N - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + n),
+                                         (__attribute__((address_space(3))) void*)(sBias + it_bias_buf * BN + wrow0 * 8), 4, 0, 0);
+      }
+    }
   };
 
   f32x4 acc[MT][NT];
@@ -168,7 +196,129 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   T* out = reinterpret_cast<T*>(p.out);
   const T* res = reinterpret_cast<const T*>(p.residual);
   // ---- epilogue: lane holds out[m][n .. n+3], m = pixel (MFMA column), n = channel (MFMA row)
-  auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
+  // Store NB 16-channel blocks of one pixel row group.  A lane holds 4 channels (8 B) of every block, so a plain store
+  // writes sixteen 32-byte segments per instruction, and the CU's store path retires ~one segment per 4 clocks whatever its
+  // size (measured, L2-resident: 8.6 B/clk/CU for 32-B segments, 16.8 for 64-B, 24.5 for 128-B) -- the epilogue of a
+  // K = 320 GEMM was ~40 % of its time.  v_permlane16_swap exchanges (block 2k, lanes 16-31 / 48-63) with (block 2k+1,
+  // lanes 0-15 / 32-47): every lane then owns 8 consecutive channels and an instruction writes 64-byte segments.
+  auto store_row_group = [&](T* prow, auto& po, auto nb_tag, bool row_ok, bool wide) __attribute__((always_inline)) {
+    constexpr int NB = decltype(nb_tag)::value;
+    if (p.debug & 64) row_ok = row_ok && po[0][0] == 0x12345678u && po[NB - 1][1] == 0x9abcdef0u;   // ablation: compute, (almost) never store
+    if (wide) {
+#pragma unroll
+      for (int k = 0; k + 1 < NB; k += 2) {
+        const auto lo = __builtin_amdgcn_permlane16_swap(po[k][0], po[k + 1][0], false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(po[k][1], po[k + 1][1], false, false);
+        const u32x4 v = {lo[0], hi[0], lo[1], hi[1]};
+        if (row_ok) *reinterpret_cast<u32x4*>(prow + (k + (fq & 1)) * 16 + (fq >> 1) * 8) = v;
+      }
+      if (NB & 1)
+        if (row_ok) *reinterpret_cast<u32x2*>(prow + (NB - 1) * 16 + fq * 4) = po[NB - 1];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NB; ++k)
+        if (row_ok) *reinterpret_cast<u32x2*>(prow + k * 16 + fq * 4) = po[k];
+    }
+  };
+  // returns the store class of the tile: 0 = unknown number of store instructions (partial tile / slow path),
+  // 1 = exactly MT*ceil(NT/2) per wave, 2 = exactly MT*ceil(NT/4) per wave (GEGLU) -- see the counted vmcnt waits of the ring
+  auto epilogue = [&](int m0, int n0, int tile) __attribute__((always_inline)) -> int {
+    if (p.debug & 2) {   // ablation: no epilogue traffic
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if (acc[i][j][0] == 12345.f) out[0] = from_f32<T>(1.f);
+          acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      return 0;
+    }
+    // Fast path (every hot layer): ALL epilogue inputs (bias + time-embedding row, residual) are requested before the first
+    // store.  Loads and stores share vmcnt on gfx9 and may complete out of order with respect to each other, so a load issued
+    // after a store makes hipcc wait vmcnt(0) = the L2 ack of that store: interleaved load/store groups serialise 20 store
+    // round trips per tile (measured: ~10 us per 256 x 160 tile, 45 % of a K = 320 GEMM).
+    if (!p.out_nchw && !p.out_f32 && (p.rows_per_batch % WM) == 0) {
+      int mw = m0 + wm * WM;
+      const int batch = (mw < p.M ? mw : p.M - 1) / p.rows_per_batch;   // one image per wave tile
+      if (p.debug & 8) mw &= 255;   // ablation: all tiles store into the same cache-resident rows
+      const bool wide = (n0 + BN <= p.N) && (p.N % 16) == 0 && !(p.debug & 32);
+      const float* tile_bias = sBias + (tile & 3) * BN;   // whole tile inside N: 16-byte stores after a lane swap
+      if (!p.geglu) {
+        f32x4 bv[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = n0 + wn * WN + j * 16 + fq * 4;
+          bv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (p.bias) bv[j] = *reinterpret_cast<const f32x4*>(tile_bias + wn * WN + j * 16 + fq * 4);
+          if (p.rowvec && n < p.N) bv[j] += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)batch * p.rowvec_stride + n);
+        }
+        // residual: one batch of loads per 16-row group (holding the whole tile's residual would need 40 more registers
+        // than the kernel has) -> 4 load/store alternations per tile instead of 20
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int m = mw + i * 16 + fr;
+          u32x2 rv[NT];
+          if (res) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              const int n = n0 + wn * WN + j * 16 + fq * 4;
+              rv[j] = (u32x2){0u, 0u};
+              if (m < p.M && n < p.N) rv[j] = *reinterpret_cast<const u32x2*>(res + (int64_t)m * p.N + n);
+            }
+          }
+          u32x2 po[NT];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            f32x4 v = acc[i][j] + bv[j];
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (res) {
+              T r[4];
+              *reinterpret_cast<u32x2*>(r) = rv[j];
+              v[0] += to_f32(r[0]); v[1] += to_f32(r[1]); v[2] += to_f32(r[2]); v[3] += to_f32(r[3]);
+            }
+            T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+            po[j] = *reinterpret_cast<u32x2*>(o);
+          }
+          store_row_group(out + (int64_t)m * p.N + n0 + wn * WN, po, std::integral_constant<int, NT>{}, m < p.M, wide);
+        }
+      } else {
+        const int No = p.N >> 1;
+        f32x4 ba[NT / 2 + 1], bg[NT / 2 + 1];
+#pragma unroll
+        for (int j = 0; j < NT / 2; ++j) {
+          const int n = n0 + wn * WN + j * 16 + fq * 4;
+          ba[j] = bg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (p.bias) {
+            ba[j] = *reinterpret_cast<const f32x4*>(tile_bias + wn * WN + j * 16 + fq * 4);
+            bg[j] = *reinterpret_cast<const f32x4*>(tile_bias + wn * WN + j * 16 + fq * 4 + WN / 2);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int m = mw + i * 16 + fr;
+          u32x2 po[NT / 2 + 1];
+#pragma unroll
+          for (int j = 0; j < NT / 2; ++j) {
+            const f32x4 a = acc[i][j] + ba[j], g = acc[i][j + NT / 2] + bg[j];
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[i][j + NT / 2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            T o[4];
+            if (p.debug & 128) {   // experiment: sigmoid-polynomial GELU on the packed-fp32 pipe (2.6e-5 abs error, ~3 % faster GEGLU)
+              const gelu_f32x2 g01 = gelu_pair((gelu_f32x2){g[0], g[1]}), g23 = gelu_pair((gelu_f32x2){g[2], g[3]});
+              o[0] = from_f32<T>(a[0] * g01[0]); o[1] = from_f32<T>(a[1] * g01[1]);
+              o[2] = from_f32<T>(a[2] * g23[0]); o[3] = from_f32<T>(a[3] * g23[1]);
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(a[q] * gelu_erf_f(g[q]));
+            }
+            po[j] = *reinterpret_cast<u32x2*>(o);
+          }
+          store_row_group(out + (int64_t)m * No + ((n0 + wn * WN) >> 1), po, std::integral_constant<int, NT / 2>{}, m < p.M, wide);
+        }
+      }
+      const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N) && !(p.debug & 16);   // every lane of every wave stored
+      return full ? (p.geglu ? 2 : 1) : 0;   // (full implies wide)
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int m = m0 + wm * WM + i * 16 + fr;
@@ -227,9 +377,16 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         }
       }
     }
+    return 0;
   };
 
   if (my_tiles <= 0) return;
+  // De-phase the two blocks that share a CU (blocks b and b + 256 of a 512-block persistent grid): they run the same tile
+  // period from the same start, so both reach their epilogues (VALU + stores, matrix pipe idle) together.  Delaying the second
+  // one by about half a tile lets each block's epilogue run under the other's matrix work.
+  if (p.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  }
   const int total_steps = my_tiles * nk;
   int it_tile = 0, it_kt = 0;          // (tile, k-tile) being issued, ahead of the compute
   int ct_tile = 0, ct_kt = 0;          // (tile, k-tile) being computed
@@ -267,13 +424,15 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = Mfma<T>::run(fb[j], fa[i], acc[i][j]);
     }
+    int cls = 0;
     if (++ct_kt == nk) {
       int m0, n0;
       tile_origin(ct_tile, m0, n0);
-      epilogue(m0, n0);
+      cls = epilogue(m0, n0, ct_tile);
       ct_kt = 0;
       ++ct_tile;
     }
+    return cls;
   };
 
   setup_issue(0);
@@ -288,8 +447,13 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         advance_issue();
         issue_tile(it_kt, cur ^ 1);
       }
-      compute_stage(cur);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int cls = compute_stage(cur);
+      // vmcnt counts loads, stores and LDS-DMA together in issue order: the epilogue's stores are younger than the DMA of
+      // step s+1, so they may stay in flight across this wait (their L2 acks are not on the critical path)
+      constexpr int S1 = MT * ((NT + 1) / 2), S2 = MT * ((NT / 2 + 1) / 2);   // 16-byte stores per wave and tile
+      if (cls == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (S1 & 15) | ((S1 >> 4) << 14));
+      else if (cls == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (S2 & 15) | ((S2 >> 4) << 14));
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();
     }
   } else {
@@ -322,6 +486,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       }
     };
     auto mfma_all = [&](u32x4 (&fa)[MT], u32x4 (&fb)[NT]) __attribute__((always_inline)) {
+      if (p.debug & 4) return;   // ablation: no matrix work
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -333,9 +498,20 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     // the first MFMA cluster, serialising the fragment reads with the matrix work (measured: exactly additive).
 #define ETAINV_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
 #define ETAINV_LGKMCNT0() __builtin_amdgcn_s_waitcnt(0xC07F)
-    auto wait_one_slot_in_flight = [&]() {
-      if (extra_b) ETAINV_VMCNT(A_LOADS + B_FULL + 1);
-      else ETAINV_VMCNT(A_LOADS + B_FULL);
+    // `young` = store class of an epilogue whose stores are YOUNGER than the DMA that has to have landed (vmcnt counts
+    // loads, stores and LDS-DMA together, in issue order): they stay in flight across the wait, so their L2 acks are off the
+    // critical path.  Valid for the two steps after the epilogue: [DMA s+2][DMA s+3][stores] and [DMA s+3][stores][DMA s+4].
+    auto wait_one_slot_in_flight = [&](int young = 0) {
+      constexpr int S1 = MT * ((NT + 1) / 2), S2 = MT * ((NT / 2 + 1) / 2), N1 = A_LOADS + B_FULL;
+      if (extra_b) {
+        if (young == 1) ETAINV_VMCNT(N1 + 1 + S1);
+        else if (young == 2) ETAINV_VMCNT(N1 + 1 + S2);
+        else ETAINV_VMCNT(N1 + 1);
+      } else {
+        if (young == 1) ETAINV_VMCNT(N1 + S1);
+        else if (young == 2) ETAINV_VMCNT(N1 + S2);
+        else ETAINV_VMCNT(N1);
+      }
     };
     auto wait_two_slots_in_flight = [&]() {
       if (extra_b) ETAINV_VMCNT(2 * (A_LOADS + B_FULL + 1));
@@ -352,6 +528,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     read_frags(0, 0, fa0, fb0);
     ETAINV_LGKMCNT0();
     int slot = 0;
+    int young_cls = 0, young_steps = 0;   // stores of the last epilogue that later waits may leave in flight
     // one pipeline step; the steady-state instance (HAS_ISSUE) is branch-free between the fragment reads and the MFMA
     // clusters -- a control-flow join there makes hipcc insert a conservative lgkmcnt(0) in front of the cluster
     auto step = [&](int sidx, auto has_next_tag, auto has_issue_tag) __attribute__((always_inline)) {
@@ -363,8 +540,13 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (HAS_NEXT) {
         ETAINV_LGKMCNT0();                   // F1 landed (issued a whole MFMA cluster ago); slot may be recycled after the barrier
-        if (HAS_ISSUE || sidx + 2 < total_steps) wait_one_slot_in_flight();
-        else ETAINV_VMCNT(0);
+        if constexpr (HAS_ISSUE) {
+          wait_one_slot_in_flight(young_steps > 0 ? young_cls : 0);
+          --young_steps;
+        } else {
+          if (sidx + 2 < total_steps) wait_one_slot_in_flight();
+          else ETAINV_VMCNT(0);
+        }
         __builtin_amdgcn_s_barrier();
         if constexpr (HAS_ISSUE) {
           advance_issue();
@@ -379,7 +561,8 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       if (++ct_kt == nk) {
         int m0, n0;
         tile_origin(ct_tile, m0, n0);
-        epilogue(m0, n0);
+        young_cls = epilogue(m0, n0, ct_tile);
+        young_steps = (nk >= 3 && HAS_ISSUE) ? 2 : 0;
         ct_kt = 0;
         ++ct_tile;
       }
@@ -398,7 +581,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
 template <typename T, int BM, int BN, int WAVES_M, int STAGES = 2>
 static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
   const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
-  const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(T);
+  const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(T) + 4 * BN * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WAVES_M, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -422,10 +605,12 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
   IGemmParams p = p_in;
   p.zeros = zero_page;
   if (const char* dbg = getenv("ETAINV_IGEMM_DEBUG")) p.debug = atoi(dbg);
+  if (const char* sg = getenv("ETAINV_STAGGER")) p.stagger = atoi(sg);
   ETAINV_CHECK(p.a1 && p.w && p.out, "null pointer");
   ETAINV_CHECK(p.M > 0 && p.N > 0 && (p.N % 4) == 0, "N must be a positive multiple of 4");
   ETAINV_CHECK(p.c1 % BK == 0 && p.c2 % BK == 0 && (p.c1 + p.c2) > 0, "channel counts must be multiples of 64");
   ETAINV_CHECK(p.taps == 1 || p.taps == 9, "taps must be 1 or 9");
+  ETAINV_CHECK(p.taps == 9 || (p.stride == 1 && !p.ups), "1x1 / Linear: stride 1, no upsample");
   ETAINV_CHECK(!p.geglu || (p.N % 128) == 0, "GEGLU needs N % 128 == 0");
   ETAINV_CHECK(p.rows_per_batch > 0, "rows_per_batch");
   ETAINV_CHECK(!p.rowvec || p.rowvec_stride >= p.N, "rowvec_stride");

@@ -19,7 +19,10 @@ struct IGemmParams {
   const void* residual = nullptr;   // [M][N]
   void* out = nullptr;              // [M][N]  (or [M][N/2] with geglu)
   const void* zeros = nullptr;      // filled in by launch_igemm
-  int debug = 0;                    // timing experiments only (ETAINV_IGEMM_DEBUG): 1 = no DMA in the loop, 2 = no MFMA
+  // timing experiments only (ETAINV_IGEMM_DEBUG bit mask): 1 no DMA in the loop, 2 no epilogue, 4 no MFMA, 8 stores hit cache-resident
+  // rows, 16 no young-store vmcnt allowance, 32 8-byte stores (no lane swap), 64 epilogue without its stores, 128 sigmoid-polynomial GELU
+  int debug = 0;
+  int stagger = 0;                  // experiment (ETAINV_STAGGER): start delay of the second co-resident block, 64-cycle ticks
   int M = 0, N = 0;
   int c1 = 0, c2 = 0;
   int H = 1, W = 1;           // source spatial dims (before the fused upsample)

@@ -51,9 +51,11 @@ def main():
             continue
         x = rnd(R, side, side, cin)
         w = rnd(cout, taps, cin) * (taps * cin) ** -0.5
-        bias = torch.randn(cout, device="cuda")
+        # as in the UNet: qkv projections have no bias; out-proj / ff2 / proj_out add bias and the residual stream
+        bias = None if "qkv" in name else torch.randn(cout, device="cuda")
+        resid = rnd(R, side, side, cout) if (taps == 1 and "qkv" not in name) else None
         out = torch.empty(R, side, side, cout, dtype=dt, device="cuda")
-        fn = lambda: _capi.check(lib.etainv_op_conv3x3(_capi.ptr(x), None, cin, 0, _capi.ptr(w), _capi.ptr(bias), None, None, _capi.ptr(out),
+        fn = lambda: _capi.check(lib.etainv_op_conv3x3(_capi.ptr(x), None, cin, 0, _capi.ptr(w), _capi.ptr(bias), None, _capi.ptr(resid), _capi.ptr(out),
                                                         R, side, side, cout, 1, 0, taps, code, st))
         ms = timeit(fn)
         fl = 2.0 * R * side * side * cout * taps * cin
