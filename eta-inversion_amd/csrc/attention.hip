@@ -14,6 +14,7 @@
 // online-softmax rescale is lane-local, and the S^T accumulator registers are already the B operand of the
 // PV product (keys of a 32-key step are taken in the order the accumulators hold them; V^T is read in that
 // same order), so P never touches LDS.  Output: 4 consecutive head channels per lane -> 8-byte stores.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -34,6 +35,18 @@ template <> struct Frag<bf16> {
 };
 
 constexpr float NEG_BIG = -1.0e30f;
+// Measured A/B switches (MI355X, N = 4096, d = 40, 128 rows; same device, same call): packed-FMA / v_max3 softmax 4.66 ms;
+// + literal-zero first MFMA 4.66; + lazy running max (wave-uniform branch) 4.93; + bounds-free K/V load variant 5.20.
+// The branchy variants lose more to the split basic blocks than the skipped instructions save: all off.
+#ifndef ATT_ZERO_LITERAL
+#define ATT_ZERO_LITERAL 0
+#endif
+#ifndef ATT_LOAD_SPLIT
+#define ATT_LOAD_SPLIT 0
+#endif
+#ifndef ATT_LAZY
+#define ATT_LAZY 0
+#endif
 #ifndef ETAINV_QT40
 #define ETAINV_QT40 4
 #endif
@@ -51,7 +64,7 @@ __device__ __forceinline__ void row_roles(int b, int n_img, int& half, int& role
 // of both halves take K,V of their source row)
 template <typename T, int D, int QT>
 __global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads,
-                                                        float scale_log2, int mode, int n_img) {
+                                                        float scale_log2, int mode, int n_img, int stagger) {
   typedef typename Frag<T>::v8 v8;
   typedef typename Frag<T>::v4 v4;
   constexpr int DP = (D + 31) / 32 * 32;
@@ -83,6 +96,14 @@ __global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qk
     if (mode == 2 && role == 1) { bk = b - n_img; bv = b - n_img; }
   }
   const int q_base = blockIdx.x * (64 * QT) + wid * (16 * QT);
+  // De-phase the two blocks that share a CU (one wave of each per SIMD): both run [QK^T MFMAs | softmax VALU | PV MFMAs] with the
+  // same period, and started together they stay together -- matrix pipe and VALU are then each idle half of the time.
+  // Blocks 256..511 of every 512 (the second resident block of each CU under round-robin dispatch) start half a tile late.
+  if (stagger > 0) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if ((lin >> 8) & 1)
+      for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  }
 
   // one-time LDS init (both buffers): zero K padding columns (0 * garbage could be NaN), V^T padding rows (ones row)
   if (DP > D) {
@@ -120,23 +141,31 @@ __global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qk
   u32x4 rk[NLD], rv[NLD];
   const T* kbase = qkv + (int64_t)bk * N * C3 + C + h * D;
   const T* vbase = qkv + (int64_t)bv * N * C3 + 2 * C + h * D;
-  auto load_kv = [&](int kv0) {
+  auto load_kv = [&](int kv0, auto full_tag) {
+    constexpr bool FULL = ATT_LOAD_SPLIT && decltype(full_tag)::value;   // every key of the tile exists: no bounds test, no zero fill
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = tid + 256 * i;
-      u32x4 a = {0u, 0u, 0u, 0u}, c = {0u, 0u, 0u, 0u};
-      if (idx < KV * NCH) {
-        {
-          const int key = idx / NCH, ch = idx % NCH;
-          if (kv0 + key < N) a = *reinterpret_cast<const u32x4*>(kbase + (int64_t)(kv0 + key) * C3 + ch * 8);
+      if (FULL) {
+        if (idx < KV * NCH) {   // (lanes past the last chunk never store their registers)
+          rk[i] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)(kv0 + idx / NCH) * C3 + (idx % NCH) * 8);
+          rv[i] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)(kv0 + idx % KV) * C3 + (idx / KV) * 8);
         }
-        {
-          const int key = idx % KV, ch = idx / KV;
-          if (kv0 + key < N) c = *reinterpret_cast<const u32x4*>(vbase + (int64_t)(kv0 + key) * C3 + ch * 8);
+      } else {
+        u32x4 a = {0u, 0u, 0u, 0u}, c = {0u, 0u, 0u, 0u};
+        if (idx < KV * NCH) {
+          {
+            const int key = idx / NCH, ch = idx % NCH;
+            if (kv0 + key < N) a = *reinterpret_cast<const u32x4*>(kbase + (int64_t)(kv0 + key) * C3 + ch * 8);
+          }
+          {
+            const int key = idx % KV, ch = idx / KV;
+            if (kv0 + key < N) c = *reinterpret_cast<const u32x4*>(vbase + (int64_t)(kv0 + key) * C3 + ch * 8);
+          }
         }
+        rk[i] = a;
+        rv[i] = c;
       }
-      rk[i] = a;
-      rv[i] = c;
     }
   };
   auto store_kv = [&](int bufi) {
@@ -172,30 +201,37 @@ __global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qk
   }
 
   const int ntiles = (N + KV - 1) / KV;
-  load_kv(0);
+  const int nfull = N / KV;
+  if (KV <= N) load_kv(0, std::true_type{});
+  else load_kv(0, std::false_type{});
   store_kv(0);
   __syncthreads();
 
   auto tile_body = [&](int j, auto ragged_tag) {
     constexpr bool RAGGED = decltype(ragged_tag)::value;
     const int kv0 = j * KV, cur = j & 1;
-    if (j + 1 < ntiles) load_kv(kv0 + KV);
+    if (j + 1 < nfull) load_kv(kv0 + KV, std::true_type{});
+    else if (j + 1 < ntiles) load_kv(kv0 + KV, std::false_type{});
     const T* tK = sK + cur * KBUF;
     const T* tV = sVt + cur * VBUF;
 
     // ---- S^T = K Q^T : s[qt][kt] holds keys kt*16 + q4*4 + r for query fr
     f32x4 s[QT][4];
+#if !ATT_ZERO_LITERAL
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) s[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
         v8 kf = *reinterpret_cast<const v8*>(tK + (kt * 16 + fr) * KSTR + ks * 32 + q4 * 8);
+        // first K step: C = literal 0 (an inline-constant MFMA operand; zeroing 64 accumulator registers per tile was 6 % of
+        // the loop's issue slots)
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) s[qt][kt] = Frag<T>::mfma(kf, qf[qt][ks], s[qt][kt]);
+        for (int qt = 0; qt < QT; ++qt) s[qt][kt] = Frag<T>::mfma(kf, qf[qt][ks], (ATT_ZERO_LITERAL && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : s[qt][kt]);
       }
     if constexpr (RAGGED) {   // only the last tile of a sequence that is not a multiple of 64 keys
 #pragma unroll
@@ -207,31 +243,43 @@ __global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qk
             if (kv0 + kt * 16 + q4 * 4 + r >= N) s[qt][kt][r] = NEG_BIG;
     }
 
-    // ---- online softmax per query (lane-local + 2 shuffles), P packed straight into PV operands
+    // ---- online softmax per query (lane-local + 2 shuffles), P packed straight into PV operands.
+    // VALU ops and MFMA issue share the SIMD's vector issue port (PMC: 40 % of wave cycles issuing, 79 % of that VALU), so the
+    // softmax is written for instruction count: v_max3 chains and packed-fp32 FMAs for the exponent arguments.  (ATT_LAZY: the
+    // stored max only moves when a query would exceed it by 2^6 -- fewer instructions, but slower, see the switches above.)
     v8 pf[QT][2];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-      float mx = fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), fmaxf(s[qt][0][2], s[qt][0][3]));
+      float mx = fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), s[qt][0][2]);
+      mx = fmaxf(fmaxf(mx, s[qt][0][3]), s[qt][1][0]);
 #pragma unroll
-      for (int kt = 1; kt < 4; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(s[qt][kt][0], s[qt][kt][1])), fmaxf(s[qt][kt][2], s[qt][kt][3]));
+      for (int e = 5; e + 1 < 16; e += 2) mx = fmaxf(fmaxf(mx, s[qt][e >> 2][e & 3]), s[qt][(e + 1) >> 2][(e + 1) & 3]);
+      mx = fmaxf(mx, s[qt][3][3]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[qt], mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * scale_log2);
-      m_run[qt] = m_new;
-      const float nm = -m_new * scale_log2;
+      if (!ATT_LAZY || __builtin_amdgcn_ballot_w64((mx - m_run[qt]) * scale_log2 > 6.0f) != 0) {
+        const float m_new = fmaxf(m_run[qt], mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * scale_log2);
+        m_run[qt] = m_new;
+        if (!ONES_ROW) l_run[qt] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[qt][dt] *= alpha;
+      }
+      const float nm = -m_run[qt] * scale_log2;
+      const f32x2 sc2 = {scale_log2, scale_log2}, nm2 = {nm, nm};
       float rs = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(s[qt][kt][r], scale_log2, nm));
-          if (!ONES_ROW) rs += pv;
-          pf[qt][kt >> 1][(kt & 1) * 4 + r] = (T)pv;
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 t = (f32x2){s[qt][kt][r], s[qt][kt][r + 1]} * sc2 + nm2;
+          const float p0 = __builtin_amdgcn_exp2f(t[0]), p1 = __builtin_amdgcn_exp2f(t[1]);
+          if (!ONES_ROW) rs += p0 + p1;
+          pf[qt][kt >> 1][(kt & 1) * 4 + r] = (T)p0;
+          pf[qt][kt >> 1][(kt & 1) * 4 + r + 1] = (T)p1;
         }
-      if (!ONES_ROW) l_run[qt] = l_run[qt] * alpha + rs;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) acc[qt][dt] *= alpha;
+      if (!ONES_ROW) l_run[qt] += rs;
     }
 
     // ---- O^T += V^T P^T
@@ -250,7 +298,6 @@ __global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qk
     if (j + 1 < ntiles) store_kv(cur ^ 1);   // buffer cur^1 was last read in iteration j-1, a barrier ago
     __syncthreads();
   };
-  const int nfull = N / KV;
   for (int j = 0; j < nfull; ++j) tile_body(j, std::false_type{});
   if (nfull < ntiles) tile_body(nfull, std::true_type{});
 
@@ -494,8 +541,9 @@ static int launch_self_t(const void* qkv, void* out, int b, int n, int heads, in
   }
   const float scale_log2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
   ProfScope prof(PROF_SELF_ATTN, 4.0 * (double)b * heads * (double)n * (double)n * D, s);
+  static const int stagger = getenv("ETAINV_ATT_STAGGER") ? atoi(getenv("ETAINV_ATT_STAGGER")) : 0;
   hipLaunchKernelGGL((self_attn_kernel<T, D, QT>), dim3(cdiv(n, 64 * QT), heads, b), dim3(256), lds, s, (const T*)qkv, (T*)out, n,
-                     heads, scale_log2, mode, n_img);
+                     heads, scale_log2, mode, n_img, stagger);
   ETAINV_LAUNCH_CHECK();
   return 0;
 }

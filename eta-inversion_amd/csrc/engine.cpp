@@ -729,6 +729,23 @@ extern "C" int etainv_prof_read(int cls, double* ms, double* work, int64_t* laun
   *launches = n;
   return 0;
 }
+extern "C" int etainv_prof_records(int cls, double* ms, double* work, int64_t cap, int64_t* launches) {
+  ETAINV_CHECK(cls >= 0 && cls < PROF_NCLASS && ms && work && launches && cap >= 0, "bad arguments");
+  ETAINV_HIP(hipDeviceSynchronize());
+  int64_t n = 0;
+  for (auto& r : g_prof)
+    if (r.cls == cls) {
+      if (n < cap) {
+        float f = 0.f;
+        ETAINV_HIP(hipEventElapsedTime(&f, r.a, r.b));
+        ms[n] = f;
+        work[n] = r.work;
+      }
+      ++n;
+    }
+  *launches = n;
+  return 0;
+}
 
 // ---- per-op entry points for the parity tests
 extern "C" int etainv_op_gemm(const void* a, const void* w, const void* bias, const void* residual, void* out, int m, int n, int k,

@@ -457,20 +457,22 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       __syncthreads();
     }
   } else {
-    // 3-slot LDS ring, software-pipelined fragments, COUNTED vmcnt, raw s_barrier (HIP rendition of the "DMA in flight
-    // across the barrier" structure).  Step s (K tile s of the flattened tile stream, slot s % 3):
-    //     F1 <- ds_read(slot s, k-half 1)            F0 (k-half 0 of slot s) is already in registers
-    //     20 MFMAs on F0                              -> matrix pipe has ~320 cycles of queued work
-    //     lgkmcnt(0)   my reads of slot s are retired (slot s may be overwritten after the barrier)
-    //     vmcnt(n)     everything but the newest slot's DMA has landed -> slot s+1 is complete for this wave
-    //     s_barrier    ... and for every wave; the MFMAs queued above keep executing while waves rendezvous
-    //     issue DMA of step s+3 into slot s % 3      two full K tiles of latency slack
-    //     F0 <- ds_read(slot s+1, k-half 0)          latency hidden under the next MFMA cluster
-    //     20 MFMAs on F1;  epilogue if this was the tile's last K tile
-    constexpr int B_FULL = BN / RP;                                     // B passes every wave takes part in
-    const bool extra_b = (BN % RP != 0) && (wrow0 + RP * B_FULL < BN);   // this wave also issues the partial pass
-    // fragments are kept as opaque 128-bit values (u32x4): arrays of bf16x8 passed by reference get unpacked / repacked
-    // element-wise by hipcc (20+ v_lshrrev / v_perm per cluster)
+    // 3-slot LDS ring, software-pipelined fragments, COUNTED vmcnt, raw s_barrier.  Step s (K tile s of the flattened tile
+    // stream, slot s % 3) is two straight-line windows, each one basic block so that the scheduler can place the non-matrix
+    // instructions INSIDE the MFMA cluster (an MFMA occupies the matrix pipe for 16 cycles but the SIMD's issue port for 8):
+    //   window 1:  20 MFMAs on F0 (k-half 0 of slot s, already in registers)  ||  9 ds_read_b128: F1 <- slot s, k-half 1
+    //              lgkmcnt(0) (slot s may be recycled), vmcnt(N1) (slot s+1 landed for this wave), s_barrier (for every wave)
+    //   window 2:  20 MFMAs on F1  ||  7 LDS-DMA pieces of step s+3 into slot s % 3 with their address arithmetic
+    //                              ||  9 ds_read_b128: F0 <- slot s+1, k-half 0
+    //   step end:  epilogue if this was the tile's last K tile; advance the issue position (tile switch + bias DMA here, off
+    //              the windows).  Before this change the DMA issue (~100 cycles per piece) and the fragment reads ran with
+    //              the matrix pipe idle: measured 47 % MFMA-busy on the large convs.
+    // Every wave issues the same number of DMA pieces per step: the B tile has BN/8 pieces, the waves of the last, partial
+    // pass that have no rows left aim their piece at a 1-KiB dummy area (uniform counted waits, no wave-dependent branch).
+    static_assert(STAGES == 3, "ring");
+    constexpr int B_PASSES = (BN + RP - 1) / RP;
+    constexpr int N1 = A_LOADS + B_PASSES;   // DMA pieces per wave and step
+    T* const dummy = reinterpret_cast<T*>(smem + (size_t)STAGES * (BM + BN) * BK * sizeof(T) + 4 * BN * sizeof(float));
     auto read_frags = [&](int st, int kk, u32x4 (&fa)[MT], u32x4 (&fb)[NT]) __attribute__((always_inline)) {
       const T* tA = sA + st * BM * BK;
       const T* tB = sB + st * BN * BK;
@@ -486,60 +488,102 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       }
     };
     auto mfma_all = [&](u32x4 (&fa)[MT], u32x4 (&fb)[NT]) __attribute__((always_inline)) {
-      if (p.debug & 4) return;   // ablation: no matrix work
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           acc[i][j] = Mfma<T>::run(__builtin_bit_cast(frag, fb[j]), __builtin_bit_cast(frag, fa[i]), acc[i][j]);
     };
-    // waits are emitted with the s_waitcnt BUILTIN (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]):
-    // hipcc's own wait insertion does not see inside inline asm and would add a conservative lgkmcnt(0) in front of
-    // the first MFMA cluster, serialising the fragment reads with the matrix work (measured: exactly additive).
+    // branch-free issue of the K tile at the issue position into ring slot `buf`
+    auto issue_ring = [&](int buf) __attribute__((always_inline)) {
+      const bool second = it_c0 >= p.c1;
+      const T* src = reinterpret_cast<const T*>(second ? p.a2 : p.a1);
+      const int cs = second ? p.c2 : p.c1;
+      const int uoff = (it_ky * p.W + it_kx) * cs + (second ? it_c0 - p.c1 : it_c0);
+      T* dA = sA + buf * BM * BK;
+      T* dB = sB + buf * BN * BK;
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) {
+        const bool ok = (a_mask[i] >> it_tap) & 1;
+        const unsigned elem = (unsigned)((second ? a_e2[i] : a_e1[i]) + uoff);   // garbage for halo lanes, never dereferenced
+        const T* g = ok ? src + elem : zero_page;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(dA + (wrow0 + RP * i) * BK), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < B_PASSES; ++i) {
+        T* dst = (BN % RP == 0 || wrow0 + RP * i < BN) ? dB + (wrow0 + RP * i) * BK : dummy;   // wave-uniform select
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_row[i] + it_kt * BK),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    };
+    auto bias_dma = [&]() __attribute__((always_inline)) {   // bias of the tile at the issue position -> sBias[tile & 3]
+      if (p.bias && wrow0 * 8 < BN) {
+        const int c = wrow0 * 8 + lane;
+        if (c < BN) {
+          const int n = it_n0 + c < p.N ? it_n0 + c : p.N - 1;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + n),
+                                           (__attribute__((address_space(3))) void*)(sBias + it_bias_buf * BN + wrow0 * 8), 4, 0, 0);
+        }
+      }
+    };
+    auto advance_ring = [&]() __attribute__((always_inline)) {
+      it_c0 += BK;
+      if (it_c0 == cin) {
+        it_c0 = 0;
+        ++it_tap;
+        if (++it_kx == 3) { it_kx = 0; ++it_ky; }
+      }
+      if (++it_kt == nk) {
+        it_kt = 0;
+        it_tap = it_ky = it_kx = 0;
+        if (++it_tile < my_tiles) {
+          setup_issue(it_tile);
+          bias_dma();
+        }
+      }
+    };
 #define ETAINV_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
 #define ETAINV_LGKMCNT0() __builtin_amdgcn_s_waitcnt(0xC07F)
     // `young` = store class of an epilogue whose stores are YOUNGER than the DMA that has to have landed (vmcnt counts
     // loads, stores and LDS-DMA together, in issue order): they stay in flight across the wait, so their L2 acks are off the
     // critical path.  Valid for the two steps after the epilogue: [DMA s+2][DMA s+3][stores] and [DMA s+3][stores][DMA s+4].
+    // (A bias DMA issued at a tile switch is younger still: it only makes the wait cover one more piece of the newest slot.)
     auto wait_one_slot_in_flight = [&](int young = 0) {
-      constexpr int S1 = MT * ((NT + 1) / 2), S2 = MT * ((NT / 2 + 1) / 2), N1 = A_LOADS + B_FULL;
-      if (extra_b) {
-        if (young == 1) ETAINV_VMCNT(N1 + 1 + S1);
-        else if (young == 2) ETAINV_VMCNT(N1 + 1 + S2);
-        else ETAINV_VMCNT(N1 + 1);
-      } else {
-        if (young == 1) ETAINV_VMCNT(N1 + S1);
-        else if (young == 2) ETAINV_VMCNT(N1 + S2);
-        else ETAINV_VMCNT(N1);
-      }
+      constexpr int S1 = MT * ((NT + 1) / 2), S2 = MT * ((NT / 2 + 1) / 2);
+      if (young == 1) ETAINV_VMCNT(N1 + S1);
+      else if (young == 2) ETAINV_VMCNT(N1 + S2);
+      else ETAINV_VMCNT(N1);
     };
-    auto wait_two_slots_in_flight = [&]() {
-      if (extra_b) ETAINV_VMCNT(2 * (A_LOADS + B_FULL + 1));
-      else ETAINV_VMCNT(2 * (A_LOADS + B_FULL));
-    };
-    issue_tile(0, 0);
-    if (total_steps > 1) { advance_issue(); issue_tile(it_kt, 1); }
-    if (total_steps > 2) { advance_issue(); issue_tile(it_kt, 2); }
-    if (total_steps > 2) wait_two_slots_in_flight();
-    else if (total_steps > 1) wait_one_slot_in_flight();
+    bias_dma();
+    issue_ring(0);
+    if (total_steps > 1) { advance_ring(); issue_ring(1); }
+    if (total_steps > 2) { advance_ring(); issue_ring(2); }
+    if (total_steps > 3) advance_ring();   // issue position = step 3
+    // (tile switches inside this prologue put bias pieces between the slots: the counts below then over-wait, never under-wait)
+    if (total_steps > 2) ETAINV_VMCNT(2 * N1);
+    else if (total_steps > 1) ETAINV_VMCNT(N1);
     else ETAINV_VMCNT(0);
     __builtin_amdgcn_s_barrier();
     u32x4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
     read_frags(0, 0, fa0, fb0);
-    ETAINV_LGKMCNT0();
     int slot = 0;
     int young_cls = 0, young_steps = 0;   // stores of the last epilogue that later waits may leave in flight
-    // one pipeline step; the steady-state instance (HAS_ISSUE) is branch-free between the fragment reads and the MFMA
-    // clusters -- a control-flow join there makes hipcc insert a conservative lgkmcnt(0) in front of the cluster
     auto step = [&](int sidx, auto has_next_tag, auto has_issue_tag) __attribute__((always_inline)) {
       constexpr bool HAS_NEXT = decltype(has_next_tag)::value, HAS_ISSUE = decltype(has_issue_tag)::value;
       const int nslot = slot == 2 ? 0 : slot + 1;
+      // ---- window 1
       read_frags(slot, 1, fa1, fb1);
-      __builtin_amdgcn_sched_barrier(0);   // keep the 20 MFMAs on F0 ABOVE the waits below
       mfma_all(fa0, fb0);
+#pragma unroll
+      for (int q = 0; q < MT + NT; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 ds_read
+      }
+      if constexpr (MT * NT - 2 * (MT + NT) > 0) __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - 2 * (MT + NT), 0);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (HAS_NEXT) {
-        ETAINV_LGKMCNT0();                   // F1 landed (issued a whole MFMA cluster ago); slot may be recycled after the barrier
+        ETAINV_LGKMCNT0();                   // F1 landed; slot may be recycled after the barrier
         if constexpr (HAS_ISSUE) {
           wait_one_slot_in_flight(young_steps > 0 ? young_cls : 0);
           --young_steps;
@@ -548,16 +592,30 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
           else ETAINV_VMCNT(0);
         }
         __builtin_amdgcn_s_barrier();
-        if constexpr (HAS_ISSUE) {
-          advance_issue();
-          if (!(p.debug & 1)) issue_tile(it_kt, slot);
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- window 2
+        if constexpr (HAS_ISSUE) issue_ring(slot);
         read_frags(nslot, 0, fa0, fb0);
       }
-      // no scheduling barrier here: the DMA issue (address VALU / SALU, M0 writes) and the F0 reads above are independent of
-      // the cluster below, so the scheduler may interleave them into the MFMA issue gaps
       mfma_all(fa1, fb1);
+      if constexpr (HAS_NEXT) {
+        if constexpr (HAS_ISSUE) {
+#pragma unroll
+          for (int q = 0; q < N1; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // 1 DMA piece (VMEM)
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < MT + NT; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if constexpr (MT * NT - (MT + NT) - (HAS_ISSUE ? N1 : 0) > 0)
+          __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT) - (HAS_ISSUE ? N1 : 0), 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
+      // ---- step end
       if (++ct_kt == nk) {
         int m0, n0;
         tile_origin(ct_tile, m0, n0);
@@ -566,7 +624,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         ct_kt = 0;
         ++ct_tile;
       }
-      if constexpr (HAS_NEXT) ETAINV_LGKMCNT0();   // F0 of the next step landed under the cluster above
+      if constexpr (HAS_ISSUE) advance_ring();
       slot = nslot;
     };
     int sidx = 0;
@@ -581,7 +639,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
 template <typename T, int BM, int BN, int WAVES_M, int STAGES = 2>
 static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
   const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
-  const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(T) + 4 * BN * sizeof(float);
+  const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(T) + 4 * BN * sizeof(float) + (STAGES == 3 ? 1024 : 0);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WAVES_M, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -160,6 +160,9 @@ int64_t etainv_engine_weight_bytes(etainv_engine_t* e);
 int etainv_prof_enable(int on);
 int etainv_prof_reset(void);
 int etainv_prof_read(int cls, double* ms, double* work, int64_t* launches);
+/* The individual launches of one class since the last reset, in launch order: fills ms[i], work[i] for i < min(n, cap) and
+ * returns n through *launches (per-shape breakdown of a UNet call: tools/unet_call.py --shapes). */
+int etainv_prof_records(int cls, double* ms, double* work, int64_t cap, int64_t* launches);
 
 /* Per-op entry points used by the parity tests (tests/test_kernels_gpu.py) -- the same launchers the
  * executor uses, exposed so every kernel is checked against a plain fp32 reference in isolation.

@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=128)
 ap.add_argument("--calls", type=int, default=2)
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--shapes", action="store_true", help="event-time every launch of the last call and print time per distinct work size")
 a = ap.parse_args()
 dt = {"fp16": torch.float16, "bf16": torch.bfloat16}[a.dtype]
 B = a.rows // 4
@@ -23,7 +24,30 @@ g = torch.Generator().manual_seed(0)
 x = torch.randn(2 * B, 4, 64, 64, generator=g).cuda()
 ctx = torch.randn(a.rows, 77, 768, generator=g).cuda()
 out = torch.empty(a.rows, 4, 64, 64, device="cuda")
+lib = _capi.load()
 for i in range(a.calls):
+    if a.shapes and i == a.calls - 1:
+        lib.etainv_prof_enable(1)
+        lib.etainv_prof_reset()
     eng.unet(x, 500, ctx, None, out=out)
 torch.cuda.synchronize()
 print("ok", float(out.abs().mean()))
+if a.shapes:
+    import ctypes as C
+    from collections import defaultdict
+    names = ["igemm (FLOP)", "self-attn (FLOP)", "cross-attn (FLOP)", "groupnorm (B)", "layernorm (B)"]
+    total = 0.0
+    for cls, nm in enumerate(names):
+        cap = 4096
+        ms, work, n = (C.c_double * cap)(), (C.c_double * cap)(), C.c_int64(0)
+        _capi.check(lib.etainv_prof_records(cls, ms, work, cap, C.byref(n)))
+        agg = defaultdict(lambda: [0, 0.0])
+        for i in range(min(n.value, cap)):
+            agg[work[i]][0] += 1
+            agg[work[i]][1] += ms[i]
+        t = sum(v[1] for v in agg.values())
+        total += t
+        print(f"== {nm}: {n.value} launches, {t:.2f} ms")
+        for w, (cnt, tm) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+            print(f"   work {w:14.4g}  x{cnt:3d}  {tm:8.3f} ms  ({tm / cnt:7.3f} each)  {w * cnt / tm / 1e9:9.1f} G/s")
+    print(f"total event-timed: {total:.2f} ms")
