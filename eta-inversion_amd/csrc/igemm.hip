@@ -16,7 +16,9 @@
 // vmcnt(0) + barrier per K tile.
 // Epilogue (fused): + bias[n] + rowvec[batch][n] (time-embedding projection) + residual[m][n], or GEGLU
 // a * gelu_erf(g) with (a, g) columns interleaved per 32-column group at weight-pack time.
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include <type_traits>
 
 #include "common.h"
@@ -494,14 +496,16 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         for (int j = 0; j < NT; ++j)
           acc[i][j] = Mfma<T>::run(__builtin_bit_cast(frag, fb[j]), __builtin_bit_cast(frag, fa[i]), acc[i][j]);
     };
-    // branch-free issue of the K tile at the issue position into ring slot `buf`
-    auto issue_ring = [&](int buf) __attribute__((always_inline)) {
+    // Branch-free issue of the K tile at the issue position into ring slot `buf`, in two parts: the activation pieces go out in
+    // window 2 of step s, the weight pieces in window 1 of step s+1.  The CU's vector-memory path moves 64 B/clk, i.e. 16 clocks
+    // per 1-KiB piece: all 56 pieces of a K tile right after the barrier are a 900-clock burst during which window 2 (640
+    // clocks of matrix work) waits on its own last piece (in-kernel stamps: window 1 338 clocks, window 2 1154).
+    auto issue_a = [&](int buf) __attribute__((always_inline)) {
       const bool second = it_c0 >= p.c1;
       const T* src = reinterpret_cast<const T*>(second ? p.a2 : p.a1);
       const int cs = second ? p.c2 : p.c1;
       const int uoff = (it_ky * p.W + it_kx) * cs + (second ? it_c0 - p.c1 : it_c0);
       T* dA = sA + buf * BM * BK;
-      T* dB = sB + buf * BN * BK;
 #pragma unroll
       for (int i = 0; i < A_LOADS; ++i) {
         const bool ok = (a_mask[i] >> it_tap) & 1;
@@ -510,6 +514,9 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(dA + (wrow0 + RP * i) * BK), 16, 0, 0);
       }
+    };
+    auto issue_b = [&](int buf) __attribute__((always_inline)) {
+      T* dB = sB + buf * BN * BK;
 #pragma unroll
       for (int i = 0; i < B_PASSES; ++i) {
         T* dst = (BN % RP == 0 || wrow0 + RP * i < BN) ? dB + (wrow0 + RP * i) * BK : dummy;   // wave-uniform select
@@ -547,7 +554,8 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
 #define ETAINV_LGKMCNT0() __builtin_amdgcn_s_waitcnt(0xC07F)
     // `young` = store class of an epilogue whose stores are YOUNGER than the DMA that has to have landed (vmcnt counts
     // loads, stores and LDS-DMA together, in issue order): they stay in flight across the wait, so their L2 acks are off the
-    // critical path.  Valid for the two steps after the epilogue: [DMA s+2][DMA s+3][stores] and [DMA s+3][stores][DMA s+4].
+    // critical path.  Valid for the step right after the epilogue, where the queue reads [A pieces s+2][stores][B pieces s+2]
+    // (one step later the B pieces of s+2 must have landed and they are younger than the stores).
     // (A bias DMA issued at a tile switch is younger still: it only makes the wait cover one more piece of the newest slot.)
     auto wait_one_slot_in_flight = [&](int young = 0) {
       constexpr int S1 = MT * ((NT + 1) / 2), S2 = MT * ((NT / 2 + 1) / 2);
@@ -555,13 +563,14 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       else if (young == 2) ETAINV_VMCNT(N1 + S2);
       else ETAINV_VMCNT(N1);
     };
+    // prologue: K tiles 0 and 1 whole, of K tile 2 only the activation pieces (its weight pieces go out in step 0's window 1)
     bias_dma();
-    issue_ring(0);
-    if (total_steps > 1) { advance_ring(); issue_ring(1); }
-    if (total_steps > 2) { advance_ring(); issue_ring(2); }
-    if (total_steps > 3) advance_ring();   // issue position = step 3
+    issue_a(0);
+    issue_b(0);
+    if (total_steps > 1) { advance_ring(); issue_a(1); issue_b(1); }
+    if (total_steps > 2) { advance_ring(); issue_a(2); }
     // (tile switches inside this prologue put bias pieces between the slots: the counts below then over-wait, never under-wait)
-    if (total_steps > 2) ETAINV_VMCNT(2 * N1);
+    if (total_steps > 2) ETAINV_VMCNT(N1 + A_LOADS);
     else if (total_steps > 1) ETAINV_VMCNT(N1);
     else ETAINV_VMCNT(0);
     __builtin_amdgcn_s_barrier();
@@ -569,19 +578,41 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     read_frags(0, 0, fa0, fb0);
     int slot = 0;
     int young_cls = 0, young_steps = 0;   // stores of the last epilogue that later waits may leave in flight
-    auto step = [&](int sidx, auto has_next_tag, auto has_issue_tag) __attribute__((always_inline)) {
+#ifdef ETAINV_IGEMM_STAMPS
+    uint64_t st_w1 = 0, st_wait = 0, st_bar = 0, st_w2 = 0, st_end = 0;   // diagnostic build only: s_memtime per step segment
+#endif
+    auto step = [&](int sidx, auto has_next_tag, auto has_issue_tag, auto has_pb_tag) __attribute__((always_inline)) {
       constexpr bool HAS_NEXT = decltype(has_next_tag)::value, HAS_ISSUE = decltype(has_issue_tag)::value;
+      constexpr bool HAS_PB = decltype(has_pb_tag)::value;   // the weight pieces of the K tile whose activation pieces went out last step
       const int nslot = slot == 2 ? 0 : slot + 1;
+      const int pslot = slot == 0 ? 2 : slot - 1;
+#ifdef ETAINV_IGEMM_STAMPS
+      const uint64_t t0 = __builtin_amdgcn_s_memtime();
+#endif
       // ---- window 1
       read_frags(slot, 1, fa1, fb1);
+      if constexpr (HAS_PB) issue_b(pslot);
       mfma_all(fa0, fb0);
 #pragma unroll
       for (int q = 0; q < MT + NT; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 ds_read
       }
-      if constexpr (MT * NT - 2 * (MT + NT) > 0) __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - 2 * (MT + NT), 0);
+      if constexpr (HAS_PB) {
+#pragma unroll
+        for (int q = 0; q < B_PASSES; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // 1 DMA piece
+        }
+      }
+      if constexpr (MT * NT - (MT + NT) - (HAS_PB ? B_PASSES : 0) > 0)
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT) - (HAS_PB ? B_PASSES : 0), 0);
       __builtin_amdgcn_sched_barrier(0);
+#ifdef ETAINV_IGEMM_STAMPS
+      const uint64_t t1 = __builtin_amdgcn_s_memtime();
+      uint64_t t2 = t1, t3 = t1;
+#endif
+      if constexpr (HAS_PB) advance_ring();   // that K tile is fully issued: move the issue position (tile switch + bias DMA here)
       if constexpr (HAS_NEXT) {
         ETAINV_LGKMCNT0();                   // F1 landed; slot may be recycled after the barrier
         if constexpr (HAS_ISSUE) {
@@ -591,46 +622,65 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
           if (sidx + 2 < total_steps) wait_one_slot_in_flight();
           else ETAINV_VMCNT(0);
         }
+#ifdef ETAINV_IGEMM_STAMPS
+        t2 = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef ETAINV_IGEMM_STAMPS
+        t3 = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // ---- window 2
-        if constexpr (HAS_ISSUE) issue_ring(slot);
         read_frags(nslot, 0, fa0, fb0);
+        if constexpr (HAS_ISSUE) issue_a(slot);
       }
       mfma_all(fa1, fb1);
       if constexpr (HAS_NEXT) {
-        if constexpr (HAS_ISSUE) {
-#pragma unroll
-          for (int q = 0; q < N1; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // 1 DMA piece (VMEM)
-          }
-        }
 #pragma unroll
         for (int q = 0; q < MT + NT; ++q) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        if constexpr (MT * NT - (MT + NT) - (HAS_ISSUE ? N1 : 0) > 0)
-          __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT) - (HAS_ISSUE ? N1 : 0), 0);
+        if constexpr (HAS_ISSUE) {
+#pragma unroll
+          for (int q = 0; q < A_LOADS; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // 1 DMA piece
+          }
+        }
+        if constexpr (MT * NT - (MT + NT) - (HAS_ISSUE ? A_LOADS : 0) > 0)
+          __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT) - (HAS_ISSUE ? A_LOADS : 0), 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+#ifdef ETAINV_IGEMM_STAMPS
+      const uint64_t t4 = __builtin_amdgcn_s_memtime();
+      st_w1 += t1 - t0; st_wait += t2 - t1; st_bar += t3 - t2; st_w2 += t4 - t3;
+#endif
       // ---- step end
       if (++ct_kt == nk) {
         int m0, n0;
         tile_origin(ct_tile, m0, n0);
         young_cls = epilogue(m0, n0, ct_tile);
-        young_steps = (nk >= 3 && HAS_ISSUE) ? 2 : 0;
+        young_steps = (nk >= 3 && HAS_ISSUE) ? 1 : 0;
         ct_kt = 0;
         ++ct_tile;
       }
-      if constexpr (HAS_ISSUE) advance_ring();
       slot = nslot;
+#ifdef ETAINV_IGEMM_STAMPS
+      st_end += __builtin_amdgcn_s_memtime() - t4;
+#endif
     };
     int sidx = 0;
-    for (; sidx + 3 < total_steps; ++sidx) step(sidx, std::true_type{}, std::true_type{});
-    for (; sidx + 1 < total_steps; ++sidx) step(sidx, std::true_type{}, std::false_type{});
-    step(sidx, std::false_type{}, std::false_type{});
+    for (; sidx + 3 < total_steps; ++sidx) step(sidx, std::true_type{}, std::true_type{}, std::true_type{});
+    if (total_steps >= 3) { step(sidx, std::true_type{}, std::false_type{}, std::true_type{}); ++sidx; }   // last weight pieces
+    for (; sidx + 1 < total_steps; ++sidx) step(sidx, std::true_type{}, std::false_type{}, std::false_type{});
+    step(sidx, std::false_type{}, std::false_type{}, std::false_type{});
+#ifdef ETAINV_IGEMM_STAMPS
+    if (p.stamps && lane == 0) {
+      uint64_t* o = p.stamps + ((size_t)blockIdx.x * 8 + wid) * 8;
+      o[0] = st_w1; o[1] = st_wait; o[2] = st_bar; o[3] = st_w2; o[4] = st_end; o[5] = (uint64_t)total_steps;
+    }
+#endif
 #undef ETAINV_VMCNT
 #undef ETAINV_LGKMCNT0
   }
@@ -648,6 +698,31 @@ static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
   // persistent grid: as many blocks as are resident at once (LDS-limited: 160 KiB / lds per CU, 256 CUs), a multiple of 8
   const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / lds)));
   const int grid = std::min(tiles, 256 * per_cu);
+#ifdef ETAINV_IGEMM_STAMPS
+  static uint64_t* d_stamps = nullptr;
+  IGemmParams ps = p;
+  if (STAGES == 3 && getenv("ETAINV_IGEMM_STAMPS")) {
+    if (!d_stamps) (void)hipMalloc(&d_stamps, 2048 * 8 * 8 * sizeof(uint64_t));
+    (void)hipMemsetAsync(d_stamps, 0, 2048 * 8 * 8 * sizeof(uint64_t), s);
+    ps.stamps = d_stamps;
+  }
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES>), dim3(grid), dim3(WAVES_M * 128), lds, s, ps);
+  if (ps.stamps) {
+    (void)hipStreamSynchronize(s);
+    std::vector<uint64_t> h((size_t)grid * 8 * 8);
+    (void)hipMemcpy(h.data(), d_stamps, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    double sum[5] = {0, 0, 0, 0, 0}, steps = 0;
+    for (int b = 0; b < grid; ++b)
+      for (int w = 0; w < 8; ++w) {
+        const uint64_t* o = &h[((size_t)b * 8 + w) * 8];
+        for (int k = 0; k < 5; ++k) sum[k] += (double)o[k];
+        steps += (double)o[5];
+      }
+    fprintf(stderr, "[igemm stamps %dx%d M=%d N=%d K=%d] s_memtime ticks (100 MHz) per step and wave: w1 %.2f wait %.2f barrier %.2f w2 %.2f end %.2f\n", BM, BN,
+            p.M, p.N, p.taps * (p.c1 + p.c2), sum[0] / steps, sum[1] / steps, sum[2] / steps, sum[3] / steps, sum[4] / steps);
+  }
+  return 0;
+#endif
   ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s);
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES>), dim3(grid), dim3(WAVES_M * 128), lds, s, p);
   ETAINV_LAUNCH_CHECK();
@@ -682,8 +757,8 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
     // experimental (opt-in): 256 x 160 x 64 tile, 8 waves, one resident block per CU (26 % fewer L2 -> LDS bytes per
     // FLOP).  Measured equal to 128 x 160 with two resident blocks (1026 vs 1033 TFLOP/s on conv 1280->1280 @16x16)
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3>(p, s)));
-  } else if (p.geglu && p.c1 >= 640 && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 128) >= 256 && !getenv("ETAINV_NO_RING")) {
-    // (K = 320 is only 5 K tiles per output tile: the epilogue-bound case stays on two resident 128 x 128 blocks per CU)
+  } else if (p.geglu && p.c1 >= (getenv("ETAINV_GEGLU_RING_MINK") ? atoi(getenv("ETAINV_GEGLU_RING_MINK")) : 320) && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 128) >= 256 && !getenv("ETAINV_NO_RING")) {
+    // (since the interleaved windows the ring also wins at K = 320: 1.42 vs 1.55 ms for ff1 320 -> 2560 at 64 x 64 x 128 rows)
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 128, 4, 3>(p, s)));
   } else if (big && !p.geglu && p.N % 160 == 0) {
     // every channel count of SD1.x is a multiple of 320: 160-wide tiles leave no padded columns (N = 320 would waste

@@ -22,6 +22,7 @@ struct IGemmParams {
   // timing experiments only (ETAINV_IGEMM_DEBUG bit mask): 1 no DMA in the loop, 2 no epilogue, 4 no MFMA, 8 stores hit cache-resident
   // rows, 16 no young-store vmcnt allowance, 32 8-byte stores (no lane swap), 64 epilogue without its stores, 128 sigmoid-polynomial GELU
   int debug = 0;
+  unsigned long* stamps = nullptr;         // diagnostic build (-DETAINV_IGEMM_STAMPS) only
   int stagger = 0;                  // experiment (ETAINV_STAGGER): start delay of the second co-resident block, 64-cycle ticks
   int M = 0, N = 0;
   int c1 = 0, c2 = 0;
