@@ -86,6 +86,13 @@ __global__ void __launch_bounds__(256) local_blend_kernel(const float* __restric
   float* mp = sm;
   float* pl = sm + 2 * RR;
   float* red = sm + 4 * RR;
+  {
+    // image without blend words in a batch (its alpha rows are all zero): the reference builds no LocalBlend for it
+    // (ptp.py:306-320, blend_words None) -- leave its latent untouched
+    int any = 0;
+    for (int k = threadIdx.x; k < 2 * 77; k += blockDim.x) any |= blend_alpha[(int64_t)img * 2 * 77 + k] != 0.f;
+    if (!__syncthreads_or(any)) return;
+  }
   for (int idx = threadIdx.x; idx < 2 * RR; idx += blockDim.x) {
     const int role = idx / RR, pix = idx - role * RR;
     const float* al = blend_alpha + ((int64_t)img * 2 + role) * 77;

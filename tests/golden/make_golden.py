@@ -427,8 +427,45 @@ def gen_e2e(S=3):
     save("e2e_toy", **out)
 
 
+
+def gen_pie_bench():
+    """reference dataset/pie_bench_data.py on a synthetic mapping_file.json (the real PIE-Bench is not in the container):
+    records, edit_word_idx and decoded RLE masks"""
+    import tempfile
+    sys.path.insert(0, str(REF))
+    from dataset.pie_bench_data import PieBenchData
+    rng = np.random.RandomState(7)
+    mapping = {}
+    rows = [("a [round] cake with orange frosting", "a [square] cake with orange frosting", "round square"),
+            ("a cat sitting on a wooden chair", "a [dog] sitting on a wooden chair", "cat dog"),
+            ("a woman with [long] hair", "a woman with [short] hair and a hat", ""),
+            ("the house near the lake", "the house near the frozen lake", "lake river"),        # target word missing -> None
+            ("a painting of a tower", "a painting of a bridge", "tower bridge")]
+    for k, (src, tgt, bw) in enumerate(rows):
+        runs, pos = [], 0
+        for _ in range(int(rng.randint(0, 6))):
+            pos += int(rng.randint(1, 60000))
+            runs += [pos, int(rng.randint(1, 3000))]
+        if k == 1:
+            runs += [512 * 512 - 10, 500]                    # run clipped at the end of the image
+        mapping[f"{k:012d}"] = {"image_path": f"0_random_140/{k:012d}.jpg", "original_prompt": src, "editing_prompt": tgt,
+                                "editing_instruction": "x", "editing_type_id": "0", "blended_word": bw, "mask": runs}
+    with tempfile.TemporaryDirectory() as d:
+        (Path(d) / "mapping_file.json").write_text(json.dumps(mapping))
+        data = PieBenchData(d, skip_img_load=True)
+        recs, masks = [], {}
+        for i in range(len(data)):
+            s = data[i]
+            masks[f"mask{i}"] = np.packbits(s["mask"].numpy().astype(np.uint8))
+            recs.append({"source_prompt": s["source_prompt"], "target_prompt": s["target_prompt"], "image_rel": os.path.relpath(s["image_file"], d),
+                         "edit_word_idx": s["edit_word_idx"], "ptp": json.loads(json.dumps(s["edit"]["ptp"])), "mask_sum": float(s["mask"].sum())})
+    (OUT / "pie_bench.json").write_text(json.dumps({"mapping": mapping, "records": recs}, indent=1))
+    save("pie_bench_masks", **masks)
+
+
 GENS = {"schedule": gen_schedule, "ddim_inverse": gen_ddim_inverse, "eta_step": gen_eta_step,
-        "ptp_tables": gen_ptp_tables, "ptp_algebra": gen_ptp_algebra, "masactrl": gen_masactrl, "e2e": gen_e2e}
+        "ptp_tables": gen_ptp_tables, "ptp_algebra": gen_ptp_algebra, "masactrl": gen_masactrl, "e2e": gen_e2e, "pie_bench": gen_pie_bench}
+
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

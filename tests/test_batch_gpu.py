@@ -1,0 +1,87 @@
+"""Batched PIE-style driver (etainv/batch.py, eval.py) vs the one-image plugin API on the same engine weights: a batch of B
+independent pairs must give each image the result `load_editor("ptp").edit` gives it alone (same kernels, per-image tables)."""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.fixture(scope="module")
+def pipe():
+    from modules import load_diffusion_model
+    p, pp = load_diffusion_model("CompVis/stable-diffusion-v1-4", "cuda", variant="fp16", latent_size=16, max_img=3)
+    return p, pp
+
+
+def _samples(n):
+    g = torch.Generator().manual_seed(11)
+    rows = [("a round cake with orange frosting", "a square cake with orange frosting", ("round", "square")),
+            ("a cat sitting on a wooden chair", "a dog sitting on a wooden chair", ("cat", "dog")),
+            ("a woman with long hair", "a woman with short hair and a hat", None)][:n]
+    out = []
+    for src, tgt, bw in rows:
+        ptp = dict(is_replace_controller=False, prompts=[src, tgt], cross_replace_steps={'default_': .4}, self_replace_steps=0.6,
+                   blend_words=((bw[0],), (bw[1],)) if bw else None, equilizer_params={"words": (bw[1],), "values": (2,)} if bw else None)
+        ew = [src.split(" ").index(bw[0]), tgt.split(" ").index(bw[1])] if bw else [3, 3]
+        out.append(dict(image=(torch.rand(1, 3, 128, 128, generator=g) * 2 - 1), source_prompt=src, target_prompt=tgt, edit_word_idx=ew, ptp=ptp))
+    return out
+
+
+def test_batch_equals_single(pipe):
+    from etainv.batch import BatchEditor
+    from modules import load_editor, load_inverter
+    p, _ = pipe
+    S = 4
+    samples = _samples(3)
+    batch = BatchEditor(p, num_inference_steps=S).edit(samples)
+    inverter = load_inverter(type="etainv", model=p, scheduler="ddim", num_inference_steps=S, eta=[[0.6, 0], [1, 0.7]])
+    editor = load_editor(type="ptp", inverter=inverter)
+    for s, got in zip(samples, batch):
+        want = editor.edit(s["image"].cuda(), s["source_prompt"], s["target_prompt"], cfg={k: v for k, v in s["ptp"].items()},
+                           inv_cfg=dict(edit_word_idx=s["edit_word_idx"]))
+        assert torch.equal(got["latent_inv"], want["latent_inv"])                 # source row replays the inversion exactly
+        assert rel(got["latent"], want["latent"]) < 2e-3                           # batch-size invariance of the kernels (fp16 tiles)
+        assert got["image"].shape == (1, 3, 128, 128) and rel(got["image"], want["image"]) < 5e-3
+
+
+def test_missing_edit_word_is_skipped(pipe):
+    from etainv.batch import BatchEditor
+    p, _ = pipe
+    samples = _samples(2)
+    samples[1]["edit_word_idx"] = [1, None]                                        # reference: invert returns None -> edit returns None
+    res = BatchEditor(p, num_inference_steps=2).edit(samples)
+    assert res[0] is not None and res[1] is None
+
+
+def test_eval_cli_writes_named_pngs_and_resumes(pipe, tmp_path):
+    from PIL import Image
+    g = json.loads((GOLD / "pie_bench.json").read_text())
+    root = tmp_path / "pie"
+    (root / "annotation_images" / "0_random_140").mkdir(parents=True)
+    (root / "mapping_file.json").write_text(json.dumps(g["mapping"]))
+    rng = np.random.RandomState(0)
+    for rec in g["records"]:
+        Image.fromarray(rng.randint(0, 255, (96, 128, 3), dtype=np.uint8)).save(str(root / rec["image_rel"]))
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "eta-inversion_amd"))
+    import eval as pie_eval
+    out = tmp_path / "res"
+    argv = ["--data_path", str(root), "--output", str(out), "--batch", "3", "--steps", "2", "--size", "128", "--prec", "fp16"]
+    pie_eval.main(argv)
+    names = sorted(f.name for f in (out / "imgs").glob("*.png"))
+    want = sorted(f"{i:04d}_{r['source_prompt']}_{r['target_prompt']}.png" for i, r in enumerate(g["records"]) if None not in r["edit_word_idx"])
+    assert names == want and len(names) == 3                                       # samples 2 (no blend word) and 3 (word missing) return None
+    assert np.array(Image.open(out / "imgs" / names[0])).shape == (128, 128, 3)
+    stamp = {n: (out / "imgs" / n).stat().st_mtime_ns for n in names}
+    pie_eval.main(argv)                                                            # second run: everything exists -> nothing rewritten
+    assert stamp == {n: (out / "imgs" / n).stat().st_mtime_ns for n in names}
