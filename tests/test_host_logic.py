@@ -152,3 +152,59 @@ def test_gather_latents_world_size_2_gloo():
         p.join(60)
     for _, vals in res:
         assert vals == [0.0, 1.0, 2.0, 3.0, 4.0]
+
+
+def _toy_bpe(tmp_path):
+    """a small byte-level BPE vocabulary trained on a toy corpus, written in the CLIP tokenizer's file formats"""
+    import collections
+    from modules.utils.tokenizer import _bytes_to_unicode
+    b2u = _bytes_to_unicode()
+    corpus = ("a photo of a cat sitting on a wooden chair . a round cake with orange frosting , the house near the frozen lake ! "
+              "it's a dog's painting of 2 towers and 35 bridges café naïve").split()
+    vocab = list(b2u.values()) + [v + "</w>" for v in b2u.values()]
+    sym = lambda w: tuple([b2u[b] for b in w.encode()][:-1] + [b2u[w.encode()[-1]] + "</w>"])
+    seqs, merges = collections.Counter(sym(w) for w in corpus), []
+    for _ in range(80):
+        pairs = collections.Counter()
+        for s, c in seqs.items():
+            for a, b in zip(s, s[1:]):
+                pairs[(a, b)] += c
+        if not pairs:
+            break
+        (a, b), _c = max(sorted(pairs.items()), key=lambda kv: kv[1])
+        merges.append((a, b))
+        vocab.append(a + b)
+        new = collections.Counter()
+        for s, c in seqs.items():
+            out, i = [], 0
+            while i < len(s):
+                if i + 1 < len(s) and s[i] == a and s[i + 1] == b:
+                    out.append(a + b)
+                    i += 2
+                else:
+                    out.append(s[i])
+                    i += 1
+            new[tuple(out)] += c
+        seqs = new
+    vocab += ["<|startoftext|>", "<|endoftext|>"]
+    (tmp_path / "vocab.json").write_text(json.dumps({t: i for i, t in enumerate(vocab)}))
+    (tmp_path / "merges.txt").write_text("#version: 0.2\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n")
+    return str(tmp_path / "vocab.json"), str(tmp_path / "merges.txt")
+
+
+def test_clip_bpe_tokenizer_matches_transformers(tmp_path):
+    """the native byte-level BPE (modules/utils/tokenizer.py) against the installed third-party implementation on the same files"""
+    transformers = pytest.importorskip("transformers")
+    from modules.utils.tokenizer import ClipBPETokenizer
+    vocab, merges = _toy_bpe(tmp_path)
+    ref, nat = transformers.CLIPTokenizer(vocab, merges), ClipBPETokenizer(vocab, merges)
+    prompts = ["a cat sitting on a wooden chair", "A  photo of 35 Dogs!", "it's the frozen-lake's painting", "", "café naïve towers,bridges...",
+               "a round cake with orange frosting", " leading and trailing  ", "x" * 200, "we'll they've i'm can't"]
+    for p in prompts:
+        assert nat.encode(p) == ref.encode(p), p
+    a = nat(prompts, padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+    b = ref(prompts, padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+    assert a.shape == (len(prompts), 77) and torch.equal(a, b)
+    assert (nat.bos_token_id, nat.eos_token_id) == (ref.bos_token_id, ref.eos_token_id)
+    ids = nat.encode("a wooden chair")
+    assert [nat.decode([i]) for i in ids[1:-1]] == [ref.decode([i]) for i in ids[1:-1]]      # ptp_utils.get_word_inds decodes single ids
