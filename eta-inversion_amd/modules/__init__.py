@@ -1,11 +1,12 @@
 """Registries of the reference's modules/__init__.py:31-111: load_inverter / load_editor / get_inversion_methods /
-get_edit_methods / register_editor.  Built on the MI355X engine: `etainv` (+ the plain `diffinv` base) and the
+get_edit_methods / register_editor.  Built on the MI355X engine: `etainv`, `dirinv` (+ the plain `diffinv` base) and the
 `simple`, `ptp`, `masactrl` editors; the reference's other method names are listed but raise a clear error."""
 from functools import partial
 from typing import Callable, List
 
 from .inversion.diffusion_inversion import DiffusionInversion
 from .inversion.eta_inversion import EtaInversion
+from .inversion.direct_inversion import DirectInversion
 from .editing.editor import Editor
 from .editing.simple_editor import SimpleEditor
 from .editing.ptp_editor import PromptToPromptEditor
@@ -14,12 +15,12 @@ from .models import StablePreprocess, StablePostProc, load_diffusion_model
 
 
 def _not_built(name, *a, **k):
-    raise NotImplementedError(f"'{name}' is outside the MI355X hot path built so far (SURVEY.md 8f); available: etainv, diffinv / "
+    raise NotImplementedError(f"'{name}' is outside the MI355X hot path built so far (SURVEY.md 8f); available: etainv, dirinv, diffinv / "
                               f"simple, ptp, masactrl")
 
 
-_inverters = {"diffinv": DiffusionInversion, "etainv": EtaInversion,
-              **{n: partial(_not_built, n) for n in ("nti", "npi", "proxnpi", "edict", "ddpminv", "cyclediff", "dirinv", "regdiffinv")}}
+_inverters = {"diffinv": DiffusionInversion, "etainv": EtaInversion, "dirinv": DirectInversion,
+              **{n: partial(_not_built, n) for n in ("nti", "npi", "proxnpi", "edict", "ddpminv", "cyclediff", "regdiffinv")}}
 _editors = {"simple": SimpleEditor, "ptp": PromptToPromptEditor, "masactrl": MasactrlEditor,
             **{n: partial(_not_built, n) for n in ("pnp", "pix2pix_zero", "invedit")}}
 

@@ -428,6 +428,33 @@ def gen_e2e(S=3):
 
 
 
+def gen_e2e_dirinv(S=2):
+    """Reference DirectInversion (modules/inversion/direct_inversion.py) + PromptToPromptEditor on the toy-width oracle UNet:
+    the eta = 0, mask-free special case of the same loop."""
+    from modules.inversion.direct_inversion import DirectInversion
+    from modules.editing.ptp_editor import PromptToPromptEditor
+    src, tgt = PROMPT_PAIRS[0]
+    unet = toy_unet(0)
+    z0 = 0.8 * torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(2025))
+    ptp_cfg = dict(is_replace_controller=False, prompts=[src, tgt], cross_replace_steps={"default_": .4},
+                   self_replace_steps=0.6, blend_words=(("cat",), ("tiger",)),
+                   equilizer_params={"words": ("tiger",), "values": (2,)})
+    pipe = make_pipe(unet)
+    inv = DirectInversion(pipe, scheduler="ddim", num_inference_steps=S)
+    captured = {}
+    orig_inv = inv.invert
+
+    def wrapped_inv(*a, _o=orig_inv, **k):
+        r = _o(*a, **k)
+        captured["inv"] = r
+        return r
+    inv.invert = wrapped_inv
+    res = PromptToPromptEditor(inv).edit(z0 / 0.18215, src, tgt, cfg={**ptp_cfg}, inv_cfg=dict(edit_word_idx=(1, 1)))
+    invr = captured["inv"]
+    save("e2e_dirinv", z0=z0, S=np.array(S), ctx_src=invr["context"], ctx_tgt=inv.create_context(tgt), inv_latents=torch.cat(invr["latents"]),
+         latent_inv=res["latent_inv"], latent=res["latent"])
+
+
 def gen_pie_bench():
     """reference dataset/pie_bench_data.py on a synthetic mapping_file.json (the real PIE-Bench is not in the container):
     records, edit_word_idx and decoded RLE masks"""
@@ -464,7 +491,7 @@ def gen_pie_bench():
 
 
 GENS = {"schedule": gen_schedule, "ddim_inverse": gen_ddim_inverse, "eta_step": gen_eta_step,
-        "ptp_tables": gen_ptp_tables, "ptp_algebra": gen_ptp_algebra, "masactrl": gen_masactrl, "e2e": gen_e2e, "pie_bench": gen_pie_bench}
+        "ptp_tables": gen_ptp_tables, "ptp_algebra": gen_ptp_algebra, "masactrl": gen_masactrl, "e2e": gen_e2e, "e2e_dirinv": gen_e2e_dirinv, "pie_bench": gen_pie_bench}
 
 
 if __name__ == "__main__":

@@ -185,6 +185,24 @@ def test_e2e_loop_vs_reference(golden, toy_unet, name):
     np.testing.assert_allclose(z[1:].numpy(), g[f"{name}/latent"], rtol=1e-3, atol=2e-4)
 
 
+def test_dirinv_is_eta_zero(golden, toy_unet):
+    """Reference DirectInversion + ptp editor on the toy UNet (make_golden.gen_e2e_dirinv) == the oracle loop with eta = 0 and no
+    mask: pins the claim that dirinv is a special case of the same path."""
+    g = golden("e2e_dirinv")
+    S = int(g["S"])
+    src, tgt = json.load(open(f"{GOLDEN_DIR}/prompt_pairs.json"))[0]
+    z0 = torch.from_numpy(g["z0"])
+    ctx_s, ctx_t = torch.from_numpy(g["ctx_src"]), torch.from_numpy(g["ctx_tgt"])
+    with torch.no_grad():
+        o = oloop.EtaInversionOracle(toy_unet, S=S, eta=(0.0, 0.0), noise_sample_count=1, use_mask=False)
+        inv = o.invert(z0, ctx_s, src)
+        np.testing.assert_allclose(torch.cat(inv["latents"]).numpy(), g["inv_latents"], rtol=1e-4, atol=2e-5)
+        controller = optp.make_edit_controller(src, tgt, S, optp.WordTokenizer(), **PTP_VARIANTS["refine"])
+        z = o.sample(inv, ctx_s, ctx_t, oloop.noise_table(S, 1, 64, seed=0), edit_word_idx=(1, 1), controller=controller)
+    np.testing.assert_allclose(z[:1].numpy(), g["latent_inv"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(z[1:].numpy(), g["latent"], rtol=1e-3, atol=2e-4)
+
+
 def test_clip_oracle_matches_transformers():
     """oracle/clip.py is pinned by the third-party implementation itself where it is importable: transformers'
     CLIPTextModel (ViT-L/14 text config) loaded with the oracle's seeded weights gives the same hidden states."""
