@@ -123,7 +123,8 @@ __global__ void __launch_bounds__(256) eta_update_kernel(const T* __restrict__ x
   if (e >= chw) return;
   const float z = to_f32(noise[(int64_t)s_best * chw + e]);
   float eta_px = k.eta;
-  if (use_mask) eta_px = (to_f32(mask_map[(int64_t)img * hw + (e % hw)]) > k.thres) ? k.eta : 0.f;
+  if (use_mask == 1) eta_px = (to_f32(mask_map[(int64_t)img * hw + (e % hw)]) > k.thres) ? k.eta : 0.f;
+  else if (use_mask == 2) eta_px = to_f32(mask_map[(int64_t)img * hw + (e % hw)]) * k.eta;   // soft / precomputed mask (thres None, pow)
   const float std_t = eta_px * sqrtf(k.var);
   const float dir_c = sqrtf(1.f - k.a_p - std_t * std_t);
   const float xp = to_f32(x_prev[(int64_t)img * chw + e]);

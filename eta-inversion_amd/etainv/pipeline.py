@@ -43,7 +43,7 @@ def eta_table(eta=(0.0, 0.4)) -> np.ndarray:
 
 class EtaLoop:
     def __init__(self, engine, S=50, guidance_scale_bwd=7.5, guidance_scale_fwd=1.0, eta=(0.0, 0.4), noise_sample_count=10,
-                 use_mask=True, mask_thres=0.2, skip_uncond_fwd=True, steps_offset=0):
+                 use_mask=True, mask_thres=0.2, skip_uncond_fwd=True, steps_offset=0, mask_eta="fwd_mean", mask_pow=None):
         self.e, self.S, self.L = engine, S, engine.L
         self.g_bwd, self.g_fwd = float(guidance_scale_bwd), float(guidance_scale_fwd)
         self.ac = alphas_cumprod()
@@ -53,6 +53,8 @@ class EtaLoop:
         self.etas = eta_table(eta)
         self.n_cand = noise_sample_count
         self.use_mask, self.mask_thres = use_mask, mask_thres
+        # non-default eta-mask modes (reference eta_inversion.py:164-201): source of the map (fwd_mean | fwd | gt), thres None = soft, pow
+        self.mask_eta, self.mask_pow = mask_eta, mask_pow
         # u + 1*(c - u) == c up to rounding: the uncond half of the forward pass is dead work when g_fwd == 1
         self.skip_uncond_fwd = skip_uncond_fwd and self.g_fwd == 1.0
         self.lib = engine.lib
@@ -77,11 +79,13 @@ class EtaLoop:
         rows = ctx.shape[0]
         eps_all = torch.empty(rows, 4, L, L, dtype=torch.float32, device=dev)
         eps = eps_all if self.skip_uncond_fwd else torch.empty(B, 4, L, L, dtype=torch.float32, device=dev)
-        maps_mean = None
+        maps_mean = maps_steps = None
         ctrl = None
         if self.use_mask:
             assert tokens is not None
             maps_mean = torch.zeros(B, tokens.shape[1], L, L, dtype=torch.float32, device=dev)
+            if self.mask_eta == "fwd":                                            # per-step maps, keyed by step (eta_inversion.py:44-49,168)
+                maps_steps = torch.zeros(S, B, tokens.shape[1], L, L, dtype=torch.float32, device=dev)
             ctrl = AttnControl(mode=_capi.ATTN_STORE, n_img=B, store_maps=True)
             e.maps_reset()
         n = B * 4 * L * L
@@ -95,10 +99,12 @@ class EtaLoop:
             _capi.check(self.lib.etainv_ddim_step(_capi.ptr(lat[j]), _capi.ptr(eps), a_from, a_to, _capi.ptr(lat[j + 1]), n, _capi.F32, st))
             if self.use_mask:
                 e.word_maps(B, tokens, j + 1, maps_mean, accumulate=True, scale=1.0 / S)
-        return {"latents": lat, "maps_mean": maps_mean}
+                if maps_steps is not None:
+                    e.word_maps(B, tokens, j + 1, maps_steps[j], accumulate=False, scale=1.0)
+        return {"latents": lat, "maps_mean": maps_mean, "maps_steps": maps_steps}
 
     # ---------------------------------------------------------------- backward / eta sampling
-    def sample(self, inv, ctx_src, ctx_tgt, noise, edit_word=None, ptp=None, masactrl=None, trace=None):
+    def sample(self, inv, ctx_src, ctx_tgt, noise, edit_word=None, ptp=None, masactrl=None, trace=None, gt_mask=None):
         """noise (S,n_cand,4,L,L) fp32: the candidates of every step (reference draws them from a generator reseeded
         per image, eta_inversion.py:156,276, so all images share the table).  edit_word (B,) index into the word maps.
         ptp: PtpTables or None; masactrl: (start_step, first_block) or None.  Returns latents (2B,4,L,L) [src.., tgt..]."""
@@ -112,10 +118,25 @@ class EtaLoop:
         eps_all = torch.empty(4 * B, 4, L, L, dtype=torch.float32, device=dev)
         best = torch.zeros(B, dtype=torch.int32, device=dev)
         scratch = torch.empty(B * 16 * 64, dtype=torch.float32, device=dev)
-        mask_map = None
+        mask_map, mask_mode = None, int(self.use_mask)
         if self.use_mask:
             idx = edit_word.to(dev).long().reshape(B, 1, 1, 1).expand(B, 1, L, L)
-            mask_map = inv["maps_mean"].gather(1, idx).reshape(B, L, L).contiguous()
+            final = self.mask_thres is None or self.mask_pow is not None or self.mask_eta != "fwd_mean"
+
+            def prep(m):                                                            # get_mask tail, eta_inversion.py:196-201
+                if not final:
+                    return m.contiguous()
+                if self.mask_thres is not None:
+                    m = (m > self.mask_thres).to(m.dtype)
+                if self.mask_pow is not None:
+                    m = torch.pow(m, self.mask_pow)
+                return m.contiguous()
+            mask_mode = 2 if final else 1                                           # 2: the map is the per-pixel eta multiplier
+            if self.mask_eta == "gt":
+                assert gt_mask is not None, "mask_eta='gt' needs the ground-truth mask (B,L,L)"
+                mask_map = prep(gt_mask.to(dev).float().reshape(B, L, L))
+            elif self.mask_eta == "fwd_mean":
+                mask_map = prep(inv["maps_mean"].gather(1, idx).reshape(B, L, L))
         if ptp is not None:
             e.maps_reset()
         st = _capi.stream_ptr()
@@ -132,9 +153,11 @@ class EtaLoop:
             p = t - self.delta
             a_t, a_p = float(self.ac[t]), (float(self.ac[p]) if p >= 0 else float(self.ac[0]))
             var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
+            if self.use_mask and self.mask_eta == "fwd":                            # map of THIS timestep (t_bwd[i] == t_fwd[S-1-i])
+                mask_map = prep(inv["maps_steps"][S - 1 - i].gather(1, idx).reshape(B, L, L))
             _capi.check(self.lib.etainv_eta_backward_step(
                 _capi.ptr(x), _capi.ptr(eps_all), self.g_bwd, _capi.ptr(lat_inv[S - 1 - i]), _capi.ptr(noise[i]), self.n_cand,
-                float(self.etas[t]), _capi.ptr(mask_map), self.mask_thres, int(self.use_mask), a_t, a_p, var, B, 4, L * L,
+                float(self.etas[t]), _capi.ptr(mask_map), float(self.mask_thres or 0.0), mask_mode, a_t, a_p, var, B, 4, L * L,
                 _capi.ptr(x_new), None, _capi.ptr(best), None, _capi.ptr(scratch), _capi.F32, st))
             x, x_new = x_new, x
             if ptp is not None and ptp.blend_alpha is not None and (i + 1) > int(0.2 * S):

@@ -23,8 +23,10 @@ class EtaInversion(DiffusionInversion):
             dft = dict(attn_from_where=["up", "down"], attn_res=16, mask_dirinv=None, mask_eta="fwd_mean", pow=None,
                        target_dirinv=None, thres=0.2)
             mask_mode_cfg = {**dft, **(mask_mode_cfg or {})}
-            if mask_mode_cfg["mask_eta"] != "fwd_mean" or mask_mode_cfg["target_dirinv"] is not None or mask_mode_cfg["pow"] is not None:
-                raise NotImplementedError("only the default eta-mask mode (fwd_mean + threshold) is built (SURVEY 8f-4)")
+            if mask_mode_cfg["mask_eta"] not in ("fwd_mean", "fwd", "gt") or mask_mode_cfg["target_dirinv"] is not None \
+                    or mask_mode_cfg["mask_dirinv"] is not None:
+                raise NotImplementedError("eta-mask sources built: fwd_mean (default), fwd, gt, each with thres / pow; the bwd_* maps of the "
+                                          "backward-pass controller and the dirinv masks are not (SURVEY 8f-4)")
         else:
             mask_mode_cfg = None
         self.mask_mode_cfg = mask_mode_cfg
@@ -36,12 +38,14 @@ class EtaInversion(DiffusionInversion):
             eta = (eta_start, eta_end)
         self.etas = eta_table(eta)
         self.attn_maps_forward = {}
+        self._step_mask = None
         self.noise_sample_count = noise_sample_count
         self.seed = seed if seed >= 0 else None
         self.L = model.engine.L
         self._loop = EtaLoop(model.engine, S=self.num_inference_steps, guidance_scale_bwd=self.guidance_scale_bwd,
                              guidance_scale_fwd=self.guidance_scale_fwd, eta=eta, noise_sample_count=noise_sample_count,
-                             use_mask=use_mask, mask_thres=(mask_mode_cfg or {}).get("thres", 0.2) or 0.0)
+                             use_mask=use_mask, mask_thres=(mask_mode_cfg or {}).get("thres", 0.2),
+                             mask_eta=(mask_mode_cfg or {}).get("mask_eta", "fwd_mean"), mask_pow=(mask_mode_cfg or {}).get("pow"))
 
     # ------------------------------------------------------------------ noise / mask
     def sample_variance_noise(self, n: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
@@ -52,8 +56,18 @@ class EtaInversion(DiffusionInversion):
     def get_mask(self, key, mask, t, edit_word_idx):
         if self.mask_mode_cfg is None or self.mask_mode_cfg[key] is None:
             return None
-        m = self.attn_maps_forward["mean"][edit_word_idx[0]]
-        return (m > self.mask_mode_cfg["thres"]).to(m.dtype)
+        mode = self.mask_mode_cfg[key]                                 # reference eta_inversion.py:159-205
+        if mode == "gt":
+            m = mask
+        elif mode == "fwd":
+            m = self.attn_maps_forward[int(t)][edit_word_idx[0]]
+        else:
+            m = self.attn_maps_forward["mean"][edit_word_idx[0]]
+        if self.mask_mode_cfg["thres"] is not None:
+            m = (m > self.mask_mode_cfg["thres"]).to(m.dtype)
+        if self.mask_mode_cfg["pow"] is not None:
+            m = torch.pow(m, self.mask_mode_cfg["pow"])
+        return m
 
     # ------------------------------------------------------------------ inversion
     def _word_tokens(self, prompt):
@@ -74,6 +88,9 @@ class EtaInversion(DiffusionInversion):
         self.attn_maps_forward = {}
         if res["maps_mean"] is not None:
             self.attn_maps_forward["mean"] = [res["maps_mean"][0, w][None] for w in range(res["maps_mean"].shape[1])]
+        if res.get("maps_steps") is not None:                              # keyed by timestep like the reference (:44-49)
+            for j, tt in enumerate(self._loop.t_fwd):
+                self.attn_maps_forward[int(tt)] = [res["maps_steps"][j, 0, w][None] for w in range(res["maps_steps"].shape[2])]
         return out
 
     # ------------------------------------------------------------------ backward
@@ -107,9 +124,15 @@ class EtaInversion(DiffusionInversion):
             ctx = context.reshape(2, 2, *context.shape[1:])            # [half][role]
             ctx_src, ctx_tgt = ctx[:, 0][None], ctx[:, 1][None]
             ew = torch.tensor([edit_word_idx[0]]) if self.mask_mode_cfg is not None else None
-            return self._loop.sample(inv_result["_native"], ctx_src, ctx_tgt, noise, edit_word=ew, ptp=ptp, masactrl=masa)
+            gt = None
+            if self.mask_mode_cfg is not None and self.mask_mode_cfg["mask_eta"] == "gt":
+                gt = inv_cfg["mask"]                                       # bilinear to the latent grid (eta_inversion.py:286-287)
+                gt = torch.nn.functional.interpolate(gt.float().reshape(1, 1, *gt.shape[-2:]), (L, L), mode="bilinear")[0]
+            return self._loop.sample(inv_result["_native"], ctx_src, ctx_tgt, noise, edit_word=ew, ptp=ptp, masactrl=masa, gt_mask=gt)
         # generic path: user-defined controllers keep their per-step callbacks
         mask = inv_cfg.get("mask", None)
+        if mask is not None:                                               # eta_inversion.py:286-287
+            mask = torch.nn.functional.interpolate(mask.float().reshape(1, 1, *mask.shape[-2:]), (L, L), mode="bilinear")[0].to(self.model.device)
         for i, t in enumerate(self.pbar(self.scheduler_bwd.timesteps, desc="backward")):
             latent, _ = self.predict_step_backward(latent, t, context, source_latent_prev=inv_result["latents"][-(i + 2)],
                                                    generator=generator, mask=mask, edit_word_idx=edit_word_idx)
@@ -121,6 +144,7 @@ class EtaInversion(DiffusionInversion):
         latent = self.controller.begin_step(latent=latent, t=t)
         assert latent.shape[0] == 2 and context.shape[0] == 4, "one (source, target) pair"
         eps_all = self.unet(torch.cat([latent] * 2), t, encoder_hidden_states=context)["sample"].float().contiguous()
+        self._step_mask = mask
         res = self.get_eta_variance_noise(source_latent_prev, latent, t, eps_all, generator, _fused=True, edit_word_idx=edit_word_idx)
         new_latent = self.controller.end_step(latent=res["latent"], noise_pred=res["noise_pred"], t=t)
         return new_latent, res["noise_pred"]
@@ -135,7 +159,7 @@ class EtaInversion(DiffusionInversion):
         p = t - sch.config.num_train_timesteps // S
         a_t, a_p, var = sch._alpha(t), sch._alpha(p), sch._get_variance(t, p)
         use_mask = self.mask_mode_cfg is not None
-        mask_map = self.attn_maps_forward["mean"][edit_word_idx[0]].float().contiguous() if use_mask else None
+        mask_map = self.get_mask("mask_eta", self._step_mask, t, edit_word_idx).float().reshape(1, L, L).contiguous() if use_mask else None
         x = latent.float().contiguous()
         out_x, out_eps = torch.empty_like(x), torch.empty_like(x)
         best = torch.zeros(1, dtype=torch.int32, device=x.device)
@@ -144,7 +168,7 @@ class EtaInversion(DiffusionInversion):
         _capi.check(_capi.load().etainv_eta_backward_step(
             _capi.ptr(x), _capi.ptr(noise_pred), float(self.guidance_scale_bwd), _capi.ptr(latent_prev.float().contiguous()),
             _capi.ptr(cand), self.noise_sample_count, float(self.etas[t]), _capi.ptr(mask_map),
-            float((self.mask_mode_cfg or {}).get("thres", 0.0) or 0.0), int(use_mask), a_t, a_p, var, 1, 4, L * L, _capi.ptr(out_x),
+            0.0, 2 if use_mask else 0, a_t, a_p, var, 1, 4, L * L, _capi.ptr(out_x),   # 2: get_mask already applied thres / pow
             _capi.ptr(out_eps), _capi.ptr(best), _capi.ptr(losses), _capi.ptr(scratch), _capi.F32, _capi.stream_ptr()))
         return {"eta": float(self.etas[t]), "variance_noise_candidates": cand, "best_idx": best, "losses": losses, "latent": out_x,
                 "noise_pred": out_eps, "latent_prev": latent_prev}

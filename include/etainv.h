@@ -66,7 +66,9 @@ int etainv_ddim_eta_step(const void* x, const void* eps, float eta, const void* 
  * eps_all  [4*n_img][chw]   UNet output rows [u_s.., u_t.., c_s.., c_t..]
  * x_prev_src [n_img][chw]   stored inversion latent latents[-(k+2)] (:291)
  * noise    [n_cand][chw]    candidates drawn by sample_variance_noise (:145-156), shared by all images
- * mask_map [n_img][hw]      forward-pass mean attention map of the source edit word (may be NULL if !use_mask)
+ * mask_map [n_img][hw]      forward-pass mean attention map of the source edit word (may be NULL if !use_mask);
+ *                            use_mask == 2: the map IS the per-pixel eta multiplier (non-default mask modes: no threshold,
+ *                            `pow`, ground-truth mask -- eta_inversion.py:164-201), mask_thres ignored
  * a_t, a_p, var             alphas_cumprod[t], alphas_cumprod[t-Delta] (or final), _get_variance(t, t-Delta)
  * out_x    [2*n_img][chw]   new latents;  out_eps [2*n_img][chw] guided noise (may be NULL)
  * best_idx [n_img] int32, losses [n_img][n_cand] float (device, may be NULL); scratch: >= n_img*16*64 floats */

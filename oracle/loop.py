@@ -79,7 +79,7 @@ class MasaCtrl:
 # --------------------------------------------------------------------------- the loops
 class EtaInversionOracle:
     def __init__(self, unet, S=50, guidance_scale_bwd=7.5, guidance_scale_fwd=1, eta=(0.0, 0.4),
-                 noise_sample_count=10, use_mask=True, thres=0.2, L=64, dtype=torch.float32):
+                 noise_sample_count=10, use_mask=True, thres=0.2, L=64, dtype=torch.float32, mask_eta="fwd_mean", mask_pow=None):
         self.unet, self.S, self.L, self.dtype = unet, S, L, dtype
         self.g_bwd, self.g_fwd = guidance_scale_bwd, guidance_scale_fwd
         self.ac = sch.alphas_cumprod()
@@ -87,6 +87,7 @@ class EtaInversionOracle:
         self.etas = sch.eta_table(eta)
         self.n = noise_sample_count
         self.use_mask, self.thres = use_mask, thres
+        self.mask_eta, self.mask_pow = mask_eta, mask_pow     # eta_inversion.py:164-201 (gt / fwd / fwd_mean; thres None; pow)
         self.attn_res = L // 4                  # 16 at L=64 (eta_inversion.py:90)
         self.thres_n = (L // 2) ** 2            # 32^2 at L=64 (ptp.py:153,226)
 
@@ -147,7 +148,11 @@ class EtaInversionOracle:
         eta, z, best, losses = self.eta_variance_noise(source_latent_prev, latent[:1], t, eps[:1], noise_choices)
         eta_map = torch.full_like(z, eta)
         if self.use_mask:
-            m = (mask_map > self.thres).to(mask_map.dtype)               # eta_inversion.py:196-198
+            m = mask_map
+            if self.thres is not None:
+                m = (m > self.thres).to(mask_map.dtype)                     # eta_inversion.py:196-198
+            if self.mask_pow is not None:
+                m = torch.pow(m, self.mask_pow)                               # eta_inversion.py:200-201
             eta_map = m * eta_map
             new = sch.ddim_eta_step(latent, eps, self.ac, int(t), self.S, eta_map, noise=z)
             new[:1] = new[:1] + (source_latent_prev[:1] - new[:1])       # eta_inversion.py:247-249
@@ -161,7 +166,7 @@ class EtaInversionOracle:
 
     # diffusion_inversion.py:493-528 + eta_inversion.py:275-294
     def sample(self, inv, ctx_src, ctx_tgt, noise_table, edit_word_idx=None, controller=None, masactrl=None,
-               trace=None):
+               trace=None, gt_mask=None):
         """noise_table: (S, n, 1, 4, L, L) -- the candidates `sample_variance_noise` would draw at each
         step from the per-image generator (eta_inversion.py:156,276), injected for reproducibility."""
         context = torch.stack([ctx_src, ctx_tgt], 1).reshape(4, *ctx_src.shape[1:])   # [u_s,u_t,c_s,c_t]
@@ -175,6 +180,10 @@ class EtaInversionOracle:
             self.unet.set_ctrl(masactrl)
         try:
             for i, t in enumerate(self.t_bwd):
+                if self.use_mask and self.mask_eta == "gt":
+                    mask_map = gt_mask                                        # already at latent resolution (eta_inversion.py:286-287)
+                elif self.use_mask and self.mask_eta == "fwd":
+                    mask_map = inv["attn_maps_per_t"][int(t)][edit_word_idx[0]]   # eta_inversion.py:168
                 latent, eps, best, losses = self.step_backward(
                     latent, t, context, inv["latents"][-(i + 2)], noise_table[i].to(latent.dtype), mask_map, controller)
                 if trace is not None:

@@ -16,8 +16,22 @@ ETA_CASES = {  # name: (eta spec, timestep, fp16?, use_mask)
 }
 
 
+ETA_MODE_CASES = {  # name: mask_mode_cfg overrides (eta_inversion.py:88-101,164-201); all at paper eta, t = 980, fp32
+    "gt_thres": dict(mask_eta="gt", thres=0.5),
+    "fwd_t": dict(mask_eta="fwd", thres=0.2),
+    "soft": dict(mask_eta="fwd_mean", thres=None),
+    "soft_pow": dict(mask_eta="fwd_mean", thres=None, pow=2.0),
+    "thres_pow": dict(mask_eta="fwd_mean", thres=0.3, pow=3.0),
+}
+
+
 def eta_case_inputs(name: str, L: int = 64):
-    fp16 = ETA_CASES[name][2]
+    if name in ETA_MODE_CASES:
+        return _eta_case_inputs("mode_" + name, False, L)
+    return _eta_case_inputs(name, ETA_CASES[name][2], L)
+
+
+def _eta_case_inputs(name: str, fp16: bool, L: int = 64):
     dt = torch.float16 if fp16 else torch.float32
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0xFFFF)
     latent = torch.randn(2, 4, L, L, generator=g).to(dt)

@@ -133,3 +133,33 @@ def test_edit_vs_oracle(setup, editor, L, dtype, use_mask, tol):
     assert e_inv < (5e-2 if bf else 5e-3) and e_map < (1e-1 if bf else 2e-2)
     assert e_src < (5e-2 if bf else 5e-3)          # source row replays the stored inversion trajectory (eta_inversion.py:247-249)
     assert e_tgt < tol
+
+
+@pytest.mark.parametrize("mode", [dict(mask_eta="fwd", thres=0.2), dict(mask_eta="fwd_mean", thres=None, pow=2.0), dict(mask_eta="gt", thres=0.5)])
+def test_mask_modes_vs_oracle(setup, mode):
+    """non-default eta-mask sources / shapes end to end (etainv + simple): per-timestep forward maps, soft mask with pow, given mask"""
+    from oracle import loop as oloop
+    from etainv.pipeline import EtaLoop
+    unet, get_engine = setup
+    L = 16
+    eng = get_engine(L, torch.float16)
+    pairs, z0, ctx_src, ctx_tgt = _inputs(L)
+    noise = oloop.noise_table(S, 10, L, seed=0)
+    gt = torch.rand(B, L, L, generator=torch.Generator().manual_seed(9))
+    ref = []
+    with torch.no_grad():
+        for i, (src, tgt) in enumerate(pairs):
+            o = oloop.EtaInversionOracle(unet, S=S, eta=(0.0, 0.4), L=L, use_mask=True, thres=mode.get("thres", 0.2), mask_eta=mode["mask_eta"],
+                                         mask_pow=mode.get("pow"))
+            inv = o.invert(z0[i:i + 1], ctx_src[i], src)
+            ref.append(o.sample(inv, ctx_src[i], ctx_tgt[i], noise, edit_word_idx=(1, 1), gt_mask=gt[i:i + 1]))
+    ref = torch.cat([torch.stack([r[0] for r in ref]), torch.stack([r[1] for r in ref])])
+    W = max(len(s.split(" ")) for s, _ in pairs)
+    tokens = torch.ones(B, W, dtype=torch.int32)
+    for i, (src, _) in enumerate(pairs):
+        ws = src.split(" ")
+        tokens[i, :len(ws)] = torch.tensor([ws.index(w) + 1 for w in ws], dtype=torch.int32)
+    loop = EtaLoop(eng, S=S, eta=(0.0, 0.4), use_mask=True, mask_thres=mode.get("thres", 0.2), mask_eta=mode["mask_eta"], mask_pow=mode.get("pow"))
+    inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
+    out = loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), noise.reshape(S, 10, 4, L, L).cuda(), edit_word=torch.tensor([1, 1]), gt_mask=gt)
+    assert relerr(out[:B].cpu(), ref[:B]) < 5e-3 and relerr(out[B:].cpu(), ref[B:]) < 3e-2

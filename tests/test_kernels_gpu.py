@@ -99,6 +99,27 @@ def test_eta_backward_step_vs_reference_golden(capi, golden, name):
     np.testing.assert_allclose(out_x.cpu().numpy(), g[f"{name}/new"], rtol=1e-4, atol=5e-5)
 
 
+@pytest.mark.parametrize("name", ["gt_thres", "fwd_t", "soft", "soft_pow", "thres_pow"])
+def test_eta_backward_step_mask_modes_vs_reference_golden(capi, golden, name):
+    """non-default eta-mask modes (reference get_mask, eta_inversion.py:159-205): the host prepares the per-pixel multiplier
+    (threshold and / or pow) and the kernel applies it as is (use_mask = 2)"""
+    from oracle import schedule as sch
+    from tests.golden import recipes
+    g = golden("eta_step_modes")
+    mode = recipes.ETA_MODE_CASES[name]
+    inp = recipes.eta_case_inputs(name)
+    assert [recipes.crc(inp[k]) for k in ("latent", "unet_out", "src_prev", "mask_map", "noise")] == list(g[f"{name}/crc"])
+    m = inp["mask_map"].float()
+    if mode.get("thres", 0.2) is not None:
+        m = (m > mode.get("thres", 0.2)).float()
+    if mode.get("pow") is not None:
+        m = torch.pow(m, mode["pow"])
+    eta = float(sch.eta_table([[0.6, 0], [1, 0.7]])[980])
+    out_x, _, _, _ = _eta_step(capi, inp["latent"].float().cuda(), inp["unet_out"].float().cuda(), 7.5, inp["src_prev"].float().cuda(),
+                               inp["noise"].float().reshape(10, 4, 64, 64).cuda(), eta, m.contiguous().cuda(), 2, sch.alphas_cumprod(), 980, 50, 1)
+    np.testing.assert_allclose(out_x.cpu().numpy(), g[f"{name}/new"], rtol=1e-4, atol=5e-5)
+
+
 def test_eta_backward_step_batched_images(capi):
     """n_img = 3 pairs in the [src.., tgt..] / [u_s.., u_t.., c_s.., c_t..] layout == three B=1 calls."""
     from oracle import schedule as sch

@@ -78,6 +78,26 @@ def test_eta_step_known_answers(golden, name):
     np.testing.assert_allclose(new.numpy(), g[f"{name}/new"], rtol=1e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("name", list(recipes.ETA_MODE_CASES))
+def test_eta_step_mask_modes(golden, name):
+    """non-default eta-mask modes (gt / fwd maps, no threshold, pow) vs the reference's get_mask + predict_step_backward"""
+    g = golden("eta_step_modes")
+    mode = recipes.ETA_MODE_CASES[name]
+    inp = recipes.eta_case_inputs(name)
+    assert [recipes.crc(inp[k]) for k in ("latent", "unet_out", "src_prev", "mask_map", "noise")] == list(g[f"{name}/crc"])
+
+    class U:
+        def __call__(self, x, t, encoder_hidden_states=None):
+            return {"sample": inp["unet_out"]}
+
+        def set_ctrl(self, c):
+            pass
+    o = oloop.EtaInversionOracle(U(), S=50, eta=[[0.6, 0], [1, 0.7]], use_mask=True, thres=mode.get("thres", 0.2), mask_eta=mode["mask_eta"],
+                                 mask_pow=mode.get("pow"))
+    new, eps, best, losses = o.step_backward(inp["latent"].clone(), 980, torch.zeros(4, 77, 8), inp["src_prev"], inp["noise"], inp["mask_map"], None)
+    np.testing.assert_allclose(new.numpy(), g[f"{name}/new"], rtol=1e-5, atol=2e-5)
+
+
 def test_ptp_tables(golden):
     g = golden("ptp_tables")
     pairs = json.load(open(f"{GOLDEN_DIR}/prompt_pairs.json"))
