@@ -184,7 +184,7 @@ def main():
     gn_ms, gn_bytes, gn_n = prof(3)
     ln_ms, ln_bytes, ln_n = prof(4)
     traffic = None          # fabric-side bytes per igemm launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    tfile = ROOT / "profiles" / "r01c_pmc_traffic_rows128.json"   # (tools/unet_call.py --rows 128, tools/pmc_traffic.py)
+    tfile = ROOT / "profiles" / "r01e_pmc_traffic_rows128.json"   # (tools/unet_call.py --rows 128, tools/pmc_traffic.py)
     if tfile.exists():
         traffic = json.load(open(tfile))["igemm"]["hbm_bytes_per_launch"]
     images = B * world * a.steps
