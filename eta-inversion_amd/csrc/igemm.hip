@@ -753,7 +753,7 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
   const bool big = p.geglu || (big_tiles >= 192 && p.N > 64);
   ETAINV_CHECK(!p.out_nchw || p.N == 4, "out_nchw needs N == 4");
   const int64_t huge_tiles = (int64_t)cdiv(p.M, 256) * cdiv(p.N, 160);
-  if (!p.geglu && p.N % 160 == 0 && huge_tiles >= 256 && !getenv("ETAINV_NO_RING")) {
+  if (!p.geglu && !p.ups && p.N % 160 == 0 && huge_tiles >= 256 && !getenv("ETAINV_NO_RING")) {   // (the ring's branch-free issue has no fused-upsample addressing)
     // experimental (opt-in): 256 x 160 x 64 tile, 8 waves, one resident block per CU (26 % fewer L2 -> LDS bytes per
     // FLOP).  Measured equal to 128 x 160 with two resident blocks (1026 vs 1033 TFLOP/s on conv 1280->1280 @16x16)
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3>(p, s)));

@@ -164,6 +164,68 @@ def test_gemm(capi, dtype, m, n, k):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,n,k,bias,res", [(16384, 960, 320, False, False), (16384, 320, 320, True, True), (65536, 320, 1280, True, True),
+                                            (32768, 640, 640, True, False), (16384 + 200, 1920, 640, True, True), (65536, 160, 64, True, False)])
+def test_gemm_persistent_ring(capi, dtype, m, n, k, bias, res):
+    """shapes large enough for the 256 x 160 ring kernel with several tiles per persistent block (the bench configuration):
+    tile switches, LDS-staged bias ring, wide stores, a ragged last M tile, nk = 1"""
+    lib = capi.load()
+    a, w = rnd(m, k, seed=1, dtype=dtype), rnd(n, k, seed=2, scale=k ** -0.5, dtype=dtype)
+    b_ = rnd(n, seed=3) if bias else None
+    r_ = rnd(m, n, seed=4, dtype=dtype) if res else None
+    out = torch.empty(m, n, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_gemm(capi.ptr(a), capi.ptr(w), capi.ptr(b_), capi.ptr(r_), capi.ptr(out), m, n, k, 0,
+                                  capi.dtype_code(dtype), capi.stream_ptr()))
+    ref = a.float() @ w.float().t()
+    if bias:
+        ref = ref + b_
+    if res:
+        ref = ref + r_.float()
+    assert relerr(out, ref) < TOL[dtype]
+    # per-tile check: the worst 256-row stripe must be as good as the average (a wrong tile hides in a global norm)
+    err = (out.float() - ref)[: m // 256 * 256].reshape(-1, 256, n).norm(dim=(1, 2)) / ref[: m // 256 * 256].reshape(-1, 256, n).norm(dim=(1, 2))
+    assert float(err.max()) < 2 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,c", [(16384, 320), (8192, 640)])
+def test_gemm_geglu_persistent_ring(capi, dtype, m, c):
+    lib = capi.load()
+    a, w = rnd(m, c, seed=1, dtype=dtype), rnd(8 * c, c, seed=2, scale=c ** -0.5, dtype=dtype)
+    bias = rnd(8 * c, seed=3)
+    out = torch.empty(m, 4 * c, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_gemm(capi.ptr(a), capi.ptr(pack_geglu(w.cpu()).cuda().contiguous()), capi.ptr(pack_geglu(bias.cpu()).cuda().contiguous()),
+                                  None, capi.ptr(out), m, 8 * c, c, 1, capi.dtype_code(dtype), capi.stream_ptr()))
+    h = a.float() @ w.float().t() + bias
+    ref = h[:, :4 * c] * F.gelu(h[:, 4 * c:])
+    assert relerr(out, ref) < TOL[dtype]
+    err = (out.float() - ref).reshape(-1, 256, 4 * c).norm(dim=(1, 2)) / ref.reshape(-1, 256, 4 * c).norm(dim=(1, 2))
+    assert float(err.max()) < 2 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_persistent_ring(capi, dtype):
+    """4 x 64 x 64 x 320 -> 320 (M = 16384, K = 2880, 128 tiles of 256 x 160) and 8 x 32 x 32 x 1280+640 -> 640"""
+    lib = capi.load()
+    for b, h, c1, c2, cout, ups, stride in ((8, 64, 320, 0, 320, 0, 1), (8, 32, 1280, 640, 640, 0, 1), (8, 32, 640, 0, 640, 1, 1),
+                                            (16, 64, 320, 0, 320, 0, 2)):   # + fused 2x upsample and stride 2 at bench-sized M
+        cin = c1 + c2
+        x = rnd(b, cin, h, h, seed=1, dtype=dtype)
+        w = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5, dtype=dtype)
+        bias, rowvec = rnd(cout, seed=3), rnd(b, cout, seed=5)
+        xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+        ref = F.conv2d(xin, w.float(), bias, stride=stride, padding=1) + rowvec[:, :, None, None]
+        ho = ref.shape[-1]
+        x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+        x1 = x_nhwc[..., :c1].contiguous()
+        x2 = x_nhwc[..., c1:].contiguous() if c2 else None
+        out = torch.empty(b, ho, ho, cout, dtype=dtype, device="cuda")
+        capi.check(lib.etainv_op_conv3x3(capi.ptr(x1), capi.ptr(x2), c1, c2, capi.ptr(w.permute(0, 2, 3, 1).contiguous()), capi.ptr(bias), capi.ptr(rowvec),
+                                         None, capi.ptr(out), b, h, h, cout, stride, ups, 9, capi.dtype_code(dtype), capi.stream_ptr()))
+        assert relerr(out.permute(0, 3, 1, 2), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_geglu(capi, dtype):
     lib = capi.load()
     m, c = 1024, 320

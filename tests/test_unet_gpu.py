@@ -62,3 +62,23 @@ def test_unet_forward_vs_oracle(engines, oracle_unet, dtype, tol, L, rows, t):
     err = relerr(out.cpu(), ref)
     print(f"L={L} rows={rows} t={t} {dtype}: rel L2 {err:.2e}, max abs {float((out.cpu() - ref).abs().max()):.2e}")
     assert err < tol
+
+
+def test_unet_bench_shape_class_vs_oracle(oracle_unet):
+    """L = 64 with 16 UNet rows: the tile dispatch of the bench configuration (256 x 160 / 256 x 128 persistent ring kernels,
+    several tiles per block, two-slot kernels for the fused-upsample convs), which small-L tests never reach.  The same sample in
+    every row, so one CPU-oracle forward checks all rows; rows must also agree bit for bit with each other."""
+    from etainv.engine import Engine
+    e = Engine(dtype=torch.float16, max_unet_batch=16, latent_size=64, max_img=4)
+    e.load_synthetic(0)
+    g = torch.Generator().manual_seed(1)
+    x1, c1 = torch.randn(1, 4, 64, 64, generator=g), torch.randn(1, 77, 768, generator=g)
+    with torch.no_grad():
+        ref = oracle_unet(x1, 500, encoder_hidden_states=c1)["sample"][0]
+    for rows in (1, 4, 16):
+        out = torch.empty(rows, 4, 64, 64, device="cuda")
+        e.unet(x1.repeat(rows, 1, 1, 1).cuda().contiguous(), 500, c1.repeat(rows, 1, 1).cuda().contiguous(), None, out=out)
+        torch.cuda.synchronize()
+        assert all(torch.equal(out[0], out[i]) for i in range(rows))
+        assert relerr(out[0].cpu(), ref) < 3e-3, rows
+    e.close()
