@@ -38,7 +38,7 @@ template <> struct Mfma<bf16> {
 
 constexpr int BK = 64;  // K elements per LDS tile (8 chunks of 16 B per row)
 
-template <typename T, int BM, int BN, int WAVES_M, int STAGES>
+template <typename T, int BM, int BN, int WAVES_M, int STAGES, bool UPS = false>
 __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) {
   constexpr int NTHR = WAVES_M * 128;      // WAVES_M x 2 waves
   constexpr int RP = NTHR / 8;             // LDS rows staged per pass (8 lanes x 16 B per 128-B row)
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
           const int iy = a_y[q] + t / 3, ix = a_x[q] + t % 3;
-          mask |= ((iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W)) << t;
+          mask |= ((iy >= 0) & (iy < Hin) & (ix >= 0) & (ix < Win)) << t;   // (Hin, Win: the fused-upsample grid when p.ups)
         }
         a_mask[q] = mask;   // (with pad0 the a_y / a_x origin is the output pixel itself)
       }
@@ -509,8 +509,15 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
 #pragma unroll
       for (int i = 0; i < A_LOADS; ++i) {
         const bool ok = (a_mask[i] >> it_tap) & 1;
-        const unsigned elem = (unsigned)((second ? a_e2[i] : a_e1[i]) + uoff);   // garbage for halo lanes, never dereferenced
-        const T* g = ok ? src + elem : zero_page;
+        const T* g;
+        if constexpr (UPS) {   // fused nearest-2x upsample: the tap lands on source pixel ((oy + ky - 1) >> 1, (ox + kx - 1) >> 1)
+          const int iy = (a_y[i] + it_ky) >> 1, ix = (a_x[i] + it_kx) >> 1;
+          const unsigned elem = (unsigned)(((a_b[i] * p.H + iy) * p.W + ix) * cs + (second ? it_c0 - p.c1 : it_c0) + lchunk * 8);
+          g = ok ? src + elem : zero_page;
+        } else {
+          const unsigned elem = (unsigned)((second ? a_e2[i] : a_e1[i]) + uoff);   // garbage for halo lanes, never dereferenced
+          g = ok ? src + elem : zero_page;
+        }
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(dA + (wrow0 + RP * i) * BK), 16, 0, 0);
       }
@@ -686,13 +693,13 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int STAGES = 2>
+template <typename T, int BM, int BN, int WAVES_M, int STAGES = 2, bool UPS = false>
 static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
   const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
   const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(T) + 4 * BN * sizeof(float) + (STAGES == 3 ? 1024 : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WAVES_M, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   // persistent grid: as many blocks as are resident at once (LDS-limited: 160 KiB / lds per CU, 256 CUs), a multiple of 8
@@ -706,7 +713,7 @@ static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
     (void)hipMemsetAsync(d_stamps, 0, 2048 * 8 * 8 * sizeof(uint64_t), s);
     ps.stamps = d_stamps;
   }
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES>), dim3(grid), dim3(WAVES_M * 128), lds, s, ps);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS>), dim3(grid), dim3(WAVES_M * 128), lds, s, ps);
   if (ps.stamps) {
     (void)hipStreamSynchronize(s);
     std::vector<uint64_t> h((size_t)grid * 8 * 8);
@@ -724,7 +731,7 @@ static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
   return 0;
 #endif
   ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s);
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES>), dim3(grid), dim3(WAVES_M * 128), lds, s, p);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS>), dim3(grid), dim3(WAVES_M * 128), lds, s, p);
   ETAINV_LAUNCH_CHECK();
   return 0;
 }
@@ -753,7 +760,10 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
   const bool big = p.geglu || (big_tiles >= 192 && p.N > 64);
   ETAINV_CHECK(!p.out_nchw || p.N == 4, "out_nchw needs N == 4");
   const int64_t huge_tiles = (int64_t)cdiv(p.M, 256) * cdiv(p.N, 160);
-  if (!p.geglu && !p.ups && p.N % 160 == 0 && huge_tiles >= 256 && !getenv("ETAINV_NO_RING")) {   // (the ring's branch-free issue has no fused-upsample addressing)
+  if (!p.geglu && p.ups && p.N % 160 == 0 && huge_tiles >= 256 && !getenv("ETAINV_NO_RING")) {
+    // the ring's issue is branch-free, so the fused-upsample addressing is its own instantiation
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, true>(p, s)));
+  } else if (!p.geglu && p.N % 160 == 0 && huge_tiles >= 256 && !getenv("ETAINV_NO_RING")) {
     // experimental (opt-in): 256 x 160 x 64 tile, 8 waves, one resident block per CU (26 % fewer L2 -> LDS bytes per
     // FLOP).  Measured equal to 128 x 160 with two resident blocks (1026 vs 1033 TFLOP/s on conv 1280->1280 @16x16)
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3>(p, s)));
