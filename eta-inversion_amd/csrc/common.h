@@ -67,27 +67,31 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // exact (erf) GELU; erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, ~14 instructions instead of libm erff's ~40:
 // the GEGLU epilogue evaluates it 32 times per lane per output tile)
-// x * Phi(x) for two values at once on the packed-fp32 pipe: Phi(x) ~ sigmoid(x (c1 + c3 x^2 + c5 x^4)), |x| clamped to 9 inside the
-// polynomial (minimax fit of the coefficients, tools/fit_gelu.py: |error| <= 2.6e-5 absolute on gelu, below half an fp16 ulp
-// for |gelu| > 0.05 and far below a bf16 ulp).  7 packed ops + 2 exp2 + 2 rcp per PAIR instead of 14 ops + exp2 + rcp per
-// value: the GEGLU epilogue of a K = 320 GEMM spent more VALU cycles in erf than the tile spends in the matrix pipe.
+// Exact (erf) GELU for two values at once on the packed-fp32 pipe: erf(|x|) = 1 - 2^(-p(|x|)), p = x (c1 + c2 x + ... + c7 x^6) fitted
+// to -log2(erfc) on [0, 4.3] (minimax, tools/fit_gelu.py: |erf error| <= 1.8e-7 in fp32, the accuracy of the A&S 7.1.26 form used
+// before) -- one transcendental instead of two and 7 packed FMAs per PAIR instead of 14 scalar ops per value: the GEGLU epilogue of a
+// K = 320 GEMM is VALU-bound on erf (16384 values per 256 x 128 tile against 5120 cycles of matrix work).
 typedef float gelu_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ gelu_f32x2 gelu_pair(gelu_f32x2 x) {
-  gelu_f32x2 xc;
-  xc[0] = __builtin_amdgcn_fmed3f(x[0], -9.0f, 9.0f);
-  xc[1] = __builtin_amdgcn_fmed3f(x[1], -9.0f, 9.0f);
-  const gelu_f32x2 x2 = xc * xc;
-  // coefficients pre-multiplied by -log2(e): t = -u * log2(e)
-  gelu_f32x2 p = x2 * 0.0010142652f + (-0.1067757382f);   // c5 = -0.0007030350676, c3 = 0.07401130191
-  p = p * x2 + (-2.3011213228f);                           // c1 = 1.595015757
-  const gelu_f32x2 t = p * xc;
-  gelu_f32x2 d;
-  d[0] = 1.0f + __builtin_amdgcn_exp2f(t[0]);
-  d[1] = 1.0f + __builtin_amdgcn_exp2f(t[1]);
-  gelu_f32x2 r;
-  r[0] = __builtin_amdgcn_rcpf(d[0]);
-  r[1] = __builtin_amdgcn_rcpf(d[1]);
-  return x * r;
+  gelu_f32x2 ax;
+  ax[0] = fminf(fabsf(x[0]) * 0.70710678118654752f, 4.3f);
+  ax[1] = fminf(fabsf(x[1]) * 0.70710678118654752f, 4.3f);
+  gelu_f32x2 p = ax * 0.000100211372f + (-0.000461519738f);          // coefficients negated: t = -p(ax)
+  p = p * ax + (-0.00230234699f);
+  p = p * ax + 0.0294526188f;
+  p = p * ax + (-0.148963716f);
+  p = p * ax + (-0.918328635f);
+  p = p * ax + (-1.62791373f);
+  const gelu_f32x2 t = p * ax;
+  gelu_f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(t[0]);
+  e[1] = __builtin_amdgcn_exp2f(t[1]);
+  const gelu_f32x2 er = 1.0f - e;
+  gelu_f32x2 s;
+  s[0] = copysignf(er[0], x[0]);
+  s[1] = copysignf(er[1], x[1]);
+  const gelu_f32x2 h = x * 0.5f;
+  return h * s + h;
 }
 __device__ __forceinline__ float gelu_erf_f(float x) {
   const float z = fabsf(x) * 0.70710678118654752f;

@@ -305,13 +305,13 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
             acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc[i][j + NT / 2] = (f32x4){0.f, 0.f, 0.f, 0.f};
             T o[4];
-            if (p.debug & 128) {   // experiment: sigmoid-polynomial GELU on the packed-fp32 pipe (2.6e-5 abs error, ~3 % faster GEGLU)
+            if (p.debug & 128) {   // A/B: scalar A&S 7.1.26 erf (exp2 + rcp per value)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(a[q] * gelu_erf_f(g[q]));
+            } else {
               const gelu_f32x2 g01 = gelu_pair((gelu_f32x2){g[0], g[1]}), g23 = gelu_pair((gelu_f32x2){g[2], g[3]});
               o[0] = from_f32<T>(a[0] * g01[0]); o[1] = from_f32<T>(a[1] * g01[1]);
               o[2] = from_f32<T>(a[2] * g23[0]); o[3] = from_f32<T>(a[3] * g23[1]);
-            } else {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(a[q] * gelu_erf_f(g[q]));
             }
             po[j] = *reinterpret_cast<u32x2*>(o);
           }

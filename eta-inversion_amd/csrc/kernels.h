@@ -20,7 +20,7 @@ struct IGemmParams {
   void* out = nullptr;              // [M][N]  (or [M][N/2] with geglu)
   const void* zeros = nullptr;      // filled in by launch_igemm
   // timing experiments only (ETAINV_IGEMM_DEBUG bit mask): 1 no DMA in the loop, 2 no epilogue, 4 no MFMA, 8 stores hit cache-resident
-  // rows, 16 no young-store vmcnt allowance, 32 8-byte stores (no lane swap), 64 epilogue without its stores, 128 sigmoid-polynomial GELU
+  // rows, 16 no young-store vmcnt allowance, 32 8-byte stores (no lane swap), 64 epilogue without its stores, 128 scalar A&S erf in GEGLU
   int debug = 0;
   unsigned long* stamps = nullptr;         // diagnostic build (-DETAINV_IGEMM_STAMPS) only
   int stagger = 0;                  // experiment (ETAINV_STAGGER): start delay of the second co-resident block, 64-cycle ticks
