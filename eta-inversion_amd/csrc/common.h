@@ -107,6 +107,7 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // Off by default: the launchers then do nothing extra.  work = algorithmic FLOPs (MFMA kernels) or bytes (HBM-bound).
 enum ProfClass { PROF_IGEMM = 0, PROF_SELF_ATTN = 1, PROF_CROSS_ATTN = 2, PROF_GROUPNORM = 3, PROF_LAYERNORM = 4, PROF_OTHER = 5, PROF_NCLASS = 6 };
 bool prof_enabled();
+void prof_pause(bool on);   // nested launchers: the outer scope times the whole operation
 void prof_begin(int cls, double work, hipStream_t s);
 void prof_end(hipStream_t s);
 struct ProfScope {

@@ -30,7 +30,9 @@ static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 static size_t g_prof_used = 0;
-bool prof_enabled() { return g_prof_on; }
+static bool g_prof_paused = false;
+bool prof_enabled() { return g_prof_on && !g_prof_paused; }
+void prof_pause(bool on) { g_prof_paused = on; }
 void prof_begin(int cls, double work, hipStream_t s) {
   if (g_prof_used == g_prof_pool.size()) {
     hipEvent_t a, b;

@@ -37,6 +37,7 @@ template <> struct Mfma<bf16> {
 };
 
 constexpr int BK = 64;  // K elements per LDS tile (8 chunks of 16 B per row)
+constexpr int64_t SPLITK_WS_BYTES = 64ll << 20;
 
 template <typename T, int BM, int BN, int WAVES_M, int STAGES, bool UPS = false>
 __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) {
@@ -66,20 +67,27 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   // K = 320 is only 5 K tiles -- otherwise pay a full memory latency + an unoverlapped epilogue per tile).
   // XCD-aware order: virtual ids v and v + 8 share an XCD (round-robin dispatch, G % 8 == 0), so each XCD walks a
   // contiguous run of tiles, n fastest: neighbours reuse the same activation panel from that XCD's L2.
+  // SPLIT-K (two-slot kernels only, small M*N with a deep K: the 8x8 / 16x16 levels at batch 1): every output tile becomes
+  // `ksplit` virtual tiles that each walk nk/ksplit K tiles and store an fp32 partial; a second kernel adds the partials in
+  // a fixed order and applies the epilogue (deterministic, no float atomics).
+  const int ksplit = (STAGES == 2 && p.ksplit > 1) ? p.ksplit : 1;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int total_tiles = ((p.M + BM - 1) / BM) * tiles_n;
+  const int total_tiles = ((p.M + BM - 1) / BM) * tiles_n * ksplit;
   const int G = gridDim.x;
   const int my_tiles = (total_tiles - (int)blockIdx.x + G - 1) / G;
-  auto tile_origin = [&](int i, int& m0, int& n0) {
+  auto tile_origin = [&](int i, int& m0, int& n0) -> int {   // returns the K part of virtual tile i
     int v = blockIdx.x + i * G;
     if ((total_tiles & 7) == 0) v = (v & 7) * (total_tiles >> 3) + (v >> 3);
+    const int part = ksplit > 1 ? v % ksplit : 0;
+    if (ksplit > 1) v /= ksplit;
     m0 = (v / tiles_n) * BM;
     n0 = (v - (v / tiles_n) * tiles_n) * BN;
+    return part;
   };
 
   const int cin = p.c1 + p.c2;
   const int kc = cin / BK;            // K tiles per tap
-  const int nk = p.taps * kc;
+  const int nk = p.taps * kc / ksplit;   // K tiles per (virtual) tile
   const int pad = (p.taps == 9 && !p.pad0) ? 1 : 0;
   const int HWo = p.Ho * p.Wo;
   const int Hin = p.ups ? p.H * 2 : p.H, Win = p.ups ? p.W * 2 : p.W;
@@ -92,11 +100,20 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   int a_e1[A_LOADS], a_e2[A_LOADS], a_mask[A_LOADS];
   const T* w_row[B_LOADS];
   int it_n0 = 0, it_bias_buf = 0;
+  // position of the K tile being issued, advanced incrementally (no integer division in the loop); it_k0 = first K tile of the part
+  int it_tap = 0, it_c0 = 0, it_ky = 0, it_kx = 0, it_k0 = 0;
   auto setup_issue = [&](int i) __attribute__((always_inline)) {   // geometry of the tile whose K tiles are being prefetched
     int m0, n0;
-    tile_origin(i, m0, n0);
+    const int part = tile_origin(i, m0, n0);
     it_n0 = n0;
     it_bias_buf = i & 3;
+    if (ksplit > 1) {
+      it_k0 = part * nk;
+      it_tap = it_k0 / kc;
+      it_c0 = (it_k0 - it_tap * kc) * BK;
+      it_ky = it_tap / 3;
+      it_kx = it_tap - it_ky * 3;
+    }
     if (p.taps == 1) {
       // 1x1 / Linear: the source row IS the output row -- no (image, y, x) decomposition, no halo mask (a K = 320 tile is
       // only five K steps long, so the ~500 VALU instructions of the general setup were ~20 % of its main loop)
@@ -141,8 +158,6 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   const T* zero_page = reinterpret_cast<const T*>(p.zeros);
   const int wrow0 = __builtin_amdgcn_readfirstlane(wid) * 8;   // first LDS row of this wave's 1-KiB DMA piece
 
-  // position of the K tile being issued, advanced incrementally (no integer division in the loop)
-  int it_tap = 0, it_c0 = 0, it_ky = 0, it_kx = 0;
   auto issue_tile = [&](int kt, int buf) __attribute__((always_inline)) {
     const int tap = it_tap, c0 = it_c0, ky = it_ky, kx = it_kx;
     const bool second = c0 >= p.c1;
@@ -177,7 +192,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i)
       if (BN % RP == 0 || wrow0 + RP * i < BN)   // wave-uniform: a wave stages 8 whole rows
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_row[i] + (int64_t)kt * BK),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_row[i] + (int64_t)(it_k0 + kt) * BK),
                                          (__attribute__((address_space(3))) void*)(dB + (wrow0 + RP * i) * BK), 16, 0, 0);
     if (kt == 0 && p.bias && wrow0 * 8 < BN) {   // waves 0 .. BN/64: 64 floats each (wrow0 = 8 * wave)
       const int c = wrow0 * 8 + lane;
@@ -224,6 +239,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   };
   // returns the store class of the tile: 0 = unknown number of store instructions (partial tile / slow path),
   // 1 = exactly MT*ceil(NT/2) per wave, 2 = exactly MT*ceil(NT/4) per wave (GEGLU) -- see the counted vmcnt waits of the ring
+  int ep_part = 0;   // K part of the tile in the epilogue (split-K)
   auto epilogue = [&](int m0, int n0, int tile) __attribute__((always_inline)) -> int {
     if (p.debug & 2) {   // ablation: no epilogue traffic
 #pragma unroll
@@ -239,7 +255,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     // store.  Loads and stores share vmcnt on gfx9 and may complete out of order with respect to each other, so a load issued
     // after a store makes hipcc wait vmcnt(0) = the L2 ack of that store: interleaved load/store groups serialise 20 store
     // round trips per tile (measured: ~10 us per 256 x 160 tile, 45 % of a K = 320 GEMM).
-    if (!p.out_nchw && !p.out_f32 && (p.rows_per_batch % WM) == 0) {
+    if (!p.out_nchw && !p.out_f32 && ksplit == 1 && (p.rows_per_batch % WM) == 0) {
       int mw = m0 + wm * WM;
       const int batch = (mw < p.M ? mw : p.M - 1) / p.rows_per_batch;   // one image per wave tile
       if (p.debug & 8) mw &= 255;   // ablation: all tiles store into the same cache-resident rows
@@ -339,7 +355,9 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
             const T* r = res + (int64_t)m * p.N + n;
             v[0] += to_f32(r[0]); v[1] += to_f32(r[1]); v[2] += to_f32(r[2]); v[3] += to_f32(r[3]);
           }
-          if (p.out_nchw) {   // conv_out: this lane holds the 4 output channels of pixel m
+          if (ksplit > 1) {   // fp32 partial of K part `ep_part` (bias / row vector / residual are applied by the reduction)
+            *reinterpret_cast<f32x4*>(p.ws + ((int64_t)ep_part * p.M + m) * p.N + n) = v;
+          } else if (p.out_nchw) {   // conv_out: this lane holds the 4 output channels of pixel m
             const int64_t base = ((int64_t)batch * p.out_nchw) * p.rows_per_batch + (m - batch * p.rows_per_batch);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -429,7 +447,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     int cls = 0;
     if (++ct_kt == nk) {
       int m0, n0;
-      tile_origin(ct_tile, m0, n0);
+      ep_part = tile_origin(ct_tile, m0, n0);
       cls = epilogue(m0, n0, ct_tile);
       ct_kt = 0;
       ++ct_tile;
@@ -695,7 +713,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
 
 template <typename T, int BM, int BN, int WAVES_M, int STAGES = 2, bool UPS = false>
 static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
-  const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
+  const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN) * (STAGES == 2 && p.ksplit > 1 ? p.ksplit : 1);   // virtual tiles with split-K
   const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(T) + 4 * BN * sizeof(float) + (STAGES == 3 ? 1024 : 0);
   static bool attr_set = false;
   if (!attr_set) {
@@ -734,6 +752,26 @@ static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS>), dim3(grid), dim3(WAVES_M * 128), lds, s, p);
   ETAINV_LAUNCH_CHECK();
   return 0;
+}
+
+// out[m][n] = sum over the K parts (fixed order) + bias + time-embedding row + residual: the epilogue of a split-K launch
+template <typename T>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p) {
+  const int n4 = p.N >> 2;
+  const int64_t total = (int64_t)p.M * n4;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int m = (int)(idx / n4), n = (int)(idx - (int64_t)m * n4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.ws + (int64_t)m * p.N + n);
+    for (int k = 1; k < p.ksplit; ++k) v += *reinterpret_cast<const f32x4*>(p.ws + ((int64_t)k * p.M + m) * p.N + n);
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)(m / p.rows_per_batch) * p.rowvec_stride + n);
+    if (p.residual) {
+      const T* r = reinterpret_cast<const T*>(p.residual) + (int64_t)m * p.N + n;
+      v[0] += to_f32(r[0]); v[1] += to_f32(r[1]); v[2] += to_f32(r[2]); v[3] += to_f32(r[3]);
+    }
+    T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+    *reinterpret_cast<u32x2*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.N + n) = *reinterpret_cast<u32x2*>(o);
+  }
 }
 
 int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
@@ -777,6 +815,41 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
   } else if (big) {
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 128, 128, 2>(p, s)));
   } else {
+    // small M*N: 64 x 64 tiles; when even those leave most CUs idle and K is deep, split K
+    const int64_t tiles = (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64);
+    const int nk = p.taps * (p.c1 + p.c2) / BK;
+    int ks = 1;
+    // (a two-slot block is bound by one memory latency per K tile -- 0.62 us -- whatever its tile: 80 blocks x 180 K tiles of a
+    //  1280 -> 1280 conv at 8 x 8 took 112 us for 29.5 MB of weights; 9 parts per tile: 29 us.  Fill the 1024 resident slots.)
+    if (!p.out_nchw && !p.out_f32 && tiles <= 512 && nk >= 16 && !getenv("ETAINV_NO_SPLITK")) {
+      static const int max_split = getenv("ETAINV_SPLITK_MAX") ? atoi(getenv("ETAINV_SPLITK_MAX")) : 32;
+      for (int d = 2; d <= max_split; ++d)
+        if (nk % d == 0 && nk / d >= 4 && tiles * d <= 1024 && (int64_t)p.M * p.N * d * 4 <= SPLITK_WS_BYTES) ks = d;
+    }
+    if (ks > 1) {
+      static float* ws = nullptr;   // one-time 64 MiB workspace (the largest split problem is M*N < 192 * 4096 elements x 32 parts)
+      if (!ws) ETAINV_HIP(hipMalloc(&ws, SPLITK_WS_BYTES));
+      IGemmParams pk = p;
+      pk.ksplit = ks;
+      pk.ws = ws;
+      pk.bias = nullptr;
+      pk.rowvec = nullptr;
+      pk.residual = nullptr;
+      IGemmParams pr = p;
+      pr.ksplit = ks;
+      pr.ws = ws;
+      ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s);
+      ETAINV_DISPATCH_HALF(dtype, T, {
+        prof_pause(true);
+        const int rc = launch_igemm_t<T, 64, 64, 2>(pk, s);
+        prof_pause(false);
+        if (rc) return rc;
+        const int64_t total = (int64_t)p.M * (p.N >> 2);
+        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 2048)), dim3(256), 0, s, pr);
+      });
+      ETAINV_LAUNCH_CHECK();
+      return 0;
+    }
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 64, 64, 2>(p, s)));
   }
   return 0;

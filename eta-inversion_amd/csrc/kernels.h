@@ -30,6 +30,8 @@ struct IGemmParams {
   int Ho = 1, Wo = 1;         // output spatial dims
   int stride = 1, ups = 0, taps = 1;
   int geglu = 0;
+  int ksplit = 1;             // split-K parts (filled in by launch_igemm for small M*N with deep K)
+  float* ws = nullptr;        // [ksplit][M][N] fp32 partials
   int rows_per_batch = 1;     // Ho*Wo for convs; M/batch for linears
 };
 int launch_igemm(const IGemmParams& p, int dtype, hipStream_t s);

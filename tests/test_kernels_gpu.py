@@ -226,6 +226,36 @@ def test_conv3x3_persistent_ring(capi, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_split_k_small_m_deep_k(capi, dtype):
+    """batch-1 shapes of the 8x8 / 16x16 levels (M = 64 .. 256, K = 11520 / 23040): split-K partials + fixed-order reduction with
+    the fused bias / time-embedding row / residual epilogue; a plain GEMM with M = 64, K = 5120 as well"""
+    lib = capi.load()
+    for b, h, c1, c2, cout in ((1, 8, 1280, 0, 1280), (4, 8, 1280, 1280, 1280), (1, 16, 1280, 0, 1280)):
+        cin = c1 + c2
+        x = rnd(b, cin, h, h, seed=1, dtype=dtype)
+        w = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5, dtype=dtype)
+        bias, rowvec = rnd(cout, seed=3), rnd(b, cout, seed=5)
+        res = rnd(b, h, h, cout, seed=6, dtype=dtype)
+        ref = F.conv2d(x.float(), w.float(), bias, padding=1) + rowvec[:, :, None, None] + res.float().permute(0, 3, 1, 2)
+        x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+        x1 = x_nhwc[..., :c1].contiguous()
+        x2 = x_nhwc[..., c1:].contiguous() if c2 else None
+        out = torch.empty(b, h, h, cout, dtype=dtype, device="cuda")
+        capi.check(lib.etainv_op_conv3x3(capi.ptr(x1), capi.ptr(x2), c1, c2, capi.ptr(w.permute(0, 2, 3, 1).contiguous()), capi.ptr(bias), capi.ptr(rowvec),
+                                         capi.ptr(res), capi.ptr(out), b, h, h, cout, 1, 0, 9, capi.dtype_code(dtype), capi.stream_ptr()))
+        assert relerr(out.permute(0, 3, 1, 2), ref) < TOL[dtype]
+    m, n, k = 64, 1280, 5120
+    a, w = rnd(m, k, seed=1, dtype=dtype), rnd(n, k, seed=2, scale=k ** -0.5, dtype=dtype)
+    bias, res = rnd(n, seed=3), rnd(m, n, seed=4, dtype=dtype)
+    out = torch.empty(m, n, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_gemm(capi.ptr(a), capi.ptr(w), capi.ptr(bias), capi.ptr(res), capi.ptr(out), m, n, k, 0, capi.dtype_code(dtype), capi.stream_ptr()))
+    assert relerr(out, a.float() @ w.float().t() + bias + res.float()) < TOL[dtype]
+    out2 = torch.empty_like(out)
+    capi.check(lib.etainv_op_gemm(capi.ptr(a), capi.ptr(w), capi.ptr(bias), capi.ptr(res), capi.ptr(out2), m, n, k, 0, capi.dtype_code(dtype), capi.stream_ptr()))
+    assert torch.equal(out, out2)      # deterministic
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_geglu(capi, dtype):
     lib = capi.load()
     m, c = 1024, 320
