@@ -808,49 +808,49 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
   } else if (p.geglu && p.c1 >= (getenv("ETAINV_GEGLU_RING_MINK") ? atoi(getenv("ETAINV_GEGLU_RING_MINK")) : 320) && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 128) >= 256 && !getenv("ETAINV_NO_RING")) {
     // (since the interleaved windows the ring also wins at K = 320: 1.42 vs 1.55 ms for ff1 320 -> 2560 at 64 x 64 x 128 rows)
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 128, 4, 3>(p, s)));
-  } else if (big && !p.geglu && p.N % 160 == 0) {
-    // every channel count of SD1.x is a multiple of 320: 160-wide tiles leave no padded columns (N = 320 would waste
-    // 17 % of a 3 x 128 tiling) and a 64 x 80 wave tile does 20 MFMAs per 9 fragment reads
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 128, 160, 2>(p, s)));
-  } else if (big) {
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 128, 128, 2>(p, s)));
   } else {
-    // small M*N: 64 x 64 tiles; when even those leave most CUs idle and K is deep, split K
-    const int64_t tiles = (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64);
+    // two-slot kernels: 128 x 160 (every channel count of SD1.x is a multiple of 320: no padded columns, 20 MFMAs per 9 fragment
+    // reads), 128 x 128 (GEGLU / other widths), 64 x 64 for small M*N.  A two-slot block is bound by one memory latency per K tile
+    // (0.62 us) whatever its tile -- 80 blocks x 180 K tiles of a 1280 -> 1280 conv at 8 x 8 took 112 us for 29.5 MB of weights --
+    // so a problem that leaves resident slots empty and has a deep K is SPLIT along K (9 parts: 29 us): fp32 partials, then a
+    // fixed-order reduction that applies the epilogue.
+    const int cfg = (big && !p.geglu && p.N % 160 == 0) ? 0 : big ? 1 : 2;
+    const int bm = cfg == 2 ? 64 : 128, bn = cfg == 0 ? 160 : cfg == 1 ? 128 : 64;
+    const int slots = cfg == 2 ? 1024 : 512;                       // resident blocks: 4 (64 x 64) or 2 per CU
+    const int64_t tiles = (int64_t)cdiv(p.M, bm) * cdiv(p.N, bn);
     const int nk = p.taps * (p.c1 + p.c2) / BK;
     int ks = 1;
-    // (a two-slot block is bound by one memory latency per K tile -- 0.62 us -- whatever its tile: 80 blocks x 180 K tiles of a
-    //  1280 -> 1280 conv at 8 x 8 took 112 us for 29.5 MB of weights; 9 parts per tile: 29 us.  Fill the 1024 resident slots.)
-    if (!p.out_nchw && !p.out_f32 && tiles <= 512 && nk >= 16 && !getenv("ETAINV_NO_SPLITK")) {
+    if (!p.geglu && !p.out_nchw && !p.out_f32 && tiles * 2 <= slots && nk >= 16 && !getenv("ETAINV_NO_SPLITK")) {
       static const int max_split = getenv("ETAINV_SPLITK_MAX") ? atoi(getenv("ETAINV_SPLITK_MAX")) : 32;
       for (int d = 2; d <= max_split; ++d)
-        if (nk % d == 0 && nk / d >= 4 && tiles * d <= 1024 && (int64_t)p.M * p.N * d * 4 <= SPLITK_WS_BYTES) ks = d;
+        if (nk % d == 0 && nk / d >= 4 && tiles * d <= slots && (int64_t)p.M * p.N * d * 4 <= SPLITK_WS_BYTES) ks = d;
     }
+    IGemmParams pk = p;
     if (ks > 1) {
-      static float* ws = nullptr;   // one-time 64 MiB workspace (the largest split problem is M*N < 192 * 4096 elements x 32 parts)
+      static float* ws = nullptr;   // one-time 64 MiB workspace
       if (!ws) ETAINV_HIP(hipMalloc(&ws, SPLITK_WS_BYTES));
-      IGemmParams pk = p;
       pk.ksplit = ks;
       pk.ws = ws;
       pk.bias = nullptr;
       pk.rowvec = nullptr;
       pk.residual = nullptr;
+    }
+    ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s);
+    prof_pause(true);
+    int rc = 0;
+    ETAINV_DISPATCH_HALF(dtype, T, rc = cfg == 0 ? launch_igemm_t<T, 128, 160, 2>(pk, s) : cfg == 1 ? launch_igemm_t<T, 128, 128, 2>(pk, s)
+                                                                                                   : launch_igemm_t<T, 64, 64, 2>(pk, s));
+    prof_pause(false);
+    if (rc) return rc;
+    if (ks > 1) {
       IGemmParams pr = p;
       pr.ksplit = ks;
-      pr.ws = ws;
-      ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s);
-      ETAINV_DISPATCH_HALF(dtype, T, {
-        prof_pause(true);
-        const int rc = launch_igemm_t<T, 64, 64, 2>(pk, s);
-        prof_pause(false);
-        if (rc) return rc;
-        const int64_t total = (int64_t)p.M * (p.N >> 2);
-        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 2048)), dim3(256), 0, s, pr);
-      });
+      pr.ws = pk.ws;
+      const int64_t total = (int64_t)p.M * (p.N >> 2);
+      ETAINV_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 2048)),
+                                                        dim3(256), 0, s, pr));
       ETAINV_LAUNCH_CHECK();
-      return 0;
     }
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 64, 64, 2>(p, s)));
   }
   return 0;
 }
