@@ -2,7 +2,7 @@
 // 61 GroupNorms + 48 LayerNorms per UNet forward).  16-byte vector loads, wave64 shuffle reductions,
 // fixed-order partial sums (bitwise reproducible, no float atomics).
 //
-// GroupNorm runs as stats -> finalize -> apply.  The stats/apply kernels read up to two source tensors so
+// GroupNorm runs as stats -> apply (the apply blocks reduce the per-chunk partial sums themselves).  The stats/apply kernels read up to two source tensors so
 // the decoder's torch.cat([x, skip], dim=1) is consumed in place; `apply` writes the concatenated,
 // normalised (and SiLU'd) tensor that feeds the following 3x3 convolution.
 #include "common.h"
@@ -86,38 +86,46 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x1,
   }
 }
 
-// grid B, block 64: (mean, rstd) per (b, group); partial -> stats [B][groups][2] placed after the partials
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int chunks, int groups, float count, float eps,
-                                   float* __restrict__ stats) {
-  const int b = blockIdx.x, g = threadIdx.x;
-  if (g >= groups) return;
-  double a = 0.0, c = 0.0;
-  for (int k = 0; k < chunks; ++k) {
-    const float* p = partial + (((int64_t)b * chunks + k) * groups + g) * 2;
-    a += p[0];
-    c += p[1];
-  }
-  double mean = a / count;
-  double var = c / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  stats[(b * groups + g) * 2 + 0] = (float)mean;
-  stats[(b * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-}
-
 // grid (chunks, B), 4 waves; same pixel / vector ownership as gn_stats_kernel, so the per-channel scale and shift
 // (rstd*gamma, beta - mean*rstd*gamma) are computed once per lane and reused for every pixel: no integer
 // division and 2 FMAs per element in the streaming loop.
 template <typename T>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x1, const T* __restrict__ x2, int c1, int c2, int hw,
-                                                       int groups, const float* __restrict__ stats,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int groups, const float* __restrict__ partial, int chunks_st, float count,
+                                                       float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int silu, T* __restrict__ out) {
   const int C = c1 + c2, nvec = C >> 3, nv1 = c1 >> 3, cpg = C / groups;
   const int b = blockIdx.y, chunks = gridDim.x;
   const int per = (hw + chunks - 1) / chunks;
   const int beg = blockIdx.x * per, end = min(hw, beg + per);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const float* st = stats + (int64_t)b * groups * 2;
+  // (mean, rstd) of this image's groups from the per-chunk partial sums, in a fixed order (no separate finalize launch: at
+  // batch 1 that 64-thread kernel was a 12 us chain of dependent loads, 8.5 % of the run)
+  __shared__ double s_red[4][64][2];
+  __shared__ float st[64 * 2];
+  {
+    double a = 0.0, c = 0.0;
+    if (lane < groups)
+      for (int k = wid; k < chunks_st; k += 4) {
+        const float* p = partial + (((int64_t)b * chunks_st + k) * groups + lane) * 2;
+        a += p[0];
+        c += p[1];
+      }
+    s_red[wid][lane][0] = a;
+    s_red[wid][lane][1] = c;
+    __syncthreads();
+    if (threadIdx.x < groups) {
+      const int g = threadIdx.x;
+      const double sa = ((s_red[0][g][0] + s_red[1][g][0]) + s_red[2][g][0]) + s_red[3][g][0];
+      const double sq = ((s_red[0][g][1] + s_red[1][g][1]) + s_red[2][g][1]) + s_red[3][g][1];
+      const double mean = sa / count;
+      double var = sq / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      st[g * 2 + 0] = (float)mean;
+      st[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+  }
   float sc[GN_MAX_VEC_PER_LANE][8], sh[GN_MAX_VEC_PER_LANE][8];
 #pragma unroll
   for (int i = 0; i < GN_MAX_VEC_PER_LANE; ++i) {
@@ -206,7 +214,6 @@ int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float
   ETAINV_CHECK(c2 == 0 || x2, "second source missing");
   int chunks = std::min(GN_MAX_CHUNKS, std::max(1, std::min(hw / 8, 1024 / std::max(1, b))));
   float* partial = scratch;
-  float* stats = scratch + (int64_t)b * GN_MAX_CHUNKS * groups * 2;
   const size_t lds = (size_t)4 * C * 2 * sizeof(float);
   // the apply pass has no cross-block reduction: use more, smaller chunks to fill the chip
   const int chunks_apply = std::max(1, std::min(hw / 4, std::max(chunks, 4096 / std::max(1, b))));
@@ -219,9 +226,8 @@ int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float
         attr = true;
       }
       hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks, b), dim3(256), lds, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups, partial);
-      hipLaunchKernelGGL(gn_finalize_kernel, dim3(b), dim3(64), 0, s, partial, chunks, groups, (float)hw * (float)(C / groups), eps, stats);
-      hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(chunks_apply, b), dim3(256), 0, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups, stats,
-                         gamma, beta, silu, (T*)out));
+      hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(chunks_apply, b), dim3(256), 0, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups, partial,
+                         chunks, (float)hw * (float)(C / groups), eps, gamma, beta, silu, (T*)out));
   ETAINV_LAUNCH_CHECK();
   return 0;
 }
