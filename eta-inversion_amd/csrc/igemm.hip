@@ -605,6 +605,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     int young_cls = 0, young_steps = 0;   // stores of the last epilogue that later waits may leave in flight
 #ifdef ETAINV_IGEMM_STAMPS
     uint64_t st_w1 = 0, st_wait = 0, st_bar = 0, st_w2 = 0, st_end = 0;   // diagnostic build only: s_memtime per step segment
+    const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();   // in-kernel clock = d(memtime)/d(memrealtime) x 100 MHz
 #endif
     auto step = [&](int sidx, auto has_next_tag, auto has_issue_tag, auto has_pb_tag) __attribute__((always_inline)) {
       constexpr bool HAS_NEXT = decltype(has_next_tag)::value, HAS_ISSUE = decltype(has_issue_tag)::value;
@@ -704,6 +705,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     if (p.stamps && lane == 0) {
       uint64_t* o = p.stamps + ((size_t)blockIdx.x * 8 + wid) * 8;
       o[0] = st_w1; o[1] = st_wait; o[2] = st_bar; o[3] = st_w2; o[4] = st_end; o[5] = (uint64_t)total_steps;
+      o[6] = __builtin_amdgcn_s_memtime() - clk0; o[7] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
 #endif
 #undef ETAINV_VMCNT
@@ -736,14 +738,17 @@ static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
     (void)hipStreamSynchronize(s);
     std::vector<uint64_t> h((size_t)grid * 8 * 8);
     (void)hipMemcpy(h.data(), d_stamps, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
-    double sum[5] = {0, 0, 0, 0, 0}, steps = 0;
+    double sum[5] = {0, 0, 0, 0, 0}, steps = 0, ck = 0, rt = 0;
     for (int b = 0; b < grid; ++b)
       for (int w = 0; w < 8; ++w) {
         const uint64_t* o = &h[((size_t)b * 8 + w) * 8];
         for (int k = 0; k < 5; ++k) sum[k] += (double)o[k];
         steps += (double)o[5];
+        ck += (double)o[6];
+        rt += (double)o[7];
       }
-    fprintf(stderr, "[igemm stamps %dx%d M=%d N=%d K=%d] s_memtime ticks (100 MHz) per step and wave: w1 %.2f wait %.2f barrier %.2f w2 %.2f end %.2f\n", BM, BN,
+    fprintf(stderr, "[igemm stamps] in-kernel clock %.3f GHz (s_memtime / s_memrealtime x 100 MHz, mean over waves)\n", rt > 0 ? ck / rt * 0.1 : 0.0);
+    fprintf(stderr, "[igemm stamps %dx%d M=%d N=%d K=%d] s_memtime ticks (core clocks) per step and wave: w1 %.2f wait %.2f barrier %.2f w2 %.2f end %.2f\n", BM, BN,
             p.M, p.N, p.taps * (p.c1 + p.c2), sum[0] / steps, sum[1] / steps, sum[2] / steps, sum[3] / steps, sum[4] / steps);
   }
   return 0;
