@@ -507,12 +507,16 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         fb[j] = *reinterpret_cast<const u32x4*>(tB + row * BK + (((kk * 4 + fq) ^ (row & 7)) << 3));
       }
     };
+    auto mfma_range = [&](u32x4 (&fa)[MT], u32x4 (&fb)[NT], auto lo_tag, auto hi_tag) __attribute__((always_inline)) {
+      constexpr int LO = decltype(lo_tag)::value, HI = decltype(hi_tag)::value;   // MFMAs LO .. HI-1 of the cluster (row-major i, j)
+#pragma unroll
+      for (int idx = LO; idx < HI; ++idx) {
+        const int i = idx / NT, j = idx % NT;
+        acc[i][j] = Mfma<T>::run(__builtin_bit_cast(frag, fb[j]), __builtin_bit_cast(frag, fa[i]), acc[i][j]);
+      }
+    };
     auto mfma_all = [&](u32x4 (&fa)[MT], u32x4 (&fb)[NT]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = Mfma<T>::run(__builtin_bit_cast(frag, fb[j]), __builtin_bit_cast(frag, fa[i]), acc[i][j]);
+      mfma_range(fa, fb, std::integral_constant<int, 0>{}, std::integral_constant<int, MT * NT>{});
     };
     // Branch-free issue of the K tile at the issue position into ring slot `buf`, in two parts: the activation pieces go out in
     // window 2 of step s, the weight pieces in window 1 of step s+1.  The CU's vector-memory path moves 64 B/clk, i.e. 16 clocks
@@ -615,10 +619,19 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
 #ifdef ETAINV_IGEMM_STAMPS
       const uint64_t t0 = __builtin_amdgcn_s_memtime();
 #endif
-      // ---- window 1
+      // ---- window 1a: the first NA MFMAs on F0 carry the F1 reads and the weight pieces.  The rendezvous comes right after them,
+      // NOT at the end of the cluster: it only needs this wave's F1 reads (slot s free) and its DMA of step s+1 (slot s+1 landed),
+      // neither depends on the MFMAs -- so the remaining MFMAs on F0 run after the barrier, fused with window 2 into one
+      // straight-line block, and a wave waiting at the barrier leaves the matrix pipe to its SIMD partner instead of both draining it
+      // (stamps: counted waits + barrier were ~540 of ~2200 cycles per K step with the rendezvous between the clusters).
+#ifndef ETAINV_RING_EARLY_SYNC
+#define ETAINV_RING_EARLY_SYNC 1
+#endif
+      constexpr int NA = (!HAS_NEXT || !ETAINV_RING_EARLY_SYNC) ? MT * NT
+                         : ((MT + NT) + (HAS_PB ? B_PASSES : 0) + 2 < MT * NT ? (MT + NT) + (HAS_PB ? B_PASSES : 0) + 2 : MT * NT);
       read_frags(slot, 1, fa1, fb1);
       if constexpr (HAS_PB) issue_b(pslot);
-      mfma_all(fa0, fb0);
+      mfma_range(fa0, fb0, std::integral_constant<int, 0>{}, std::integral_constant<int, NA>{});
 #pragma unroll
       for (int q = 0; q < MT + NT; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
@@ -631,8 +644,8 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
           __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // 1 DMA piece
         }
       }
-      if constexpr (MT * NT - (MT + NT) - (HAS_PB ? B_PASSES : 0) > 0)
-        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT) - (HAS_PB ? B_PASSES : 0), 0);
+      if constexpr (NA - (MT + NT) - (HAS_PB ? B_PASSES : 0) > 0)
+        __builtin_amdgcn_sched_group_barrier(0x008, NA - (MT + NT) - (HAS_PB ? B_PASSES : 0), 0);
       __builtin_amdgcn_sched_barrier(0);
 #ifdef ETAINV_IGEMM_STAMPS
       const uint64_t t1 = __builtin_amdgcn_s_memtime();
@@ -656,12 +669,15 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         t3 = __builtin_amdgcn_s_memtime();
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        // ---- window 2
+        // ---- window 1b + 2: the rest of the F0 cluster, then the F1 cluster with the F0 reads of the next step and the
+        // activation pieces of step s+3
+        mfma_range(fa0, fb0, std::integral_constant<int, NA>{}, std::integral_constant<int, MT * NT>{});
         read_frags(nslot, 0, fa0, fb0);
         if constexpr (HAS_ISSUE) issue_a(slot);
       }
       mfma_all(fa1, fb1);
       if constexpr (HAS_NEXT) {
+        if constexpr (MT * NT - NA > 0) __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - NA, 0);
 #pragma unroll
         for (int q = 0; q < MT + NT; ++q) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
