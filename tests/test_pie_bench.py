@@ -39,3 +39,48 @@ def test_limit_and_categories(tmp_path):
     assert len(PieBenchData(str(tmp_path), skip_img_load=True, limit=2)) == 2
     assert len(list(PieBenchData(str(tmp_path), skip_img_load=True, limit=3))) == 3
     assert list(PieBenchData.categories["9_change_style"]) == list(range(620, 700))
+
+
+def test_eval_driver_host_logic(tmp_path, monkeypatch):
+    """eval.py without a GPU: rank sharding, output naming, None results skipped, skip-existing resume -- engine and editor
+    replaced by fakes (the real ones are exercised by tests/test_batch_gpu.py)."""
+    import sys
+    import torch
+    from PIL import Image
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "eta-inversion_amd"))
+    import eval as pie_eval
+    g = json.loads((GOLD / "pie_bench.json").read_text())
+    root = tmp_path / "pie"
+    (root / "annotation_images" / "0_random_140").mkdir(parents=True)
+    (root / "mapping_file.json").write_text(json.dumps(g["mapping"]))
+    for rec in g["records"]:
+        Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(str(root / rec["image_rel"]))
+    calls = []
+
+    class FakePipe:
+        device = "cpu"
+
+    class FakeEditor:
+        def __init__(self, pipe, num_inference_steps=50, edit_method="ptp"):
+            pass
+
+        def edit(self, samples):
+            calls.append([s["source_prompt"] for s in samples])
+            return [None if s["edit_word_idx"] is None or None in s["edit_word_idx"] else
+                    {"image": torch.zeros(1, 3, 16, 16), "latent": torch.zeros(1, 4, 2, 2)} for s in samples]
+    monkeypatch.setattr(pie_eval, "load_diffusion_model",
+                        lambda *a, **k: (FakePipe(), (lambda f: torch.zeros(1, 3, 16, 16), lambda img: np.zeros((16, 16, 3), np.uint8))))
+    monkeypatch.setattr(pie_eval, "BatchEditor", FakeEditor)
+    out = tmp_path / "res"
+    argv = ["--data_path", str(root), "--output", str(out), "--batch", "2", "--steps", "2", "--size", "16"]
+    for rank in (0, 1):                                   # two ranks, run one after the other (no collective without --save_latents)
+        monkeypatch.setenv("RANK", str(rank))
+        monkeypatch.setenv("WORLD_SIZE", "1")             # keep torch.distributed out of the CPU test; sharding is shard_indices' job
+        pie_eval.main(argv)
+    names = sorted(f.name for f in (out / "imgs").glob("*.png"))
+    want = sorted(f"{i:04d}_{r['source_prompt']}_{r['target_prompt']}.png" for i, r in enumerate(g["records"]) if None not in r["edit_word_idx"])
+    assert names == want
+    assert all(len(c) <= 2 for c in calls)                # batches of at most --batch samples
+    n_calls = len(calls)
+    pie_eval.main(argv)                                   # resume: only the samples without an output (the None ones) are retried
+    assert sum(len(c) for c in calls[n_calls:]) == len(g["records"]) - len(want)
