@@ -89,6 +89,9 @@ typedef struct etainv_engine_config {
   int reserved[4];
 } etainv_engine_config;
 
+/* Memory: weights + one activation workspace are allocated here and freed by etainv_engine_destroy; calls never allocate,
+ * except two process-wide one-time buffers of the GEMM launcher (a 256-byte zero page for the 3x3 halo and a 64 MiB split-K
+ * workspace, created by the first launch that needs them).  One engine per device and process; not thread-safe. */
 int etainv_engine_create(const etainv_engine_config* cfg, etainv_engine_t** out);
 int etainv_engine_destroy(etainv_engine_t* e);
 
