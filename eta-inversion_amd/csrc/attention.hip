@@ -50,7 +50,10 @@ constexpr float NEG_BIG = -1.0e30f;
 #ifndef ETAINV_QT40
 #define ETAINV_QT40 4
 #endif
-constexpr int SELF_QT(int d) { return d == 40 ? ETAINV_QT40 : 2; }
+#ifndef ETAINV_QT80
+#define ETAINV_QT80 2
+#endif
+constexpr int SELF_QT(int d) { return d == 40 ? ETAINV_QT40 : d == 80 ? ETAINV_QT80 : 2; }
 
 // batch-row roles for the backward layout [u_s x B, u_t x B, c_s x B, c_t x B]
 __device__ __forceinline__ void row_roles(int b, int n_img, int& half, int& role, int& img) {
