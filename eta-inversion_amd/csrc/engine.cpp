@@ -696,6 +696,13 @@ extern "C" int etainv_maps_word_maps(etainv_engine_t* e, int n_img, const int32_
                           accumulate, scale, (hipStream_t)stream);
 }
 
+extern "C" int etainv_maps_word_maps_role(etainv_engine_t* e, int n_img, const int32_t* tokens, int n_tok, int steps_done, int row_sel,
+                                          float* out, int accumulate, float scale, void* stream) {
+  ETAINV_CHECK(e && n_img >= 1 && n_img <= e->max_img && (row_sel == 0 || row_sel == 1), "bad arguments");
+  return launch_word_maps(e->maps_acc, 5, e->max_img, 2, row_sel, etainv_engine::kHeads, e->L / 4, e->L, n_img, tokens, n_tok, steps_done, out,
+                          accumulate, scale, (hipStream_t)stream);
+}
+
 extern "C" int etainv_local_blend(etainv_engine_t* e, float* x, int n_img, const float* blend_alpha, float thres, void* stream) {
   ETAINV_CHECK(e && n_img >= 1 && n_img <= e->max_img, "bad arguments");
   return launch_local_blend(e->maps_acc, 5, e->max_img, etainv_engine::kHeads, e->L / 4, e->L, x, n_img, blend_alpha, thres,

@@ -46,6 +46,7 @@ SIGNATURES = {
     "etainv_unet_forward": [_p, _p, _i, C.POINTER(_i64), _p, _i, C.POINTER(AttnCtrl), _p, _i, _p],
     "etainv_maps_reset": [_p, _p],
     "etainv_maps_word_maps": [_p, _i, _p, _i, _i, _p, _i, _f, _p],
+    "etainv_maps_word_maps_role": [_p, _i, _p, _i, _i, _i, _p, _i, _f, _p],
     "etainv_local_blend": [_p, _p, _i, _p, _f, _p],
     "etainv_engine_workspace_bytes": [_p],
     "etainv_engine_weight_bytes": [_p],

@@ -117,6 +117,12 @@ class Engine:
                                                    int(accumulate), float(scale), _capi.stream_ptr()))
         return out
 
+    def word_maps_role(self, n_img, tokens, steps_done, row_sel, out):
+        """maps of one role of the backward-pass store (0 source, 1 target cond row), averaged over `steps_done` steps"""
+        _capi.check(self.lib.etainv_maps_word_maps_role(self.h, n_img, _capi.ptr(tokens), tokens.shape[1], steps_done, row_sel, _capi.ptr(out),
+                                                        0, 1.0, _capi.stream_ptr()))
+        return out
+
     def local_blend(self, x, n_img, blend_alpha, thres=0.3):
         assert x.dtype == torch.float32
         _capi.check(self.lib.etainv_local_blend(self.h, _capi.ptr(x), n_img, _capi.ptr(blend_alpha), float(thres), _capi.stream_ptr()))

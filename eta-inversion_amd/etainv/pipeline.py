@@ -104,7 +104,7 @@ class EtaLoop:
         return {"latents": lat, "maps_mean": maps_mean, "maps_steps": maps_steps}
 
     # ---------------------------------------------------------------- backward / eta sampling
-    def sample(self, inv, ctx_src, ctx_tgt, noise, edit_word=None, ptp=None, masactrl=None, trace=None, gt_mask=None):
+    def sample(self, inv, ctx_src, ctx_tgt, noise, edit_word=None, ptp=None, masactrl=None, trace=None, gt_mask=None, edit_word_tgt=None):
         """noise (S,n_cand,4,L,L) fp32: the candidates of every step (reference draws them from a generator reseeded
         per image, eta_inversion.py:156,276, so all images share the table).  edit_word (B,) index into the word maps.
         ptp: PtpTables or None; masactrl: (start_step, first_block) or None.  Returns latents (2B,4,L,L) [src.., tgt..]."""
@@ -118,7 +118,7 @@ class EtaLoop:
         eps_all = torch.empty(4 * B, 4, L, L, dtype=torch.float32, device=dev)
         best = torch.zeros(B, dtype=torch.int32, device=dev)
         scratch = torch.empty(B * 16 * 64, dtype=torch.float32, device=dev)
-        mask_map, mask_mode = None, int(self.use_mask)
+        mask_map, mask_mode, bwd = None, int(self.use_mask), False
         if self.use_mask:
             idx = edit_word.to(dev).long().reshape(B, 1, 1, 1).expand(B, 1, L, L)
             final = self.mask_thres is None or self.mask_pow is not None or self.mask_eta != "fwd_mean"
@@ -132,6 +132,13 @@ class EtaLoop:
                     m = torch.pow(m, self.mask_pow)
                 return m.contiguous()
             mask_mode = 2 if final else 1                                           # 2: the map is the per-pixel eta multiplier
+            bwd = self.mask_eta.startswith("bwd")
+            if bwd:                                                                 # maps of the backward-pass store (eta_inversion.py:176-183)
+                assert ptp is not None, "bwd_* eta masks read the prompt-to-prompt controller's maps"
+                tok_s = (edit_word.to(dev).int() + 1).reshape(B, 1).contiguous()
+                tok_t = ((edit_word_tgt if edit_word_tgt is not None else edit_word).to(dev).int() + 1).reshape(B, 1).contiguous()
+                map_s = torch.empty(B, 1, L, L, dtype=torch.float32, device=dev)
+                map_t = torch.empty(B, 1, L, L, dtype=torch.float32, device=dev)
             if self.mask_eta == "gt":
                 assert gt_mask is not None, "mask_eta='gt' needs the ground-truth mask (B,L,L)"
                 mask_map = prep(gt_mask.to(dev).float().reshape(B, L, L))
@@ -153,6 +160,13 @@ class EtaLoop:
             p = t - self.delta
             a_t, a_p = float(self.ac[t]), (float(self.ac[p]) if p >= 0 else float(self.ac[0]))
             var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
+            if self.use_mask and bwd:                                              # average over the i+1 backward steps done, this one included
+                if self.mask_eta != "bwd_target":
+                    e.word_maps_role(B, tok_s, i + 1, 0, map_s)
+                if self.mask_eta != "bwd_source":
+                    e.word_maps_role(B, tok_t, i + 1, 1, map_t)
+                m = map_s if self.mask_eta == "bwd_source" else map_t if self.mask_eta == "bwd_target" else torch.maximum(map_s, map_t)
+                mask_map = prep(m.reshape(B, L, L))
             if self.use_mask and self.mask_eta == "fwd":                            # map of THIS timestep (t_bwd[i] == t_fwd[S-1-i])
                 mask_map = prep(inv["maps_steps"][S - 1 - i].gather(1, idx).reshape(B, L, L))
             _capi.check(self.lib.etainv_eta_backward_step(

@@ -23,10 +23,10 @@ class EtaInversion(DiffusionInversion):
             dft = dict(attn_from_where=["up", "down"], attn_res=16, mask_dirinv=None, mask_eta="fwd_mean", pow=None,
                        target_dirinv=None, thres=0.2)
             mask_mode_cfg = {**dft, **(mask_mode_cfg or {})}
-            if mask_mode_cfg["mask_eta"] not in ("fwd_mean", "fwd", "gt") or mask_mode_cfg["target_dirinv"] is not None \
-                    or mask_mode_cfg["mask_dirinv"] is not None:
-                raise NotImplementedError("eta-mask sources built: fwd_mean (default), fwd, gt, each with thres / pow; the bwd_* maps of the "
-                                          "backward-pass controller and the dirinv masks are not (SURVEY 8f-4)")
+            if mask_mode_cfg["mask_eta"] not in ("fwd_mean", "fwd", "gt", "bwd_source", "bwd_target", "bwd_source_target") \
+                    or mask_mode_cfg["target_dirinv"] is not None or mask_mode_cfg["mask_dirinv"] is not None:
+                raise NotImplementedError("eta-mask sources built: fwd_mean (default), fwd, gt, bwd_source, bwd_target, bwd_source_target, each "
+                                          "with thres / pow; the dirinv masks are not (SURVEY 8f-4)")
         else:
             mask_mode_cfg = None
         self.mask_mode_cfg = mask_mode_cfg
@@ -57,6 +57,8 @@ class EtaInversion(DiffusionInversion):
         if self.mask_mode_cfg is None or self.mask_mode_cfg[key] is None:
             return None
         mode = self.mask_mode_cfg[key]                                 # reference eta_inversion.py:159-205
+        if mode.startswith("bwd"):
+            raise NotImplementedError("bwd_* eta masks are built for the fused loop (etainv + ptp editor), not for the per-step API")
         if mode == "gt":
             m = mask
         elif mode == "fwd":
@@ -128,7 +130,9 @@ class EtaInversion(DiffusionInversion):
             if self.mask_mode_cfg is not None and self.mask_mode_cfg["mask_eta"] == "gt":
                 gt = inv_cfg["mask"]                                       # bilinear to the latent grid (eta_inversion.py:286-287)
                 gt = torch.nn.functional.interpolate(gt.float().reshape(1, 1, *gt.shape[-2:]), (L, L), mode="bilinear")[0]
-            return self._loop.sample(inv_result["_native"], ctx_src, ctx_tgt, noise, edit_word=ew, ptp=ptp, masactrl=masa, gt_mask=gt)
+            ew_t = torch.tensor([edit_word_idx[1]]) if self.mask_mode_cfg is not None else None
+            return self._loop.sample(inv_result["_native"], ctx_src, ctx_tgt, noise, edit_word=ew, ptp=ptp, masactrl=masa, gt_mask=gt,
+                                     edit_word_tgt=ew_t)
         # generic path: user-defined controllers keep their per-step callbacks
         mask = inv_cfg.get("mask", None)
         if mask is not None:                                               # eta_inversion.py:286-287

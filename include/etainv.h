@@ -150,6 +150,10 @@ int etainv_maps_reset(etainv_engine_t* e, void* stream);
  * accumulated with weight `scale` (accumulate == 1; scale = 1/S gives the "fwd_mean" map, :392-396). */
 int etainv_maps_word_maps(etainv_engine_t* e, int n_img, const int32_t* tokens, int n_tok, int steps_done,
                           float* out, int accumulate, float scale, void* stream);
+/* same, for one role of the backward-pass store: row_sel 0 = source cond row, 1 = target cond row (the `bwd_source` /
+ * `bwd_target` eta-mask sources, reference modules/inversion/eta_inversion.py:176-183 via ptp_editor.py:43-85) */
+int etainv_maps_word_maps_role(etainv_engine_t* e, int n_img, const int32_t* tokens, int n_tok, int steps_done, int row_sel, float* out,
+                               int accumulate, float scale, void* stream);
 
 /* LocalBlend (modules/utils/ptp.py:18-47) on the backward latents x [2*n_img][4][L][L] (in place, fp32):
  * blend_alpha [n_img][2][77] selects the blend-word tokens of (source, target) prompt. */

@@ -145,6 +145,16 @@ class EtaInversionOracle:
     # eta_inversion.py:207-273
     def step_backward(self, latent, t, context, source_latent_prev, noise_choices, mask_map, controller):
         eps = self.predict_noise(latent, t, context, self.g_bwd)
+        if self.use_mask and self.mask_eta.startswith("bwd"):                # eta_inversion.py:176-183: maps of the backward-pass controller,
+            ew = self._edit_word_idx                                          # averaged over the steps done so far (this one included)
+            amap = lambda word, sel: optp.attention_map(controller, word + 1, res=self.attn_res, from_where=("up", "down"), resize=self.L,
+                                                        num_prompts=2, select=sel)
+            if self.mask_eta == "bwd_source":
+                mask_map = amap(ew[0], 0)
+            elif self.mask_eta == "bwd_target":
+                mask_map = amap(ew[1], 1)
+            else:
+                mask_map = torch.maximum(amap(ew[0], 0), amap(ew[1], 1))
         eta, z, best, losses = self.eta_variance_noise(source_latent_prev, latent[:1], t, eps[:1], noise_choices)
         eta_map = torch.full_like(z, eta)
         if self.use_mask:
@@ -170,9 +180,10 @@ class EtaInversionOracle:
         """noise_table: (S, n, 1, 4, L, L) -- the candidates `sample_variance_noise` would draw at each
         step from the per-image generator (eta_inversion.py:156,276), injected for reproducibility."""
         context = torch.stack([ctx_src, ctx_tgt], 1).reshape(4, *ctx_src.shape[1:])   # [u_s,u_t,c_s,c_t]
+        self._edit_word_idx = edit_word_idx
         latent = torch.cat([inv["latents"][-1]] * 2)
         mask_map = None
-        if self.use_mask:
+        if self.use_mask and not self.mask_eta.startswith("bwd"):
             mask_map = inv["attn_maps_mean"][edit_word_idx[0]]            # eta_inversion.py:171
         if controller is not None:
             self.unet.set_ctrl(ptp_hook(controller))

@@ -475,6 +475,28 @@ def gen_e2e_dirinv(S=2):
          latent_inv=res["latent_inv"], latent=res["latent"])
 
 
+def gen_e2e_bwdmask(S=2):
+    """EtaInversion with the eta mask taken from the BACKWARD-pass controller maps (mask_eta = bwd_source / bwd_source_target,
+    eta_inversion.py:176-183) + ptp editor on the toy UNet."""
+    from modules.inversion.eta_inversion import EtaInversion
+    from modules.editing.ptp_editor import PromptToPromptEditor
+    src, tgt = PROMPT_PAIRS[0]
+    unet = toy_unet(0)
+    z0 = 0.8 * torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(2026))
+    ptp_cfg = dict(is_replace_controller=False, prompts=[src, tgt], cross_replace_steps={"default_": .4},
+                   self_replace_steps=0.6, blend_words=(("cat",), ("tiger",)),
+                   equilizer_params={"words": ("tiger",), "values": (2,)})
+    out = {"z0": z0, "S": np.array(S)}
+    for mode in ("bwd_source", "bwd_source_target"):
+        pipe = make_pipe(unet)
+        inv = EtaInversion(pipe, scheduler="ddim", num_inference_steps=S, eta=(0.3, 0.6), noise_sample_count=10, seed=0,
+                           mask_mode_cfg=dict(mask_eta=mode, thres=0.15))
+        res = PromptToPromptEditor(inv).edit(z0 / 0.18215, src, tgt, cfg={**ptp_cfg}, inv_cfg=dict(edit_word_idx=(1, 1)))
+        out[f"{mode}/latent_inv"] = res["latent_inv"]
+        out[f"{mode}/latent"] = res["latent"]
+    save("e2e_bwdmask", **out)
+
+
 def gen_pie_bench():
     """reference dataset/pie_bench_data.py on a synthetic mapping_file.json (the real PIE-Bench is not in the container):
     records, edit_word_idx and decoded RLE masks"""
@@ -511,7 +533,7 @@ def gen_pie_bench():
 
 
 GENS = {"schedule": gen_schedule, "ddim_inverse": gen_ddim_inverse, "eta_step": gen_eta_step, "eta_step_modes": gen_eta_step_modes,
-        "ptp_tables": gen_ptp_tables, "ptp_algebra": gen_ptp_algebra, "masactrl": gen_masactrl, "e2e": gen_e2e, "e2e_dirinv": gen_e2e_dirinv, "pie_bench": gen_pie_bench}
+        "ptp_tables": gen_ptp_tables, "ptp_algebra": gen_ptp_algebra, "masactrl": gen_masactrl, "e2e": gen_e2e, "e2e_dirinv": gen_e2e_dirinv, "e2e_bwdmask": gen_e2e_bwdmask, "pie_bench": gen_pie_bench}
 
 
 if __name__ == "__main__":

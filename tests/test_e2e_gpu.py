@@ -163,3 +163,45 @@ def test_mask_modes_vs_oracle(setup, mode):
     inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
     out = loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), noise.reshape(S, 10, 4, L, L).cuda(), edit_word=torch.tensor([1, 1]), gt_mask=gt)
     assert relerr(out[:B].cpu(), ref[:B]) < 5e-3 and relerr(out[B:].cpu(), ref[B:]) < 3e-2
+
+
+@pytest.mark.parametrize("mode", ["bwd_source", "bwd_target", "bwd_source_target"])
+def test_bwd_mask_sources_vs_oracle(setup, mode):
+    """eta mask from the backward-pass prompt-to-prompt store (running average over the steps done), etainv + ptp"""
+    from oracle import loop as oloop, ptp as optp
+    from etainv.pipeline import EtaLoop, PtpTables
+    unet, get_engine = setup
+    L = 16
+    eng = get_engine(L, torch.float16)
+    pairs, z0, ctx_src, ctx_tgt = _inputs(L)
+    tok = optp.WordTokenizer()
+    noise = oloop.noise_table(S, 10, L, seed=0)
+    eta = (0.3, 0.6)
+    ref = []
+    with torch.no_grad():
+        for i, (src, tgt) in enumerate(pairs):
+            o = oloop.EtaInversionOracle(unet, S=S, eta=eta, L=L, use_mask=True, thres=0.15, mask_eta=mode)
+            inv = o.invert(z0[i:i + 1], ctx_src[i], src)
+            bw, tw = src.split(" ")[1], tgt.split(" ")[1]
+            controller = optp.make_edit_controller(src, tgt, S, tok, blend_words=((bw,), (tw,)), equilizer_params={"words": (tw,), "values": (2,)},
+                                                   res=L // 4, thres_n=(L // 2) ** 2, **PTP_CFG)
+            ref.append(o.sample(inv, ctx_src[i], ctx_tgt[i], noise, edit_word_idx=(1, 1), controller=controller))
+    ref = torch.cat([torch.stack([r[0] for r in ref]), torch.stack([r[1] for r in ref])])
+    W = max(len(s.split(" ")) for s, _ in pairs)
+    tokens = torch.ones(B, W, dtype=torch.int32)
+    mp, al, eq, ba, ca = [], [], [], [], []
+    for i, (src, tgt) in enumerate(pairs):
+        ws = src.split(" ")
+        tokens[i, :len(ws)] = torch.tensor([ws.index(w) + 1 for w in ws], dtype=torch.int32)
+        bw, tw = src.split(" ")[1], tgt.split(" ")[1]
+        m, a = optp.refinement_mapper(src, tgt, tok)
+        mp.append(m); al.append(a)
+        eq.append(optp.equalizer(tgt, (tw,), (2,), tok))
+        ba.append(optp.blend_alpha_layers([src, tgt], ((bw,), (tw,)), tok))
+        ca.append(optp.time_words_alpha([src, tgt], S, {"default_": .4}, tok)[:, 0])
+    ptp = PtpTables(np.stack(mp), np.stack(al), np.stack(ca, 1), 0.6, S, equalizer=np.stack(eq), blend_alpha=np.stack(ba))
+    loop = EtaLoop(eng, S=S, eta=eta, use_mask=True, mask_thres=0.15, mask_eta=mode)
+    inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
+    out = loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), noise.reshape(S, 10, 4, L, L).cuda(), edit_word=torch.tensor([1, 1]), ptp=ptp,
+                      edit_word_tgt=torch.tensor([1, 1]))
+    assert relerr(out[:B].cpu(), ref[:B]) < 5e-3 and relerr(out[B:].cpu(), ref[B:]) < 3e-2

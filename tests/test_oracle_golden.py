@@ -223,6 +223,27 @@ def test_dirinv_is_eta_zero(golden, toy_unet):
     np.testing.assert_allclose(z[1:].numpy(), g["latent"], rtol=1e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("mode", [pytest.param("bwd_source", marks=pytest.mark.slow), "bwd_source_target"])
+def test_bwd_mask_sources_vs_reference(golden, toy_unet, mode):
+    """eta mask from the backward-pass controller's maps (eta_inversion.py:176-183) through the reference's EtaInversion + ptp editor
+    on the toy UNet (make_golden.gen_e2e_bwdmask)"""
+    g = golden("e2e_bwdmask")
+    S = int(g["S"])
+    src, tgt = json.load(open(f"{GOLDEN_DIR}/prompt_pairs.json"))[0]
+    tok = optp.WordTokenizer()
+    from tests.golden.make_golden import text_embed            # the generator's stand-in text encoder (no reference code involved)
+    emb = lambda p: text_embed(torch.tensor([tok.pad_ids(p)]))[0]
+    ctx_s, ctx_t = torch.stack([emb(""), emb(src)]), torch.stack([emb(""), emb(tgt)])
+    z0 = torch.from_numpy(g["z0"])
+    with torch.no_grad():
+        o = oloop.EtaInversionOracle(toy_unet, S=S, eta=(0.3, 0.6), use_mask=True, thres=0.15, mask_eta=mode)
+        inv = o.invert(z0, ctx_s, src)
+        controller = optp.make_edit_controller(src, tgt, S, tok, **PTP_VARIANTS["refine"])
+        z = o.sample(inv, ctx_s, ctx_t, oloop.noise_table(S, 10, 64, seed=0), edit_word_idx=(1, 1), controller=controller)
+    np.testing.assert_allclose(z[:1].numpy(), g[f"{mode}/latent_inv"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(z[1:].numpy(), g[f"{mode}/latent"], rtol=1e-3, atol=2e-4)
+
+
 def test_clip_oracle_matches_transformers():
     """oracle/clip.py is pinned by the third-party implementation itself where it is importable: transformers'
     CLIPTextModel (ViT-L/14 text config) loaded with the oracle's seeded weights gives the same hidden states."""
