@@ -33,6 +33,7 @@ constexpr int ETA_LOSS_BLOCKS = 64;  // partial sums per (image, candidate)
 
 struct EtaCoef {
   float g, eta, sa_t, s1m_t, sa_p, a_p, var, thres;
+  float tdir;   // target_dirinv weight (0 = off): the target row takes tdir * dirinv_map * (x_prev_src - x_src_new)
 };
 
 // pass 1: guided source noise, DDIM-eta mean (noise = 0), ideal noise z*, squared distance of each candidate
@@ -86,7 +87,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) eta_update_kernel(const T* __restrict__ x, const T* __restrict__ eps_all,
                                                          const T* __restrict__ x_prev, const T* __restrict__ noise,
                                                          int n_cand, EtaCoef k, const T* __restrict__ mask_map, int use_mask,
-                                                         int n_img, int chw, int hw, const float* __restrict__ partial,
+                                                         const T* __restrict__ dirinv_map, int n_img, int chw, int hw,
+                                                         const float* __restrict__ partial,
                                                          T* __restrict__ out_x, T* __restrict__ out_eps,
                                                          int32_t* __restrict__ best_idx, float* __restrict__ losses) {
   const int img = blockIdx.y;
@@ -128,6 +130,7 @@ __global__ void __launch_bounds__(256) eta_update_kernel(const T* __restrict__ x
   const float std_t = eta_px * sqrtf(k.var);
   const float dir_c = sqrtf(1.f - k.a_p - std_t * std_t);
   const float xp = to_f32(x_prev[(int64_t)img * chw + e]);
+  float delta = 0.f;
 #pragma unroll
   for (int role = 0; role < 2; ++role) {
     const int64_t lrow = (int64_t)(role * n_img + img) * chw + e;
@@ -136,7 +139,13 @@ __global__ void __launch_bounds__(256) eta_update_kernel(const T* __restrict__ x
     float eps = u + k.g * (c - u);
     float x0 = (to_f32(x[lrow]) - k.s1m_t * eps) / k.sa_t;
     float xn = k.sa_p * x0 + dir_c * eps + std_t * z;
-    if (role == 0) xn = use_mask ? xn + (xp - xn) : xp;
+    if (role == 0) {
+      delta = xp - xn;                          // source correction (eta_inversion.py:247)
+      xn = use_mask ? xn + delta : xp;
+    } else if (k.tdir != 0.f) {                 // target_dirinv (eta_inversion.py:251-256): part of the correction leaks to the target
+      const float md = dirinv_map ? to_f32(dirinv_map[(int64_t)img * hw + (e % hw)]) : 1.f;   // host passes 1 - mask_dirinv
+      xn += k.tdir * md * delta;
+    }
     out_x[lrow] = from_f32<T>(xn);
     if (out_eps) out_eps[lrow] = from_f32<T>(eps);
   }
@@ -210,6 +219,16 @@ extern "C" int etainv_eta_backward_step(const void* x, const void* eps_all, floa
                                         int n_cand, float eta, const void* mask_map, float mask_thres, int use_mask, float a_t,
                                         float a_p, float var, int n_img, int c, int hw, void* out_x, void* out_eps,
                                         int32_t* best_idx, float* losses, float* scratch, int io_dtype, void* stream) {
+  return etainv_eta_backward_step_ex(x, eps_all, g, x_prev_src, noise, n_cand, eta, mask_map, mask_thres, use_mask, a_t, a_p, var, n_img, c, hw,
+                                     out_x, out_eps, best_idx, losses, scratch, io_dtype, 0.f, nullptr, stream);
+}
+
+extern "C" int etainv_eta_backward_step_ex(const void* x, const void* eps_all, float g, const void* x_prev_src, const void* noise,
+                                           int n_cand, float eta, const void* mask_map, float mask_thres, int use_mask, float a_t,
+                                           float a_p, float var, int n_img, int c, int hw, void* out_x, void* out_eps,
+                                           int32_t* best_idx, float* losses, float* scratch, int io_dtype, float target_dirinv,
+                                           const void* dirinv_map, void* stream) {
+  ETAINV_CHECK(target_dirinv == 0.f || use_mask, "target_dirinv is part of the masked update (mask_mode_cfg)");
   ETAINV_CHECK(x && eps_all && x_prev_src && noise && out_x && scratch, "null pointer");
   ETAINV_CHECK(n_cand >= 1 && n_cand <= ETA_MAX_CAND, "noise_sample_count must be in [1,16]");
   ETAINV_CHECK(n_img >= 1 && c >= 1 && hw >= 1, "bad sizes");
@@ -224,6 +243,7 @@ extern "C" int etainv_eta_backward_step(const void* x, const void* eps_all, floa
   k.a_p = a_p;
   k.var = var;
   k.thres = mask_thres;
+  k.tdir = target_dirinv;
   const int chw = c * hw;
   hipStream_t s = (hipStream_t)stream;
   ETAINV_DISPATCH_DTYPE(
@@ -231,7 +251,7 @@ extern "C" int etainv_eta_backward_step(const void* x, const void* eps_all, floa
       hipLaunchKernelGGL(eta_loss_kernel<T>, dim3(ETA_LOSS_BLOCKS, n_img), dim3(256), 0, s, (const T*)x, (const T*)eps_all,
                          (const T*)x_prev_src, (const T*)noise, n_cand, k, n_img, chw, scratch);
       hipLaunchKernelGGL(eta_update_kernel<T>, dim3(cdiv(chw, 256), n_img), dim3(256), 0, s, (const T*)x, (const T*)eps_all,
-                         (const T*)x_prev_src, (const T*)noise, n_cand, k, (const T*)mask_map, use_mask, n_img, chw, hw,
+                         (const T*)x_prev_src, (const T*)noise, n_cand, k, (const T*)mask_map, use_mask, (const T*)dirinv_map, n_img, chw, hw,
                          (const float*)scratch, (T*)out_x, (T*)out_eps, best_idx, losses));
   ETAINV_LAUNCH_CHECK();
   return 0;

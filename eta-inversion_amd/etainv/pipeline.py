@@ -43,7 +43,8 @@ def eta_table(eta=(0.0, 0.4)) -> np.ndarray:
 
 class EtaLoop:
     def __init__(self, engine, S=50, guidance_scale_bwd=7.5, guidance_scale_fwd=1.0, eta=(0.0, 0.4), noise_sample_count=10,
-                 use_mask=True, mask_thres=0.2, skip_uncond_fwd=True, steps_offset=0, mask_eta="fwd_mean", mask_pow=None):
+                 use_mask=True, mask_thres=0.2, skip_uncond_fwd=True, steps_offset=0, mask_eta="fwd_mean", mask_pow=None, target_dirinv=None,
+                 mask_dirinv=None):
         self.e, self.S, self.L = engine, S, engine.L
         self.g_bwd, self.g_fwd = float(guidance_scale_bwd), float(guidance_scale_fwd)
         self.ac = alphas_cumprod()
@@ -55,6 +56,11 @@ class EtaLoop:
         self.use_mask, self.mask_thres = use_mask, mask_thres
         # non-default eta-mask modes (reference eta_inversion.py:164-201): source of the map (fwd_mean | fwd | gt), thres None = soft, pow
         self.mask_eta, self.mask_pow = mask_eta, mask_pow
+        # target_dirinv w: x_tgt += w (1 - mask_dirinv) (x_prev_src - x_src_new)  (eta_inversion.py:251-256); mask_dirinv must name the
+        # same map source as mask_eta (or None)
+        self.target_dirinv, self.mask_dirinv = target_dirinv, mask_dirinv
+        assert mask_dirinv is None or mask_dirinv == mask_eta, "mask_dirinv: same source as mask_eta"
+        assert target_dirinv is None or use_mask, "target_dirinv is part of the masked update"
         # u + 1*(c - u) == c up to rounding: the uncond half of the forward pass is dead work when g_fwd == 1
         self.skip_uncond_fwd = skip_uncond_fwd and self.g_fwd == 1.0
         self.lib = engine.lib
@@ -169,10 +175,14 @@ class EtaLoop:
                 mask_map = prep(m.reshape(B, L, L))
             if self.use_mask and self.mask_eta == "fwd":                            # map of THIS timestep (t_bwd[i] == t_fwd[S-1-i])
                 mask_map = prep(inv["maps_steps"][S - 1 - i].gather(1, idx).reshape(B, L, L))
-            _capi.check(self.lib.etainv_eta_backward_step(
+            dmap = None
+            if self.target_dirinv is not None and self.mask_dirinv is not None:     # 1 - (thresholded / powered) map of the same source
+                m = mask_map if mask_mode == 2 else (mask_map > self.mask_thres).to(mask_map.dtype)
+                dmap = (1.0 - m).contiguous()
+            _capi.check(self.lib.etainv_eta_backward_step_ex(
                 _capi.ptr(x), _capi.ptr(eps_all), self.g_bwd, _capi.ptr(lat_inv[S - 1 - i]), _capi.ptr(noise[i]), self.n_cand,
                 float(self.etas[t]), _capi.ptr(mask_map), float(self.mask_thres or 0.0), mask_mode, a_t, a_p, var, B, 4, L * L,
-                _capi.ptr(x_new), None, _capi.ptr(best), None, _capi.ptr(scratch), _capi.F32, st))
+                _capi.ptr(x_new), None, _capi.ptr(best), None, _capi.ptr(scratch), _capi.F32, float(self.target_dirinv or 0.0), _capi.ptr(dmap), st))
             x, x_new = x_new, x
             if ptp is not None and ptp.blend_alpha is not None and (i + 1) > int(0.2 * S):
                 e.local_blend(x, B, ptp.blend_alpha, 0.3)                       # LocalBlend, reference ptp.py:31-47

@@ -24,9 +24,9 @@ class EtaInversion(DiffusionInversion):
                        target_dirinv=None, thres=0.2)
             mask_mode_cfg = {**dft, **(mask_mode_cfg or {})}
             if mask_mode_cfg["mask_eta"] not in ("fwd_mean", "fwd", "gt", "bwd_source", "bwd_target", "bwd_source_target") \
-                    or mask_mode_cfg["target_dirinv"] is not None or mask_mode_cfg["mask_dirinv"] is not None:
+                    or mask_mode_cfg["mask_dirinv"] not in (None, mask_mode_cfg["mask_eta"]):
                 raise NotImplementedError("eta-mask sources built: fwd_mean (default), fwd, gt, bwd_source, bwd_target, bwd_source_target, each "
-                                          "with thres / pow; the dirinv masks are not (SURVEY 8f-4)")
+                                          "with thres / pow; mask_dirinv must be None or the same source as mask_eta")
         else:
             mask_mode_cfg = None
         self.mask_mode_cfg = mask_mode_cfg
@@ -45,7 +45,8 @@ class EtaInversion(DiffusionInversion):
         self._loop = EtaLoop(model.engine, S=self.num_inference_steps, guidance_scale_bwd=self.guidance_scale_bwd,
                              guidance_scale_fwd=self.guidance_scale_fwd, eta=eta, noise_sample_count=noise_sample_count,
                              use_mask=use_mask, mask_thres=(mask_mode_cfg or {}).get("thres", 0.2),
-                             mask_eta=(mask_mode_cfg or {}).get("mask_eta", "fwd_mean"), mask_pow=(mask_mode_cfg or {}).get("pow"))
+                             mask_eta=(mask_mode_cfg or {}).get("mask_eta", "fwd_mean"), mask_pow=(mask_mode_cfg or {}).get("pow"),
+                             target_dirinv=(mask_mode_cfg or {}).get("target_dirinv"), mask_dirinv=(mask_mode_cfg or {}).get("mask_dirinv"))
 
     # ------------------------------------------------------------------ noise / mask
     def sample_variance_noise(self, n: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
@@ -169,10 +170,15 @@ class EtaInversion(DiffusionInversion):
         best = torch.zeros(1, dtype=torch.int32, device=x.device)
         losses = torch.zeros(1, self.noise_sample_count, dtype=torch.float32, device=x.device)
         scratch = torch.empty(16 * 64, dtype=torch.float32, device=x.device)
-        _capi.check(_capi.load().etainv_eta_backward_step(
+        tdir = (self.mask_mode_cfg or {}).get("target_dirinv")
+        dmap = None
+        if tdir is not None and self.mask_mode_cfg["mask_dirinv"] is not None:
+            dmap = (1.0 - self.get_mask("mask_dirinv", self._step_mask, t, edit_word_idx).float().reshape(1, L, L)).contiguous()
+        _capi.check(_capi.load().etainv_eta_backward_step_ex(
             _capi.ptr(x), _capi.ptr(noise_pred), float(self.guidance_scale_bwd), _capi.ptr(latent_prev.float().contiguous()),
             _capi.ptr(cand), self.noise_sample_count, float(self.etas[t]), _capi.ptr(mask_map),
             0.0, 2 if use_mask else 0, a_t, a_p, var, 1, 4, L * L, _capi.ptr(out_x),   # 2: get_mask already applied thres / pow
-            _capi.ptr(out_eps), _capi.ptr(best), _capi.ptr(losses), _capi.ptr(scratch), _capi.F32, _capi.stream_ptr()))
+            _capi.ptr(out_eps), _capi.ptr(best), _capi.ptr(losses), _capi.ptr(scratch), _capi.F32, float(tdir or 0.0), _capi.ptr(dmap),
+            _capi.stream_ptr()))
         return {"eta": float(self.etas[t]), "variance_noise_candidates": cand, "best_idx": best, "losses": losses, "latent": out_x,
                 "noise_pred": out_eps, "latent_prev": latent_prev}

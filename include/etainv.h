@@ -77,6 +77,12 @@ int etainv_eta_backward_step(const void* x, const void* eps_all, float g, const 
                              int use_mask, float a_t, float a_p, float var, int n_img, int c, int hw,
                              void* out_x, void* out_eps, int32_t* best_idx, float* losses, float* scratch,
                              int io_dtype, void* stream);
+/* same + the reference's `target_dirinv` option (eta_inversion.py:251-256): x_tgt += target_dirinv * dirinv_map * (x_prev_src - x_src_new),
+ * dirinv_map [n_img][hw] = 1 - mask_dirinv prepared by the caller (NULL = 1 everywhere); needs use_mask != 0 */
+int etainv_eta_backward_step_ex(const void* x, const void* eps_all, float g, const void* x_prev_src, const void* noise, int n_cand, float eta,
+                                const void* mask_map, float mask_thres, int use_mask, float a_t, float a_p, float var, int n_img, int c, int hw,
+                                void* out_x, void* out_eps, int32_t* best_idx, float* losses, float* scratch, int io_dtype,
+                                float target_dirinv, const void* dirinv_map, void* stream);
 
 /* ---------------------------------------------------------------- engine */
 typedef struct etainv_engine etainv_engine_t;

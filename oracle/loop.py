@@ -79,7 +79,7 @@ class MasaCtrl:
 # --------------------------------------------------------------------------- the loops
 class EtaInversionOracle:
     def __init__(self, unet, S=50, guidance_scale_bwd=7.5, guidance_scale_fwd=1, eta=(0.0, 0.4),
-                 noise_sample_count=10, use_mask=True, thres=0.2, L=64, dtype=torch.float32, mask_eta="fwd_mean", mask_pow=None):
+                 noise_sample_count=10, use_mask=True, thres=0.2, L=64, dtype=torch.float32, mask_eta="fwd_mean", mask_pow=None, target_dirinv=None, mask_dirinv=None):
         self.unet, self.S, self.L, self.dtype = unet, S, L, dtype
         self.g_bwd, self.g_fwd = guidance_scale_bwd, guidance_scale_fwd
         self.ac = sch.alphas_cumprod()
@@ -88,6 +88,7 @@ class EtaInversionOracle:
         self.n = noise_sample_count
         self.use_mask, self.thres = use_mask, thres
         self.mask_eta, self.mask_pow = mask_eta, mask_pow     # eta_inversion.py:164-201 (gt / fwd / fwd_mean; thres None; pow)
+        self.target_dirinv, self.mask_dirinv = target_dirinv, mask_dirinv   # eta_inversion.py:251-256
         self.attn_res = L // 4                  # 16 at L=64 (eta_inversion.py:90)
         self.thres_n = (L // 2) ** 2            # 32^2 at L=64 (ptp.py:153,226)
 
@@ -165,7 +166,12 @@ class EtaInversionOracle:
                 m = torch.pow(m, self.mask_pow)                               # eta_inversion.py:200-201
             eta_map = m * eta_map
             new = sch.ddim_eta_step(latent, eps, self.ac, int(t), self.S, eta_map, noise=z)
-            new[:1] = new[:1] + (source_latent_prev[:1] - new[:1])       # eta_inversion.py:247-249
+            delta = source_latent_prev[:1] - new[:1]
+            new[:1] = new[:1] + delta                                      # eta_inversion.py:247-249
+            if self.target_dirinv is not None:                             # eta_inversion.py:251-256 (mask_dirinv: same source map, thres, pow)
+                if self.mask_dirinv is not None:
+                    delta = (1 - m) * delta
+                new[1:] = new[1:] + self.target_dirinv * delta
         else:
             new = sch.ddim_eta_step(latent, eps, self.ac, int(t), self.S, eta_map, noise=z)
             new[:1] = source_latent_prev[:1]

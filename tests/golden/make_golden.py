@@ -301,6 +301,25 @@ def gen_eta_step_modes():
     save("eta_step_modes", **out)
 
 
+def gen_eta_step_dirinv():
+    """the reference's target_dirinv / mask_dirinv options of predict_step_backward (eta_inversion.py:236-256)"""
+    from modules.inversion.eta_inversion import EtaInversion
+    from tests.golden.recipes import ETA_DIRINV_CASES, eta_case_inputs, crc
+    out, t = {}, 980
+    for name, mode in ETA_DIRINV_CASES.items():
+        inp = eta_case_inputs(name)
+        latent, unet_out, src_prev, mask_map, noise = (inp[k] for k in ("latent", "unet_out", "src_prev", "mask_map", "noise"))
+        cu = _ConstUnet(unet_out)
+        cu.dtype = latent.dtype
+        inv = EtaInversion(make_pipe(cu), scheduler="ddim", num_inference_steps=50, eta=[[0.6, 0], [1, 0.7]], use_mask=True, mask_mode_cfg=mode)
+        inv.attn_maps_forward = {"mean": [mask_map, mask_map], t: [mask_map, mask_map]}
+        with inv.use_controller(None):
+            new, eps = inv.predict_step_backward(latent.clone(), torch.tensor(t), torch.zeros(4, 77, 8), source_latent_prev=src_prev,
+                                                 generator=torch.Generator().manual_seed(5), mask=mask_map, edit_word_idx=(0, 0))
+        out.update({f"{name}/new": new.float(), f"{name}/crc": np.array([crc(latent), crc(unet_out), crc(src_prev), crc(mask_map), crc(noise)])})
+    save("eta_step_dirinv", **out)
+
+
 PROMPT_PAIRS = [
     ("a cat sitting next to a mirror", "a tiger sitting next to a mirror"),
     ("a photo of a house on a hill", "a photo of a wooden house on a snowy hill"),
@@ -532,7 +551,7 @@ def gen_pie_bench():
     save("pie_bench_masks", **masks)
 
 
-GENS = {"schedule": gen_schedule, "ddim_inverse": gen_ddim_inverse, "eta_step": gen_eta_step, "eta_step_modes": gen_eta_step_modes,
+GENS = {"schedule": gen_schedule, "ddim_inverse": gen_ddim_inverse, "eta_step": gen_eta_step, "eta_step_modes": gen_eta_step_modes, "eta_step_dirinv": gen_eta_step_dirinv,
         "ptp_tables": gen_ptp_tables, "ptp_algebra": gen_ptp_algebra, "masactrl": gen_masactrl, "e2e": gen_e2e, "e2e_dirinv": gen_e2e_dirinv, "e2e_bwdmask": gen_e2e_bwdmask, "pie_bench": gen_pie_bench}
 
 

@@ -25,8 +25,15 @@ ETA_MODE_CASES = {  # name: mask_mode_cfg overrides (eta_inversion.py:88-101,164
 }
 
 
+ETA_DIRINV_CASES = {  # target_dirinv (eta_inversion.py:251-256) with / without a mask_dirinv; paper eta, t = 980, fp32
+    "tdir": dict(mask_eta="fwd_mean", thres=0.2, target_dirinv=0.5),
+    "tdir_masked": dict(mask_eta="fwd_mean", mask_dirinv="fwd_mean", thres=0.4, target_dirinv=0.8),
+    "tdir_soft": dict(mask_eta="fwd_mean", mask_dirinv="fwd_mean", thres=None, pow=2.0, target_dirinv=0.3),
+}
+
+
 def eta_case_inputs(name: str, L: int = 64):
-    if name in ETA_MODE_CASES:
+    if name in ETA_MODE_CASES or name in ETA_DIRINV_CASES:
         return _eta_case_inputs("mode_" + name, False, L)
     return _eta_case_inputs(name, ETA_CASES[name][2], L)
 

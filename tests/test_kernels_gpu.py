@@ -120,6 +120,38 @@ def test_eta_backward_step_mask_modes_vs_reference_golden(capi, golden, name):
     np.testing.assert_allclose(out_x.cpu().numpy(), g[f"{name}/new"], rtol=1e-4, atol=5e-5)
 
 
+@pytest.mark.parametrize("name", ["tdir", "tdir_masked", "tdir_soft"])
+def test_eta_backward_step_target_dirinv_vs_reference_golden(capi, golden, name):
+    """etainv_eta_backward_step_ex: the reference's target_dirinv / mask_dirinv options (eta_inversion.py:251-256)"""
+    from oracle import schedule as sch
+    from tests.golden import recipes
+    g = golden("eta_step_dirinv")
+    mode = recipes.ETA_DIRINV_CASES[name]
+    inp = recipes.eta_case_inputs(name)
+    assert [recipes.crc(inp[k]) for k in ("latent", "unet_out", "src_prev", "mask_map", "noise")] == list(g[f"{name}/crc"])
+    m = inp["mask_map"].float()
+    if mode.get("thres", 0.2) is not None:
+        m = (m > mode.get("thres", 0.2)).float()
+    if mode.get("pow") is not None:
+        m = torch.pow(m, mode["pow"])
+    dmap = (1 - m).contiguous().cuda() if mode.get("mask_dirinv") else None
+    lib = capi.load()
+    ac, t, S = sch.alphas_cumprod(), 980, 50
+    eta = float(sch.eta_table([[0.6, 0], [1, 0.7]])[t])
+    x = inp["latent"].float().cuda()
+    eps_all, xp, noise = inp["unet_out"].float().cuda(), inp["src_prev"].float().cuda(), inp["noise"].float().reshape(10, 4, 64, 64).cuda()
+    mm = m.contiguous().cuda()
+    out_x = torch.empty_like(x)
+    best = torch.zeros(1, dtype=torch.int32, device="cuda")
+    scratch = torch.zeros(16 * 64, dtype=torch.float32, device="cuda")
+    p_ = t - 1000 // S
+    capi.check(lib.etainv_eta_backward_step_ex(capi.ptr(x), capi.ptr(eps_all), 7.5, capi.ptr(xp), capi.ptr(noise), 10, eta, capi.ptr(mm), 0.0, 2,
+                                               float(ac[t]), float(ac[p_]), sch.variance(ac, t, S), 1, 4, 64 * 64, capi.ptr(out_x), None, capi.ptr(best), None,
+                                               capi.ptr(scratch), capi.F32, float(mode["target_dirinv"]), capi.ptr(dmap) if dmap is not None else None,
+                                               capi.stream_ptr()))
+    np.testing.assert_allclose(out_x.cpu().numpy(), g[f"{name}/new"], rtol=1e-4, atol=5e-5)
+
+
 def test_eta_backward_step_batched_images(capi):
     """n_img = 3 pairs in the [src.., tgt..] / [u_s.., u_t.., c_s.., c_t..] layout == three B=1 calls."""
     from oracle import schedule as sch

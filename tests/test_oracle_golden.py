@@ -98,6 +98,26 @@ def test_eta_step_mask_modes(golden, name):
     np.testing.assert_allclose(new.numpy(), g[f"{name}/new"], rtol=1e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("name", list(recipes.ETA_DIRINV_CASES))
+def test_eta_step_target_dirinv(golden, name):
+    """target_dirinv / mask_dirinv of the reference's predict_step_backward (eta_inversion.py:236-256)"""
+    g = golden("eta_step_dirinv")
+    mode = recipes.ETA_DIRINV_CASES[name]
+    inp = recipes.eta_case_inputs(name)
+    assert [recipes.crc(inp[k]) for k in ("latent", "unet_out", "src_prev", "mask_map", "noise")] == list(g[f"{name}/crc"])
+
+    class U:
+        def __call__(self, x, t, encoder_hidden_states=None):
+            return {"sample": inp["unet_out"]}
+
+        def set_ctrl(self, c):
+            pass
+    o = oloop.EtaInversionOracle(U(), S=50, eta=[[0.6, 0], [1, 0.7]], use_mask=True, thres=mode.get("thres", 0.2), mask_eta=mode["mask_eta"],
+                                 mask_pow=mode.get("pow"), target_dirinv=mode["target_dirinv"], mask_dirinv=mode.get("mask_dirinv"))
+    new, eps, best, losses = o.step_backward(inp["latent"].clone(), 980, torch.zeros(4, 77, 8), inp["src_prev"], inp["noise"], inp["mask_map"], None)
+    np.testing.assert_allclose(new.numpy(), g[f"{name}/new"], rtol=1e-5, atol=2e-5)
+
+
 def test_ptp_tables(golden):
     g = golden("ptp_tables")
     pairs = json.load(open(f"{GOLDEN_DIR}/prompt_pairs.json"))
