@@ -46,7 +46,9 @@ class EtaLoop:
                  use_mask=True, mask_thres=0.2, skip_uncond_fwd=True, steps_offset=0, mask_eta="fwd_mean", mask_pow=None, target_dirinv=None,
                  mask_dirinv=None):
         self.e, self.S, self.L = engine, S, engine.L
-        self.g_bwd, self.g_fwd = float(guidance_scale_bwd), float(guidance_scale_fwd)
+        # guidance_scale_fwd may be a (start, end) pair: linspace over the 1000 training timesteps, indexed by t (eta_inversion.py:108-110,325-326)
+        self.g_fwd_table = np.linspace(guidance_scale_fwd[0], guidance_scale_fwd[1], NUM_TRAIN) if isinstance(guidance_scale_fwd, (tuple, list)) else None
+        self.g_bwd, self.g_fwd = float(guidance_scale_bwd), (1.0 if self.g_fwd_table is not None else float(guidance_scale_fwd))
         self.ac = alphas_cumprod()
         self.delta = NUM_TRAIN // S
         self.t_bwd = ((np.arange(S) * self.delta)[::-1] + steps_offset).astype(np.int64)
@@ -62,7 +64,7 @@ class EtaLoop:
         assert mask_dirinv is None or mask_dirinv == mask_eta, "mask_dirinv: same source as mask_eta"
         assert target_dirinv is None or use_mask, "target_dirinv is part of the masked update"
         # u + 1*(c - u) == c up to rounding: the uncond half of the forward pass is dead work when g_fwd == 1
-        self.skip_uncond_fwd = skip_uncond_fwd and self.g_fwd == 1.0
+        self.skip_uncond_fwd = skip_uncond_fwd and self.g_fwd == 1.0 and self.g_fwd_table is None
         self.lib = engine.lib
 
     def _alpha(self, tau):
@@ -99,7 +101,8 @@ class EtaLoop:
         for j, t in enumerate(self.t_fwd):
             e.unet(lat[j], int(t), ctx, ctrl, out=eps_all)
             if not self.skip_uncond_fwd:
-                _capi.check(self.lib.etainv_cfg_combine(_capi.ptr(eps_all[:B]), _capi.ptr(eps_all[B:]), self.g_fwd, _capi.ptr(eps), n,
+                g = float(self.g_fwd_table[int(t)]) if self.g_fwd_table is not None else self.g_fwd
+                _capi.check(self.lib.etainv_cfg_combine(_capi.ptr(eps_all[:B]), _capi.ptr(eps_all[B:]), g, _capi.ptr(eps), n,
                                                         _capi.F32, st))
             a_from, a_to = self._alpha(int(t) - self.delta), self._alpha(int(t))   # "sameshift" (scheduling_ddim_inverse.py:127-131)
             _capi.check(self.lib.etainv_ddim_step(_capi.ptr(lat[j]), _capi.ptr(eps), a_from, a_to, _capi.ptr(lat[j + 1]), n, _capi.F32, st))

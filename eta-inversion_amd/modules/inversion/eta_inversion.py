@@ -30,9 +30,12 @@ class EtaInversion(DiffusionInversion):
         else:
             mask_mode_cfg = None
         self.mask_mode_cfg = mask_mode_cfg
-        if isinstance(guidance_scale_fwd, (tuple, list)):
-            raise NotImplementedError("per-timestep guidance_scale_fwd tables are not built")
+        g_fwd_pair = None
+        if isinstance(guidance_scale_fwd, (tuple, list)):                  # per-timestep table (reference :108-110): handled by the native loop
+            assert len(guidance_scale_fwd) == 2
+            g_fwd_pair, guidance_scale_fwd = tuple(guidance_scale_fwd), None
         super().__init__(model, scheduler, num_inference_steps, guidance_scale_bwd, guidance_scale_fwd, verbose)
+        self._g_fwd_pair = g_fwd_pair
         if eta_start is not None:
             assert eta_end is not None
             eta = (eta_start, eta_end)
@@ -43,7 +46,7 @@ class EtaInversion(DiffusionInversion):
         self.seed = seed if seed >= 0 else None
         self.L = model.engine.L
         self._loop = EtaLoop(model.engine, S=self.num_inference_steps, guidance_scale_bwd=self.guidance_scale_bwd,
-                             guidance_scale_fwd=self.guidance_scale_fwd, eta=eta, noise_sample_count=noise_sample_count,
+                             guidance_scale_fwd=self._g_fwd_pair or self.guidance_scale_fwd, eta=eta, noise_sample_count=noise_sample_count,
                              use_mask=use_mask, mask_thres=(mask_mode_cfg or {}).get("thres", 0.2),
                              mask_eta=(mask_mode_cfg or {}).get("mask_eta", "fwd_mean"), mask_pow=(mask_mode_cfg or {}).get("pow"),
                              target_dirinv=(mask_mode_cfg or {}).get("target_dirinv"), mask_dirinv=(mask_mode_cfg or {}).get("mask_dirinv"))

@@ -82,6 +82,8 @@ class EtaInversionOracle:
                  noise_sample_count=10, use_mask=True, thres=0.2, L=64, dtype=torch.float32, mask_eta="fwd_mean", mask_pow=None, target_dirinv=None, mask_dirinv=None):
         self.unet, self.S, self.L, self.dtype = unet, S, L, dtype
         self.g_bwd, self.g_fwd = guidance_scale_bwd, guidance_scale_fwd
+        if isinstance(guidance_scale_fwd, (tuple, list)):                     # per-timestep table, eta_inversion.py:108-110,325-326
+            self.g_fwd = np.linspace(guidance_scale_fwd[0], guidance_scale_fwd[1], 1000)
         self.ac = sch.alphas_cumprod()
         self.t_fwd, self.t_bwd = sch.timesteps_forward(S), sch.timesteps_backward(S)
         self.etas = sch.eta_table(eta)
@@ -114,7 +116,7 @@ class EtaInversionOracle:
         latents, noise_preds, maps_per_t = [z0], [], {}
         try:
             for t in self.t_fwd:
-                eps = self.predict_noise(latent, t, context, self.g_fwd)
+                eps = self.predict_noise(latent, t, context, float(self.g_fwd[int(t)]) if isinstance(self.g_fwd, np.ndarray) else self.g_fwd)
                 a_from, a_to = sch.ddim_inverse_coeffs(self.ac, int(t), self.S)
                 latent = sch.ddim_step(latent, eps, a_from, a_to)
                 if store is not None:                                     # eta_inversion.py:44-49

@@ -233,3 +233,21 @@ def test_target_dirinv_vs_oracle(setup):
     inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
     out = loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), noise.reshape(S, 10, 4, L, L).cuda(), edit_word=torch.tensor([1, 1]))
     assert relerr(out[:B].cpu(), ref[:B]) < 5e-3 and relerr(out[B:].cpu(), ref[B:]) < 3e-2
+
+
+def test_forward_guidance_table_vs_oracle(setup):
+    """guidance_scale_fwd = (start, end): per-timestep CFG in the inversion pass (eta_inversion.py:108-110,325-326) -- the uncond half is run"""
+    from oracle import loop as oloop
+    from etainv.pipeline import EtaLoop
+    unet, get_engine = setup
+    L = 16
+    eng = get_engine(L, torch.float16)
+    pairs, z0, ctx_src, ctx_tgt = _inputs(L)
+    tokens = torch.ones(B, 8, dtype=torch.int32)
+    with torch.no_grad():
+        ref = torch.stack([torch.cat(oloop.EtaInversionOracle(unet, S=S, L=L, use_mask=False, guidance_scale_fwd=(1.0, 3.0)).invert(z0[i:i + 1], ctx_src[i], pairs[i][0])["latents"])
+                           for i in range(B)], 1)
+    loop = EtaLoop(eng, S=S, use_mask=False, guidance_scale_fwd=(1.0, 3.0))
+    assert not loop.skip_uncond_fwd
+    inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
+    assert relerr(inv["latents"].cpu(), ref) < 5e-3
