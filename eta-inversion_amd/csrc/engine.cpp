@@ -110,10 +110,7 @@ struct etainv_engine {
   void *skip[12] = {}, *tmp[3] = {}, *gnbuf = nullptr, *h1 = nullptr, *scbuf = nullptr;
   void *hsA = nullptr, *hsB = nullptr, *lnbuf = nullptr, *qkvbuf = nullptr, *attnbuf = nullptr, *qbuf = nullptr, *kvbuf = nullptr,
        *ffbuf = nullptr, *ctxT = nullptr, *tembuf = nullptr, *temb1 = nullptr, *temb2 = nullptr;
-  float *tprojbuf = nullptr, *gn_scratch = nullptr, *t_dev = nullptr, *maps_acc = nullptr;
-  float* t_host_pinned = nullptr;
-  int t_ring = 0;
-  static constexpr int kTRing = 64;
+  float *tprojbuf = nullptr, *gn_scratch = nullptr, *maps_acc = nullptr;
   size_t maps_bytes = 0;
 };
 
@@ -335,7 +332,6 @@ int build_workspace(etainv_engine* e) {
   want(&e->temb2, B * 1280 * 2);
   want(reinterpret_cast<void**>(&e->tprojbuf), B * (size_t)e->tproj_total * 4);
   want(reinterpret_cast<void**>(&e->gn_scratch), B * (GN_MAX_CHUNKS + 1) * etainv_engine::kGroups * 2 * 4);
-  want(reinterpret_cast<void**>(&e->t_dev), (size_t)etainv_engine::kTRing * B * 4);
   const size_t res = L / 4;
   e->maps_bytes = (size_t)5 * e->max_img * 2 * etainv_engine::kHeads * res * res * 77 * 4;
   want(reinterpret_cast<void**>(&e->maps_acc), e->maps_bytes);
@@ -343,7 +339,6 @@ int build_workspace(etainv_engine* e) {
   ETAINV_HIP(hipMalloc(reinterpret_cast<void**>(&e->wsarena), e->wsbytes));
   for (auto& f : fix) f(e->wsarena);
   ETAINV_HIP(hipMemset(e->maps_acc, 0, e->maps_bytes));
-  ETAINV_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->t_host_pinned), (size_t)etainv_engine::kTRing * B * 4));
   return 0;
 }
 
@@ -506,7 +501,6 @@ extern "C" int etainv_engine_destroy(etainv_engine_t* e) {
   if (!e) return 0;
   if (e->warena) (void)hipFree(e->warena);
   if (e->wsarena) (void)hipFree(e->wsarena);
-  if (e->t_host_pinned) (void)hipHostFree(e->t_host_pinned);
   delete e;
   return 0;
 }
@@ -563,13 +557,8 @@ extern "C" int etainv_unet_forward(etainv_engine_t* e, const void* latent, int n
   const int L = e->L;
   Fwd f{e, s, n_rows, ctrl};
 
-  // timesteps -> device (pinned ring slot, async copy), embedding, MLP, all 22 projections in one GEMM
-  float* th = e->t_host_pinned + (size_t)e->t_ring * e->maxB;
-  float* td = e->t_dev + (size_t)e->t_ring * e->maxB;
-  e->t_ring = (e->t_ring + 1) % etainv_engine::kTRing;
-  for (int i = 0; i < n_rows; ++i) th[i] = (float)t_host[i];
-  ETAINV_HIP(hipMemcpyAsync(td, th, (size_t)n_rows * 4, hipMemcpyHostToDevice, s));
-  if (launch_time_embedding(td, n_rows, etainv_engine::kCh0, e->tembuf, e->dt, s)) return 1;
+  // timesteps (by value in the kernel arguments: no host buffer outlives this call) -> embedding, MLP, all 22 projections in one GEMM
+  if (launch_time_embedding(t_host, n_rows, etainv_engine::kCh0, e->tembuf, e->dt, s)) return 1;
   if (f.gemm(e->tembuf, e->time1, e->temb1, n_rows)) return 1;
   if (launch_silu(e->temb1, e->temb1, (int64_t)n_rows * etainv_engine::kTemb, e->dt, s)) return 1;
   if (f.gemm(e->temb1, e->time2, e->temb2, n_rows)) return 1;

@@ -37,6 +37,12 @@ template <> struct Mfma<bf16> {
 };
 
 constexpr int BK = 64;  // K elements per LDS tile (8 chunks of 16 B per row)
+constexpr int kMaxDevices = 16;
+static inline int current_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return (d >= 0 && d < kMaxDevices) ? d : 0;
+}
 constexpr int64_t SPLITK_WS_BYTES = 64ll << 20;
 
 template <typename T, int BM, int BN, int WAVES_M, int STAGES, bool UPS = false>
@@ -733,10 +739,11 @@ template <typename T, int BM, int BN, int WAVES_M, int STAGES = 2, bool UPS = fa
 static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
   const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN) * (STAGES == 2 && p.ksplit > 1 ? p.ksplit : 1);   // virtual tiles with split-K
   const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(T) + 4 * BN * sizeof(float) + (STAGES == 3 ? 1024 : 0);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[kMaxDevices] = {};   // per device: function attributes and the allocations below belong to the current device
+  const int dev = current_device();
+  if (!attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+    attr_set[dev] = true;
   }
   // persistent grid: as many blocks as are resident at once (LDS-limited: 160 KiB / lds per CU, 256 CUs), a multiple of 8
   const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / lds)));
@@ -796,13 +803,14 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p) {
 }
 
 int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
-  static void* zero_page = nullptr;   // 256 zero bytes read by the halo lanes of the 3x3 taps (one-time allocation)
-  if (!zero_page) {
-    ETAINV_HIP(hipMalloc(&zero_page, 256));
-    ETAINV_HIP(hipMemset(zero_page, 0, 256));
+  static void* zero_pages[kMaxDevices] = {};   // 256 zero bytes read by the halo lanes of the 3x3 taps (one-time allocation per device)
+  const int dev = current_device();
+  if (!zero_pages[dev]) {
+    ETAINV_HIP(hipMalloc(&zero_pages[dev], 256));
+    ETAINV_HIP(hipMemset(zero_pages[dev], 0, 256));
   }
   IGemmParams p = p_in;
-  p.zeros = zero_page;
+  p.zeros = zero_pages[dev];
   if (const char* dbg = getenv("ETAINV_IGEMM_DEBUG")) p.debug = atoi(dbg);
   if (const char* sg = getenv("ETAINV_STAGGER")) p.stagger = atoi(sg);
   ETAINV_CHECK(p.a1 && p.w && p.out, "null pointer");
@@ -848,10 +856,12 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
     }
     IGemmParams pk = p;
     if (ks > 1) {
-      static float* ws = nullptr;   // one-time 64 MiB workspace
-      if (!ws) ETAINV_HIP(hipMalloc(&ws, SPLITK_WS_BYTES));
+      // one-time 64 MiB workspace per device.  Launches on one device are serialised by the caller's stream (the engine runs one stream);
+      // concurrent split-K launches on two streams of the same device would share it.
+      static float* ws[kMaxDevices] = {};
+      if (!ws[dev]) ETAINV_HIP(hipMalloc(&ws[dev], SPLITK_WS_BYTES));
       pk.ksplit = ks;
-      pk.ws = ws;
+      pk.ws = ws[dev];
       pk.bias = nullptr;
       pk.rowvec = nullptr;
       pk.residual = nullptr;

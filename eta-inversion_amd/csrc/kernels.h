@@ -77,8 +77,8 @@ int launch_im2col_in(const void* latent, int io_dtype, int n_lat, int rows, int 
 // conv_out: NHWC T [rows][L*L][cin] (already GroupNorm+SiLU'd) -> NCHW io-dtype [rows][4][L][L]
 int launch_conv_out(const void* x, int rows, int L, int cin, const void* w, const float* bias, void* out, int io_dtype, int dtype,
                     hipStream_t s);
-// sinusoidal timestep embedding (flip_sin_to_cos, freq_shift 0): t [rows] float -> [rows][dim] T
-int launch_time_embedding(const float* t, int rows, int dim, void* out, int dtype, hipStream_t s);
+// sinusoidal timestep embedding (flip_sin_to_cos, freq_shift 0): t_host [rows] (HOST array, passed by value in the kernel arguments) -> [rows][dim] T
+int launch_time_embedding(const int64_t* t_host, int rows, int dim, void* out, int dtype, hipStream_t s);
 // y = silu(x) elementwise on T
 int launch_silu(const void* x, void* out, int64_t n, int dtype, hipStream_t s);
 // cast fp32 -> T with optional row permutation (weights)

@@ -1,5 +1,7 @@
 // Small kernels around the UNet body: conv_in / conv_out (the only convolutions whose channel count is not
 // a multiple of 64; 0.03 % of the FLOPs), sinusoidal timestep embedding, SiLU, weight packing, dtype casts.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -106,15 +108,18 @@ __global__ void im2col_in_kernel(const TIO* __restrict__ x, int n_lat, int L, in
   for (int q = 0; q < 8; ++q) o[q] = reinterpret_cast<u32x4*>(v)[q];
 }
 
+// The timesteps travel BY VALUE in the kernel arguments (one scalar when every row shares it -- always the case in the loops -- else
+// chunks of 64): no host staging buffer that a later call could overwrite before an asynchronous copy has read it.
+struct TimeVec { float t[64]; };
 template <typename T>
-__global__ void time_embedding_kernel(const float* __restrict__ t, int rows, int dim, T* __restrict__ out) {
+__global__ void time_embedding_kernel(TimeVec tv, int uniform, int row0, int rows, int dim, T* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * dim) return;
   const int r = i / dim, c = i - r * dim, half = dim / 2;
   const int k = c < half ? c : c - half;
   const float freq = expf(-9.210340371976184f * (float)k / (float)half);  // ln(10000)
-  const float a = t[r] * freq;
-  out[i] = from_f32<T>(c < half ? cosf(a) : sinf(a));
+  const float a = tv.t[uniform ? 0 : r] * freq;
+  out[(int64_t)row0 * dim + i] = from_f32<T>(c < half ? cosf(a) : sinf(a));
 }
 
 template <typename T>
@@ -201,9 +206,21 @@ int launch_conv_out(const void* x, int rows, int L, int cin, const void* w, cons
   return 0;
 }
 
-int launch_time_embedding(const float* t, int rows, int dim, void* out, int dtype, hipStream_t s) {
-  ETAINV_CHECK(t && out && dim % 2 == 0, "bad arguments");
-  ETAINV_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL(time_embedding_kernel<T>, dim3(cdiv(rows * dim, 256)), dim3(256), 0, s, t, rows, dim, (T*)out));
+int launch_time_embedding(const int64_t* t_host, int rows, int dim, void* out, int dtype, hipStream_t s) {
+  ETAINV_CHECK(t_host && out && dim % 2 == 0 && rows > 0, "bad arguments");
+  bool uniform = true;
+  for (int i = 1; i < rows; ++i) uniform = uniform && t_host[i] == t_host[0];
+  TimeVec tv;
+  if (uniform) {
+    tv.t[0] = (float)t_host[0];
+    ETAINV_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL(time_embedding_kernel<T>, dim3(cdiv(rows * dim, 256)), dim3(256), 0, s, tv, 1, 0, rows, dim, (T*)out));
+  } else {
+    for (int r0 = 0; r0 < rows; r0 += 64) {
+      const int n = std::min(64, rows - r0);
+      for (int i = 0; i < n; ++i) tv.t[i] = (float)t_host[r0 + i];
+      ETAINV_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL(time_embedding_kernel<T>, dim3(cdiv(n * dim, 256)), dim3(256), 0, s, tv, 0, r0, n, dim, (T*)out));
+    }
+  }
   ETAINV_LAUNCH_CHECK();
   return 0;
 }

@@ -72,9 +72,11 @@ class EtaLoop:
         return float(self.ac[tau]) if tau >= 0 else float(self.ac[0])
 
     # ---------------------------------------------------------------- forward / inversion
-    def invert(self, z0, ctx_src, tokens=None):
+    def invert(self, z0, ctx_src, tokens=None, teacher=None):
         """z0 (B,4,L,L) fp32; ctx_src (B,2,77,768) = [uncond, cond] per image; tokens (B,W) int32 token index of each
-        whitespace word (first occurrence + 1).  Returns latents (S+1,B,4,L,L) and the mean word maps (B,W,L,L)."""
+        whitespace word (first occurrence + 1).  Returns latents (S+1,B,4,L,L) and the mean word maps (B,W,L,L).
+        teacher (S+1,B,4,L,L), tests only: step j reads teacher[j] instead of its own previous output (teacher-forced parity:
+        every step is compared with the oracle on the oracle's input, so rounding is not amplified by the recursion)."""
         e, S, L = self.e, self.S, self.L
         B = z0.shape[0]
         dev = z0.device
@@ -99,13 +101,14 @@ class EtaLoop:
         n = B * 4 * L * L
         st = _capi.stream_ptr()
         for j, t in enumerate(self.t_fwd):
-            e.unet(lat[j], int(t), ctx, ctrl, out=eps_all)
+            x_in = lat[j] if teacher is None else teacher[j].contiguous()
+            e.unet(x_in, int(t), ctx, ctrl, out=eps_all)
             if not self.skip_uncond_fwd:
                 g = float(self.g_fwd_table[int(t)]) if self.g_fwd_table is not None else self.g_fwd
                 _capi.check(self.lib.etainv_cfg_combine(_capi.ptr(eps_all[:B]), _capi.ptr(eps_all[B:]), g, _capi.ptr(eps), n,
                                                         _capi.F32, st))
             a_from, a_to = self._alpha(int(t) - self.delta), self._alpha(int(t))   # "sameshift" (scheduling_ddim_inverse.py:127-131)
-            _capi.check(self.lib.etainv_ddim_step(_capi.ptr(lat[j]), _capi.ptr(eps), a_from, a_to, _capi.ptr(lat[j + 1]), n, _capi.F32, st))
+            _capi.check(self.lib.etainv_ddim_step(_capi.ptr(x_in), _capi.ptr(eps), a_from, a_to, _capi.ptr(lat[j + 1]), n, _capi.F32, st))
             if self.use_mask:
                 e.word_maps(B, tokens, j + 1, maps_mean, accumulate=True, scale=1.0 / S)
                 if maps_steps is not None:
@@ -113,10 +116,12 @@ class EtaLoop:
         return {"latents": lat, "maps_mean": maps_mean, "maps_steps": maps_steps}
 
     # ---------------------------------------------------------------- backward / eta sampling
-    def sample(self, inv, ctx_src, ctx_tgt, noise, edit_word=None, ptp=None, masactrl=None, trace=None, gt_mask=None, edit_word_tgt=None):
+    def sample(self, inv, ctx_src, ctx_tgt, noise, edit_word=None, ptp=None, masactrl=None, trace=None, gt_mask=None, edit_word_tgt=None,
+               teacher=None):
         """noise (S,n_cand,4,L,L) fp32: the candidates of every step (reference draws them from a generator reseeded
         per image, eta_inversion.py:156,276, so all images share the table).  edit_word (B,) index into the word maps.
-        ptp: PtpTables or None; masactrl: (start_step, first_block) or None.  Returns latents (2B,4,L,L) [src.., tgt..]."""
+        ptp: PtpTables or None; masactrl: (start_step, first_block) or None.  Returns latents (2B,4,L,L) [src.., tgt..].
+        teacher (S,2B,4,L,L), tests only: step i starts from teacher[i] (see invert)."""
         e, S, L = self.e, self.S, self.L
         lat_inv = inv["latents"]
         B = lat_inv.shape[1]
@@ -165,6 +170,8 @@ class EtaLoop:
                                    self_replace_active=ptp.self_lo <= i < ptp.self_hi, self_max_tokens=(L // 2) ** 2)
             elif masactrl is not None:
                 ctrl = AttnControl(mode=_capi.ATTN_MASA, n_img=B, masa_active=masactrl[0] <= i < 50, masa_first_block=masactrl[1])
+            if teacher is not None:
+                x.copy_(teacher[i])
             e.unet(x, t, ctx, ctrl, out=eps_all)
             p = t - self.delta
             a_t, a_p = float(self.ac[t]), (float(self.ac[p]) if p >= 0 else float(self.ac[0]))

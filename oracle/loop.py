@@ -50,15 +50,30 @@ def ptp_hook(controller):
 class MasaCtrl:
     """MutualSelfAttentionControl(start_step=4, start_layer=10, total_steps=50): masactrl.py:20-72."""
 
-    def __init__(self, start_step=4, start_layer=10, total_steps=50, total_layers=16, num_att_layers=32):
+    def __init__(self, start_step=4, start_layer=10, total_steps=50, total_layers=16, num_att_layers=32, fast_n=2304):
         self.step_idx = list(range(start_step, total_steps))
         self.layer_idx = list(range(start_layer, total_layers))
         self.cur_step, self.cur_att_layer, self.num_att_layers = 0, 0, num_att_layers
+        # more than fast_n query tokens: the same softmax(q k^T) v through torch's fused SDPA, so that the 9216 x 9216 probabilities
+        # of a 768^2 image (5.4 GB per half in fp32) are never materialised on the CPU; checked against the literal path in
+        # tests/test_oracle_golden.py
+        self.fast_n = fast_n
 
     def __call__(self, is_cross, layer_idx, place, q, k, v, scale, heads):
         active = (not is_cross) and self.cur_step in self.step_idx and (self.cur_att_layer // 2) in self.layer_idx
+        sdpa = torch.nn.functional.scaled_dot_product_attention
         if not active:
-            out = _merge_heads(torch.einsum("bij,bjd->bid", _plain(q, k, v, scale), v), heads)
+            if q.shape[1] > self.fast_n:
+                out = _merge_heads(sdpa(q, k, v, scale=scale), heads)
+            else:
+                out = _merge_heads(torch.einsum("bij,bjd->bid", _plain(q, k, v, scale), v), heads)
+        elif q.shape[1] > self.fast_n:
+            outs = []
+            for qh, kh, vh in zip(q.chunk(2), k.chunk(2), v.chunk(2)):      # uncond half, cond half: K, V of the half's source sample
+                b = qh.shape[0] // heads
+                o = sdpa(qh.reshape(b, heads, *qh.shape[1:]), kh[:heads][None], vh[:heads][None], scale=scale)
+                outs.append(o.permute(0, 2, 1, 3).reshape(b, qh.shape[1], -1))
+            out = torch.cat(outs, dim=0)
         else:
             outs = []
             for qh, kh, vh in zip(q.chunk(2), k.chunk(2), v.chunk(2)):      # uncond half, cond half

@@ -113,6 +113,8 @@ def install_stubs():
     _mod("diffusers.pipelines.stable_diffusion.pipeline_stable_diffusion", False, StableDiffusionPipeline=_Dummy)
     _mod("diffusers.models")
     _mod("diffusers.models.unet_2d_condition", False, UNet2DConditionOutput=_Dummy, UNet2DConditionModel=_Dummy)
+    _mod("diffusers.models.attention_processor", False, Attention=_Dummy)
+    _mod("diffusers.models.resnet", False, ResnetBlock2D=_Dummy)
     _mod("cv2", False)
     tv = _mod("torchvision")
     tvu = _mod("torchvision.utils", False, save_image=lambda *a, **k: None)
@@ -551,8 +553,37 @@ def gen_pie_bench():
     save("pie_bench_masks", **masks)
 
 
+def gen_resnet_block():
+    """The reference's in-tree restatement of [3P] diffusers ResnetBlock2D.forward (modules/utils/pnp_utils.py:136-185, installed by
+    register_conv_control_efficient on unet.up_blocks[1].resnets[1]) run on the ORACLE's ResnetBlock2D parameters: pins the residual block
+    arithmetic of oracle/unet.py (GroupNorm -> SiLU -> conv3x3 -> + time_emb_proj(SiLU(temb)) -> GroupNorm -> SiLU -> conv3x3 -> + shortcut)
+    at SD1.x width (cat input 2560 -> 1280 with a 1x1 shortcut, the block the reference patches) and at a same-width block (no shortcut)."""
+    import torch.nn.functional as F
+    from modules.utils.pnp_utils import register_conv_control_efficient
+    from oracle.unet import ResnetBlock2D, synthetic_tensor
+    out = {}
+    for tag, (cin, cout, hw) in {"up1r1": (2560, 1280, 8), "same": (320, 320, 16)}.items():
+        blk = ResnetBlock2D(cin, cout).eval()
+        for n, prm in blk.named_parameters():
+            prm.copy_(synthetic_tensor(f"pin.{tag}.{n}", prm.shape, 3))
+        g = torch.Generator().manual_seed(cin + hw)
+        x = torch.randn(2, cin, hw, hw, generator=g)
+        temb = torch.randn(2, 1280, generator=g)
+        # attributes of the diffusers module that the reference's forward reads and the oracle's module does not carry
+        blk.nonlinearity, blk.upsample, blk.downsample = F.silu, None, None
+        blk.time_embedding_norm, blk.output_scale_factor, blk.dropout = "default", 1.0, torch.nn.Identity()
+        blk.t = 5
+        fake = types.SimpleNamespace(unet=types.SimpleNamespace(up_blocks=[None, types.SimpleNamespace(resnets=[None, blk])]))
+        register_conv_control_efficient(fake, torch.tensor([999]))      # t = 5 is not in the schedule: no feature injection
+        y = blk.forward(x, temb)                                         # the reference's conv_forward
+        # inputs and weights are regenerated from their seeds by the test (oracle.unet.synthetic_tensor + torch.Generator): only a probe is stored
+        out.update({f"{tag}_x_probe": x.flatten()[:8], f"{tag}_y": y.to(torch.float32)})
+    save("resnet_block", **out)
+
+
 GENS = {"schedule": gen_schedule, "ddim_inverse": gen_ddim_inverse, "eta_step": gen_eta_step, "eta_step_modes": gen_eta_step_modes, "eta_step_dirinv": gen_eta_step_dirinv,
-        "ptp_tables": gen_ptp_tables, "ptp_algebra": gen_ptp_algebra, "masactrl": gen_masactrl, "e2e": gen_e2e, "e2e_dirinv": gen_e2e_dirinv, "e2e_bwdmask": gen_e2e_bwdmask, "pie_bench": gen_pie_bench}
+        "ptp_tables": gen_ptp_tables, "ptp_algebra": gen_ptp_algebra, "masactrl": gen_masactrl, "e2e": gen_e2e, "e2e_dirinv": gen_e2e_dirinv, "e2e_bwdmask": gen_e2e_bwdmask, "pie_bench": gen_pie_bench,
+        "resnet_block": gen_resnet_block}
 
 
 if __name__ == "__main__":

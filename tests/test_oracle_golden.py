@@ -183,6 +183,11 @@ def test_masactrl(golden):
         q, k, v = (torch.from_numpy(g[f"{c}/{n}"]) for n in "qkv")
         out = m(layer % 2 == 1, layer, "up", q, k, v, q.shape[-1] ** -0.5, 8)
         np.testing.assert_allclose(out.numpy(), g[f"{c}/out"], rtol=1e-5, atol=1e-6, err_msg=c)
+        # the fused-SDPA path used above fast_n tokens (768^2 images) is the same function: force it on the reference's cases
+        m2 = oloop.MasaCtrl(4, 10, fast_n=0)
+        m2.cur_step, m2.cur_att_layer = step, layer
+        out2 = m2(layer % 2 == 1, layer, "up", q, k, v, q.shape[-1] ** -0.5, 8)
+        np.testing.assert_allclose(out2.numpy(), g[f"{c}/out"], rtol=1e-5, atol=2e-6, err_msg=c + " (sdpa)")
 
 
 # ----------------------------------------------------------------------------- end-to-end loop replay
@@ -284,3 +289,22 @@ def test_clip_oracle_matches_transformers():
         want = hf(ids)[0]
         got = ora(ids)[0]
     torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag,cin,cout,hw", [("up1r1", 2560, 1280, 8), ("same", 320, 320, 16)])
+def test_resnet_block_matches_reference_restatement(golden, tag, cin, cout, hw):
+    """oracle.unet.ResnetBlock2D vs the reference's own restatement of the [3P] diffusers forward (pnp_utils.py:136-185) run on the
+    same parameters (fixture: tests/golden/make_golden.py gen_resnet_block): pins the residual block of the oracle UNet numerically."""
+    from oracle.unet import ResnetBlock2D, synthetic_tensor
+    g = golden("resnet_block")
+    blk = ResnetBlock2D(cin, cout).eval()
+    with torch.no_grad():
+        for n, prm in blk.named_parameters():
+            prm.copy_(synthetic_tensor(f"pin.{tag}.{n}", prm.shape, 3))
+        gen = torch.Generator().manual_seed(cin + hw)
+        x = torch.randn(2, cin, hw, hw, generator=gen)
+        temb = torch.randn(2, 1280, generator=gen)
+        assert np.array_equal(x.flatten()[:8].numpy(), g[f"{tag}_x_probe"])
+        y = blk(x, temb)
+    ref = torch.from_numpy(g[f"{tag}_y"])
+    assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5), float((y - ref).abs().max())
