@@ -331,6 +331,287 @@ __global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qk
   }
 }
 
+// ------------------------------------------------------------------------------------------------ self, head_dim 40 (v2)
+// The 64^2- and 96^2-token levels (N = 4096 / 9216, d = 40) are 85 % of the self-attention FLOPs of the UNet and ran at 23 % of the MFMA
+// peak in the generic kernel above: the loop is bound by the SIMD's vector-issue port (PMC: 40 % of wave cycles issuing, 79 % of that
+// VALU), with one v_exp_f32 (8 issue cycles) per 160 FLOPs.  This kernel removes everything else from the per-element path:
+//   * v_mfma_f32_32x32x16 for both products: an MFMA holds the issue port 8 of its 32 cycles (16x16x32: 8 of 16), and K = 16 steps pad
+//     40 -> 48 (not 64) in S^T = K Q^T.  Query on lane & 31, the 16 accumulator registers of a 32-key block are directly the B operand
+//     of two K = 16 steps of O^T = V^T P^T (keys taken in the order the accumulator holds them: step s <- registers 8s .. 8s+7, i.e.
+//     key 16s + 8(j>>2) + 4h + (j&3) in element j of lane half h; V^T is read in that same order);
+//   * the softmax scale * log2(e) is folded into the to_q weights by the engine (q_scale = 1; the raw-op entry point rescales Q once
+//     at load), and the running reference maximum m' enters through the MFMA itself: padding dimension 40 of every K row is 1 and the
+//     query operand carries -m' there, so the accumulator IS the exponent argument: p = exp2(acc), no subtract, no multiply;
+//   * m' only moves when a tile exceeds it by 2^8 (wave-uniform test; the first tile always sets it): no per-tile rescale of the
+//     output accumulators.  P is bounded by 2^8 (fits f16), its relative precision is scale-independent, O and the denominators
+//     accumulate in fp32.  m' is kept representable in the operand type, so the value the MFMA subtracts and the value the rescale
+//     uses are the same number;
+//   * the softmax denominator is row 40 of O^T: the pad chunk of every V row is (1, 0, ...), the MFMA sums p for free;
+//   * V stays row-major [key][48] in LDS (16-byte staging stores, no 2-byte transposition: 39 % of the LDS cycles of the generic kernel
+//     were bank conflicts of those stores) and is read transposed by ds_read_b64_tr_b16.
+// Per 64-key tile and 32-query block: 14 MFMAs (448 matrix cycles), 32 v_exp + 16 v_max3 + 16 v_cvt_pk (~400 issue cycles).
+template <typename T> struct Frag32;
+template <> struct Frag32<f16> {
+  static __device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Frag32<bf16> {
+  static __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int A40_KV = 64;                 // keys per tile
+constexpr int A40_KROW = 56;               // K row: 40 dims + pad chunk (1, 0 x 7) + 8 unused = 112 B (7 chunks: conflict-free ds_read_b128)
+constexpr int A40_VROW = 48;               // V row: 40 dims + pad chunk (1, 0 x 7) = 96 B
+constexpr int A40_KBUF = A40_KV * A40_KROW, A40_VBUF = A40_KV * A40_VROW;
+constexpr size_t A40_LDS = (size_t)(2 * A40_KBUF + 3 * A40_VBUF) * 2;   // 2 K + 2 V buffers + one all-zero V image (rows 48..63 of V^T)
+constexpr float A40_THR = 8.0f;
+
+template <typename T, bool XCD_REMAP>
+__global__ void __launch_bounds__(256, 2) self_attn40_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads, float q_scale,
+                                                             int mode, int n_img, int nqb) {
+  typedef typename Frag<T>::v8 v8;
+  constexpr int D = 40, KV = A40_KV, QB = 2, KROW = A40_KROW, VROW = A40_VROW, KBUF = A40_KBUF, VBUF = A40_VBUF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sK = reinterpret_cast<T*>(smem);      // [2][KV][KROW]
+  T* sV = sK + 2 * KBUF;                   // [2][KV][VROW]
+  T* sZ = sV + 2 * VBUF;                   // [KV][VROW] zeros
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  // block -> (query block, head, batch row).  XCD_REMAP: the nqb query blocks of one (row, head) share its K / V (655 KB at N = 4096);
+  // blocks b and b + 8 run on the same XCD (round-robin dispatch), so all blocks of a (row, head) are given ids of one residue class
+  // and read K / V from that XCD's L2 (speed only: any placement computes the same thing)
+  int qblk, hd, b;
+  if (XCD_REMAP) {
+    const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+    const int set = (slot / nqb) * 8 + xcd;
+    qblk = slot - (slot / nqb) * nqb;
+    hd = set % heads;
+    b = set / heads;
+  } else {
+    qblk = blockIdx.x;
+    hd = blockIdx.y;
+    b = blockIdx.z;
+  }
+  const int C = heads * D, C3 = 3 * C;
+  int bq = b, bk = b, bv = b;
+  if (mode != 0) {
+    int half, role, img;
+    row_roles(b, n_img, half, role, img);
+    if (mode == 1 && half == 1 && role == 1) { bq = b - n_img; bk = b - n_img; }
+    if (mode == 2 && role == 1) { bk = b - n_img; bv = b - n_img; }
+  }
+  const int q_base = qblk * 256 + wid * 64;
+
+  // ---- one-time LDS constants: pad chunks (1, 0 x 7) of every K and V row of both buffers, the all-zero V image
+  {
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    u32x4 one4 = zero4;
+    {
+      T one[2] = {(T)1.0f, (T)0.0f};
+      one4[0] = *reinterpret_cast<unsigned*>(one);
+    }
+    for (int idx = tid; idx < 2 * KV; idx += 256) {
+      *reinterpret_cast<u32x4*>(sK + idx * KROW + D) = one4;
+      *reinterpret_cast<u32x4*>(sK + idx * KROW + D + 8) = zero4;
+      *reinterpret_cast<u32x4*>(sV + idx * VROW + D) = one4;
+    }
+    for (int idx = tid; idx < VBUF / 8; idx += 256) *reinterpret_cast<u32x4*>(sZ + idx * 8) = zero4;
+  }
+
+  // ---- Q fragments (B operand of S^T): lane (query r, half h) holds dims 16 s + 8 h .. + 7 of K step s; dims 40 .. 47 (step 2, h = 1)
+  // are the pad dimensions: element 0 carries -m' (set below), the rest 0
+  v8 qf[QB][3];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    int query = q_base + qb * 32 + r;
+    query = query < N ? query : N - 1;
+    const T* qp = qkv + ((int64_t)bq * N + query) * C3 + hd * D;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int d0 = s * 16 + h * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (d0 < D) v = *reinterpret_cast<const u32x4*>(qp + d0);
+      v8 q = *reinterpret_cast<v8*>(&v);
+      if (q_scale != 1.0f) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = (T)((float)q[j] * q_scale);
+      }
+      qf[qb][s] = q;
+    }
+  }
+
+  // ---- K / V staging through registers: 320 16-byte chunks each per tile (64 keys x 5 chunks), 2 per thread (threads >= 64 take one)
+  u32x4 rk[2], rv[2];
+  const T* kbase = qkv + (int64_t)bk * N * C3 + C + hd * D;
+  const T* vbase = qkv + (int64_t)bv * N * C3 + 2 * C + hd * D;
+  int st_row[2], st_ch[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i;
+    st_row[i] = c / 5;
+    st_ch[i] = c - st_row[i] * 5;
+  }
+  auto load_kv = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      u32x4 a = {0u, 0u, 0u, 0u}, c = {0u, 0u, 0u, 0u};
+      if (tid + 256 * i < KV * 5 && kv0 + st_row[i] < N) {          // keys past N: zeros (finite), masked in the scores
+        const int64_t off = (int64_t)(kv0 + st_row[i]) * C3 + st_ch[i] * 8;
+        a = *reinterpret_cast<const u32x4*>(kbase + off);
+        c = *reinterpret_cast<const u32x4*>(vbase + off);
+      }
+      rk[i] = a;
+      rv[i] = c;
+    }
+  };
+  auto store_kv = [&](int bufi) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (tid + 256 * i < KV * 5) {
+        *reinterpret_cast<u32x4*>(sK + bufi * KBUF + st_row[i] * KROW + st_ch[i] * 8) = rk[i];
+        *reinterpret_cast<u32x4*>(sV + bufi * VBUF + st_row[i] * VROW + st_ch[i] * 8) = rv[i];
+      }
+  };
+
+  // ---- per-lane LDS read offsets (elements)
+  const int kA = r * KROW + h * 8;                                    // K A-operand: key r of the 32-key block, dims 16 s + 8 h
+  const int gi = lane & 15, vg = (lane >> 4) & 1, vq = gi >> 2, vp = gi & 3;
+  const int vA = (4 * h + vq) * VROW + 16 * vg + 4 * vp;              // V^T A-operand through ds_read_b64_tr_b16: lane 4q+p of a 16-lane group
+                                                                      // addresses row (key) q, columns (dims) 4p .. 4p+3 of a 4 x 16 block
+
+  float mref[QB];
+  f32x16 o[QB][2];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    mref[qb] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[qb][dt][i] = 0.f;
+  }
+
+  const int ntiles = (N + KV - 1) / KV;
+  const int nfull = N / KV;
+  load_kv(0);
+  store_kv(0);
+  __syncthreads();
+
+  auto tile_body = [&](int j, auto ragged_tag) {
+    constexpr bool RAGGED = decltype(ragged_tag)::value;
+    const int kv0 = j * KV, cur = j & 1;
+    if (j + 1 < ntiles) load_kv(kv0 + KV);
+    const T* tK = sK + cur * KBUF + kA;
+    const T* tV0 = sV + cur * VBUF + vA;                              // dims 0 .. 31
+    const T* tV1 = vg ? (sZ + vA - 16) : (sV + cur * VBUF + vA + 32);   // dims 32 .. 47 (incl. the ones column); rows 48 .. 63 of V^T are zero
+
+    // ---- S'^T = K Q^T - m' : s[qb][kb] register i = key kb*32 + (i&3) + 8(i>>2) + 4h, query r
+    f32x16 s[QB][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int st = 0; st < 3; ++st) {
+        const v8 kf = *reinterpret_cast<const v8*>(tK + kb * 32 * KROW + st * 16);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          if (st == 0) {
+            f32x16 z;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[i] = 0.f;
+            s[qb][kb] = Frag32<T>::mfma(kf, qf[qb][st], z);
+          } else {
+            s[qb][kb] = Frag32<T>::mfma(kf, qf[qb][st], s[qb][kb]);
+          }
+        }
+      }
+    if constexpr (RAGGED) {   // only the last tile of a sequence that is not a multiple of 64 keys
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= N) s[qb][kb][i] = NEG_BIG;
+    }
+
+    // ---- reference maximum: moves only when a query exceeds it by 2^THR (or on the first tile)
+    float mx[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float m = fmaxf(fmaxf(s[qb][0][0], s[qb][0][1]), s[qb][0][2]);
+#pragma unroll
+      for (int e = 3; e + 1 < 32; e += 2) m = fmaxf(fmaxf(m, s[qb][e >> 4][e & 15]), s[qb][(e + 1) >> 4][(e + 1) & 15]);
+      m = fmaxf(m, s[qb][1][15]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+      mx[qb] = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));   // both key halves of the query
+    }
+    const bool first = j == 0;
+    if (first || __builtin_amdgcn_ballot_w64(fmaxf(mx[0], mx[1]) > A40_THR) != 0) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        const float d = first ? mx[qb] : fmaxf(mx[qb], 0.f);
+        const T mt = (T)(mref[qb] + d);                                // m' stays representable in the operand type
+        const float mnew = (float)mt, de = mnew - mref[qb];
+        mref[qb] = mnew;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s[qb][kb][i] -= de;
+        if (!first) {
+          const float f = __builtin_amdgcn_exp2f(-de);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[qb][dt][i] *= f;
+        }
+        if (h == 1) qf[qb][2][0] = (T)(-mnew);
+      }
+    }
+
+    // ---- P = exp2(S') packed straight into the PV operands, O^T += V^T P^T
+    v8 pf[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[qb][ks][e] = (T)__builtin_amdgcn_exp2f(s[qb][ks >> 1][(ks & 1) * 8 + e]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const T* vp_ = (dt ? tV1 : tV0) + ks * 16 * VROW;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp_));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp_ + 8 * VROW));
+          const v8 vf = __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          o[qb][dt] = Frag32<T>::mfma(vf, pf[qb][ks], o[qb][dt]);
+        }
+    }
+
+    if (j + 1 < ntiles) store_kv(cur ^ 1);   // buffer cur^1 was last read in iteration j-1, a barrier ago
+    __syncthreads();
+  };
+  for (int j = 0; j < nfull; ++j) tile_body(j, std::false_type{});
+  if (nfull < ntiles) tile_body(nfull, std::true_type{});
+
+  // ---- normalise and store: lane (query r, half h) holds dims (i&3) + 8(i>>2) + 4h (+32); the denominator is row 40 = tile 1, register 4, h = 0
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const float l = __shfl(o[qb][1][4], r, 64);
+    const float inv = 1.f / l;
+    const int query = q_base + qb * 32 + r;
+    if (query >= N) continue;
+    T* op = out + ((int64_t)b * N + query) * C + hd * D + 4 * h;
+#pragma unroll
+    for (int g4 = 0; g4 < 5; ++g4) {
+      const int dt = g4 >> 2, i0 = (g4 & 3) * 4;
+      T v[4] = {(T)(o[qb][dt][i0] * inv), (T)(o[qb][dt][i0 + 1] * inv), (T)(o[qb][dt][i0 + 2] * inv), (T)(o[qb][dt][i0 + 3] * inv)};
+      *reinterpret_cast<u32x2*>(op + 8 * g4) = *reinterpret_cast<u32x2*>(v);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ cross
 template <typename T, int D, int QT>
 __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ kv, T* __restrict__ out,
@@ -551,10 +832,40 @@ static int launch_self_t(const void* qkv, void* out, int b, int n, int heads, in
   return 0;
 }
 
+bool self_attn40_v2_enabled() {
+  static const bool on = getenv("ETAINV_ATT_OLD") == nullptr;
+  return on;
+}
+
+template <typename T>
+static int launch_self40(const void* qkv, void* out, int b, int n, int heads, int mode, int n_img, int q_prescaled, hipStream_t s) {
+  static bool attr[2] = {false, false};
+  const int nqb = cdiv(n, 256);
+  const bool remap = ((b * heads) % 8) == 0;
+  if (!attr[remap]) {
+    if (remap) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn40_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)A40_LDS);
+    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn40_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)A40_LDS);
+    attr[remap] = true;
+  }
+  const float q_scale = q_prescaled ? 1.0f : (1.0f / sqrtf(40.f)) * 1.4426950408889634f;
+  ProfScope prof(PROF_SELF_ATTN, 4.0 * (double)b * heads * (double)n * (double)n * 40, s);
+  if (remap)
+    hipLaunchKernelGGL((self_attn40_kernel<T, true>), dim3(nqb * heads * b), dim3(256), A40_LDS, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb);
+  else
+    hipLaunchKernelGGL((self_attn40_kernel<T, false>), dim3(nqb, heads, b), dim3(256), A40_LDS, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb);
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int heads, int d, int mode, int n_img, int dtype,
-                               hipStream_t s) {
+                               hipStream_t s, int q_prescaled) {
   ETAINV_CHECK(qkv && out && b > 0 && n > 0, "bad arguments");
   ETAINV_CHECK(mode == 0 || (n_img > 0 && b == 4 * n_img), "ptp / masactrl modes need the 4*n_img backward layout");
+  ETAINV_CHECK(!q_prescaled || d == 40, "pre-scaled queries: head_dim 40 only");
+  ETAINV_CHECK(!q_prescaled || self_attn40_v2_enabled(), "pre-scaled queries need the d = 40 kernel");
+  if (d == 40 && self_attn40_v2_enabled()) {
+    ETAINV_DISPATCH_HALF(dtype, T, return launch_self40<T>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s));
+  }
   ETAINV_DISPATCH_HALF(dtype, T, switch (d) {
     case 40: return launch_self_t<T, 40>(qkv, out, b, n, heads, mode, n_img, s);
     case 80: return launch_self_t<T, 80>(qkv, out, b, n, heads, mode, n_img, s);

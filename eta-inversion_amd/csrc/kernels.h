@@ -48,8 +48,11 @@ int launch_layernorm(const void* x, const float* gamma, const float* beta, void*
 // ---- attention.hip
 // self-attention modes: 0 plain; 1 ptp self-replace (cond target rows use Q,K of their source row);
 // 2 masactrl (target rows use K,V of their source row).  Modes 1/2 need the 4*n_img backward row layout.
+// A/B switch ETAINV_ATT_OLD: head_dim 40 on the generic 16x16x32 kernel (then the engine does not fold the scale into to_q)
+bool self_attn40_v2_enabled();
+// q_prescaled (d == 40 only): the queries already carry softmax scale * log2(e) (the engine folds it into the to_q weights)
 int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int heads, int d, int mode, int n_img, int dtype,
-                               hipStream_t s);
+                               hipStream_t s, int q_prescaled = 0);
 struct CrossParams {
   int N = 0, heads = 8, n_ctx = 77;
   float scale_log2 = 0.f;
@@ -82,7 +85,7 @@ int launch_time_embedding(const int64_t* t_host, int rows, int dim, void* out, i
 // y = silu(x) elementwise on T
 int launch_silu(const void* x, void* out, int64_t n, int dtype, hipStream_t s);
 // cast fp32 -> T with optional row permutation (weights)
-int launch_pack_weight(const float* src, void* dst, int64_t rows, int64_t cols, int mode, int taps, int dtype, hipStream_t s);
+int launch_pack_weight(const float* src, void* dst, int64_t rows, int64_t cols, int mode, int taps, int dtype, hipStream_t s, float scale = 1.0f);
 int launch_cast_f32(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, hipStream_t s);
 
 // ---- maps.hip

@@ -28,6 +28,11 @@ __global__ void __launch_bounds__(256) word_maps_kernel(const float* __restrict_
   const int img = blockIdx.y, ti = blockIdx.x;
   const int tok = tokens[img * n_tok + ti];
   const int RR = res * res;
+  if (tok < 0 || tok >= 77) {   // a word index past the 77-token context (the reference raises IndexError, ptp.py:296): poison the map, never read out of range
+    float* o = out + ((int64_t)img * n_tok + ti) * L * L;
+    for (int p = threadIdx.x; p < L * L; p += blockDim.x) o[p] = __builtin_nanf("");
+    return;
+  }
   float lmax = -3.0e38f;
   for (int pix = threadIdx.x; pix < RR; pix += blockDim.x) {
     float s = 0.f;

@@ -137,7 +137,7 @@ __global__ void silu_kernel(const T* x, T* out, int64_t n) {
 //   mode 4: conv_out [4][I][3][3] -> [tap][I][4]                         (rows = 4, cols = I*9)
 //   mode 5: conv_in as a K = 64 GEMM: [O][4][3][3] -> [O][64], k = tap*4 + ci, k >= 36 zero   (rows = O, cols = 36)
 template <typename TD>
-__global__ void pack_weight_kernel(const float* __restrict__ src, TD* __restrict__ dst, int64_t rows, int64_t cols, int mode, int taps) {
+__global__ void pack_weight_kernel(const float* __restrict__ src, TD* __restrict__ dst, int64_t rows, int64_t cols, int mode, int taps, float scale) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (mode == 5) {
     if (i >= rows * 64) return;
@@ -165,7 +165,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, TD* __restrict
     const int64_t tap = i / (cin * 4), r = i - tap * cin * 4, ci = r / 4, o = r - ci * 4;
     s = o * cols + ci * 9 + tap;
   }
-  dst[i] = from_f32<TD>(src[s]);
+  dst[i] = from_f32<TD>(src[s] * scale);   // scale: 1, or a constant folded into the weights in fp32 BEFORE the rounding (softmax scale of to_q)
 }
 
 template <typename TS, typename TD>
@@ -231,10 +231,10 @@ int launch_silu(const void* x, void* out, int64_t n, int dtype, hipStream_t s) {
   return 0;
 }
 
-int launch_pack_weight(const float* src, void* dst, int64_t rows, int64_t cols, int mode, int taps, int dtype, hipStream_t s) {
+int launch_pack_weight(const float* src, void* dst, int64_t rows, int64_t cols, int mode, int taps, int dtype, hipStream_t s, float scale) {
   ETAINV_CHECK(src && dst && rows > 0 && cols > 0, "bad arguments");
   const int64_t n = mode == 5 ? rows * 64 : rows * cols;
-  ETAINV_DISPATCH_DTYPE(dtype, TD, hipLaunchKernelGGL(pack_weight_kernel<TD>, dim3(cdiv(n, 256)), dim3(256), 0, s, src, (TD*)dst, rows, cols, mode, taps));
+  ETAINV_DISPATCH_DTYPE(dtype, TD, hipLaunchKernelGGL(pack_weight_kernel<TD>, dim3(cdiv(n, 256)), dim3(256), 0, s, src, (TD*)dst, rows, cols, mode, taps, scale));
   ETAINV_LAUNCH_CHECK();
   return 0;
 }

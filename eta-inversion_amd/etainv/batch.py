@@ -32,6 +32,8 @@ class BatchEditor:
     @staticmethod
     def _word_tokens(prompts: List[str]) -> torch.Tensor:
         rows = [[p.split(" ").index(w) + 1 for w in p.split(" ")] for p in prompts]      # ptp_editor.py:72 (first occurrence)
+        if max(len(r) for r in rows) > 75:
+            raise IndexError("a prompt has more than 75 whitespace words: word maps index the 77-token context (ptp.py:296)")
         W = max(len(r) for r in rows)
         return torch.tensor([r + [0] * (W - len(r)) for r in rows], dtype=torch.int32)
 

@@ -58,10 +58,9 @@ class EtaLoop:
         self.use_mask, self.mask_thres = use_mask, mask_thres
         # non-default eta-mask modes (reference eta_inversion.py:164-201): source of the map (fwd_mean | fwd | gt), thres None = soft, pow
         self.mask_eta, self.mask_pow = mask_eta, mask_pow
-        # target_dirinv w: x_tgt += w (1 - mask_dirinv) (x_prev_src - x_src_new)  (eta_inversion.py:251-256); mask_dirinv must name the
-        # same map source as mask_eta (or None)
+        # target_dirinv w: x_tgt += w (1 - mask_dirinv) (x_prev_src - x_src_new)  (eta_inversion.py:251-256); mask_dirinv names its own map
+        # source (any of the mask_eta sources) or None
         self.target_dirinv, self.mask_dirinv = target_dirinv, mask_dirinv
-        assert mask_dirinv is None or mask_dirinv == mask_eta, "mask_dirinv: same source as mask_eta"
         assert target_dirinv is None or use_mask, "target_dirinv is part of the masked update"
         # u + 1*(c - u) == c up to rounding: the uncond half of the forward pass is dead work when g_fwd == 1
         self.skip_uncond_fwd = skip_uncond_fwd and self.g_fwd == 1.0 and self.g_fwd_table is None
@@ -94,7 +93,7 @@ class EtaLoop:
         if self.use_mask:
             assert tokens is not None
             maps_mean = torch.zeros(B, tokens.shape[1], L, L, dtype=torch.float32, device=dev)
-            if self.mask_eta == "fwd":                                            # per-step maps, keyed by step (eta_inversion.py:44-49,168)
+            if "fwd" in (self.mask_eta, self.mask_dirinv):                        # per-step maps, keyed by step (eta_inversion.py:44-49,168)
                 maps_steps = torch.zeros(S, B, tokens.shape[1], L, L, dtype=torch.float32, device=dev)
             ctrl = AttnControl(mode=_capi.ATTN_STORE, n_img=B, store_maps=True)
             e.maps_reset()
@@ -132,32 +131,44 @@ class EtaLoop:
         eps_all = torch.empty(4 * B, 4, L, L, dtype=torch.float32, device=dev)
         best = torch.zeros(B, dtype=torch.int32, device=dev)
         scratch = torch.empty(B * 16 * 64, dtype=torch.float32, device=dev)
-        mask_map, mask_mode, bwd = None, int(self.use_mask), False
+        mask_map, mask_mode = None, int(self.use_mask)
+        src_map = shaped = None
         if self.use_mask:
             idx = edit_word.to(dev).long().reshape(B, 1, 1, 1).expand(B, 1, L, L)
             final = self.mask_thres is None or self.mask_pow is not None or self.mask_eta != "fwd_mean"
+            mask_mode = 2 if final else 1                                           # 2: the map is the per-pixel eta multiplier
+            sources = {self.mask_eta, self.mask_dirinv} - {None}
+            if any(sname.startswith("bwd") for sname in sources):                    # maps of the backward-pass store (eta_inversion.py:176-183)
+                assert ptp is not None, "bwd_* masks read the prompt-to-prompt controller's maps"
+                tok_s = (edit_word.to(dev).int() + 1).reshape(B, 1).contiguous()
+                tok_t = ((edit_word_tgt if edit_word_tgt is not None else edit_word).to(dev).int() + 1).reshape(B, 1).contiguous()
+                map_s = torch.empty(B, 1, L, L, dtype=torch.float32, device=dev)
+                map_t = torch.empty(B, 1, L, L, dtype=torch.float32, device=dev)
+            static = {}
+            if "gt" in sources:
+                assert gt_mask is not None, "a 'gt' mask source needs the ground-truth mask (B,L,L)"
+                static["gt"] = gt_mask.to(dev).float().reshape(B, L, L)
+            if "fwd_mean" in sources:
+                static["fwd_mean"] = inv["maps_mean"].gather(1, idx).reshape(B, L, L)
 
-            def prep(m):                                                            # get_mask tail, eta_inversion.py:196-201
-                if not final:
-                    return m.contiguous()
+            def shaped(m):                                                          # get_mask tail, eta_inversion.py:196-201
                 if self.mask_thres is not None:
                     m = (m > self.mask_thres).to(m.dtype)
                 if self.mask_pow is not None:
                     m = torch.pow(m, self.mask_pow)
                 return m.contiguous()
-            mask_mode = 2 if final else 1                                           # 2: the map is the per-pixel eta multiplier
-            bwd = self.mask_eta.startswith("bwd")
-            if bwd:                                                                 # maps of the backward-pass store (eta_inversion.py:176-183)
-                assert ptp is not None, "bwd_* eta masks read the prompt-to-prompt controller's maps"
-                tok_s = (edit_word.to(dev).int() + 1).reshape(B, 1).contiguous()
-                tok_t = ((edit_word_tgt if edit_word_tgt is not None else edit_word).to(dev).int() + 1).reshape(B, 1).contiguous()
-                map_s = torch.empty(B, 1, L, L, dtype=torch.float32, device=dev)
-                map_t = torch.empty(B, 1, L, L, dtype=torch.float32, device=dev)
-            if self.mask_eta == "gt":
-                assert gt_mask is not None, "mask_eta='gt' needs the ground-truth mask (B,L,L)"
-                mask_map = prep(gt_mask.to(dev).float().reshape(B, L, L))
-            elif self.mask_eta == "fwd_mean":
-                mask_map = prep(inv["maps_mean"].gather(1, idx).reshape(B, L, L))
+
+            def src_map(name, i):                                                   # raw map of one source at backward step i (eta_inversion.py:164-183)
+                if name in static:
+                    return static[name]
+                if name == "fwd":                                                   # map of THIS timestep (t_bwd[i] == t_fwd[S-1-i])
+                    return inv["maps_steps"][S - 1 - i].gather(1, idx).reshape(B, L, L)
+                if name != "bwd_target":                                            # average over the i+1 backward steps done, this one included
+                    e.word_maps_role(B, tok_s, i + 1, 0, map_s)
+                if name != "bwd_source":
+                    e.word_maps_role(B, tok_t, i + 1, 1, map_t)
+                m = map_s if name == "bwd_source" else map_t if name == "bwd_target" else torch.maximum(map_s, map_t)
+                return m.reshape(B, L, L)
         if ptp is not None:
             e.maps_reset()
         st = _capi.stream_ptr()
@@ -176,19 +187,12 @@ class EtaLoop:
             p = t - self.delta
             a_t, a_p = float(self.ac[t]), (float(self.ac[p]) if p >= 0 else float(self.ac[0]))
             var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
-            if self.use_mask and bwd:                                              # average over the i+1 backward steps done, this one included
-                if self.mask_eta != "bwd_target":
-                    e.word_maps_role(B, tok_s, i + 1, 0, map_s)
-                if self.mask_eta != "bwd_source":
-                    e.word_maps_role(B, tok_t, i + 1, 1, map_t)
-                m = map_s if self.mask_eta == "bwd_source" else map_t if self.mask_eta == "bwd_target" else torch.maximum(map_s, map_t)
-                mask_map = prep(m.reshape(B, L, L))
-            if self.use_mask and self.mask_eta == "fwd":                            # map of THIS timestep (t_bwd[i] == t_fwd[S-1-i])
-                mask_map = prep(inv["maps_steps"][S - 1 - i].gather(1, idx).reshape(B, L, L))
             dmap = None
-            if self.target_dirinv is not None and self.mask_dirinv is not None:     # 1 - (thresholded / powered) map of the same source
-                m = mask_map if mask_mode == 2 else (mask_map > self.mask_thres).to(mask_map.dtype)
-                dmap = (1.0 - m).contiguous()
+            if self.use_mask:
+                raw = src_map(self.mask_eta, i)
+                mask_map = shaped(raw) if mask_mode == 2 else raw.contiguous()      # mode 1: the kernel thresholds the raw forward-mean map
+                if self.target_dirinv is not None and self.mask_dirinv is not None:  # 1 - shaped map of the mask_dirinv source (eta_inversion.py:234-256)
+                    dmap = (1.0 - shaped(raw if self.mask_dirinv == self.mask_eta else src_map(self.mask_dirinv, i))).contiguous()
             _capi.check(self.lib.etainv_eta_backward_step_ex(
                 _capi.ptr(x), _capi.ptr(eps_all), self.g_bwd, _capi.ptr(lat_inv[S - 1 - i]), _capi.ptr(noise[i]), self.n_cand,
                 float(self.etas[t]), _capi.ptr(mask_map), float(self.mask_thres or 0.0), mask_mode, a_t, a_p, var, B, 4, L * L,

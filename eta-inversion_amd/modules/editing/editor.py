@@ -15,8 +15,9 @@ def _split(edit_res):
 
 class ControllerBasedEditor(Editor):
     def __init__(self, inverter, no_source_backward: bool = False, dft_cfg: Optional[Dict[Any, str]] = None, fake_edit: bool = False) -> None:
-        if no_source_backward or fake_edit:
-            raise NotImplementedError("no_source_backward / fake_edit are not built (eta inversion needs the source row)")
+        # no_source_backward: the backward pass runs the target prompt only (reference editor.py:100-116); fake_edit: no inversion, the
+        # backward pass starts from cfg["zT_gt"] (editor.py:84-88).  Both are meaningful for the plain inverters (diffinv); `etainv` and
+        # `dirinv` need the source row and refuse a single-row backward pass.
         self.inverter, self.no_source_backward, self.fake_edit = inverter, no_source_backward, fake_edit
         self.dft_cfg = dft_cfg if dft_cfg is not None else {}
 
@@ -28,9 +29,16 @@ class ControllerBasedEditor(Editor):
         inv_cfg = {} if inv_cfg is None else inv_cfg
         src_context = self.inverter.create_context(source_prompt)
         target_context = self.inverter.create_context(target_prompt)
-        cfg.pop("zT_gt", None)
-        inv_res = self.inverter.invert(image, prompt=source_prompt, context=src_context, inv_cfg=inv_cfg)
+        zT_gt = cfg.pop("zT_gt", None)
+        if self.fake_edit:
+            image = None
+            inv_res = {"latents": [zT_gt.to(self.inverter.model.device)]}
+        else:
+            inv_res = self.inverter.invert(image, prompt=source_prompt, context=src_context, inv_cfg=inv_cfg)
         controller = self.make_controller(image=image, source_prompt=source_prompt, target_prompt=target_prompt, inv_res=inv_res, **cfg, **kwargs)
         with self.inverter.use_controller(controller):
-            edit_res = self.inverter.sample(inv_res, context=[src_context, target_context])
-            return None if edit_res is None else _split(edit_res)
+            if not self.no_source_backward:
+                edit_res = self.inverter.sample(inv_res, context=[src_context, target_context])
+                return None if edit_res is None else _split(edit_res)
+            edit_res = self.inverter.sample(inv_res, context=[target_context])
+            return None if edit_res is None else {"image": edit_res["image"], "latent": edit_res["latent"]}

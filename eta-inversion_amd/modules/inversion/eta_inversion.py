@@ -20,13 +20,17 @@ class EtaInversion(DiffusionInversion):
                  eta=(0.0, 0.4), noise_sample_count: int = 10, seed: int = 0, eta_start: Optional[float] = None,
                  eta_end: Optional[float] = None, use_mask=True, mask_mode_cfg=None) -> None:
         if use_mask:
-            dft = dict(attn_from_where=["up", "down"], attn_res=16, mask_dirinv=None, mask_eta="fwd_mean", pow=None,
+            # attn_res: the reference's 16 is 64 / 4 (eta_inversion.py:90); generalised to L / 4 for other latent sizes
+            dft = dict(attn_from_where=["up", "down"], attn_res=model.engine.L // 4, mask_dirinv=None, mask_eta="fwd_mean", pow=None,
                        target_dirinv=None, thres=0.2)
             mask_mode_cfg = {**dft, **(mask_mode_cfg or {})}
-            if mask_mode_cfg["mask_eta"] not in ("fwd_mean", "fwd", "gt", "bwd_source", "bwd_target", "bwd_source_target") \
-                    or mask_mode_cfg["mask_dirinv"] not in (None, mask_mode_cfg["mask_eta"]):
-                raise NotImplementedError("eta-mask sources built: fwd_mean (default), fwd, gt, bwd_source, bwd_target, bwd_source_target, each "
-                                          "with thres / pow; mask_dirinv must be None or the same source as mask_eta")
+            srcs = ("fwd_mean", "fwd", "gt", "bwd_source", "bwd_target", "bwd_source_target")
+            if mask_mode_cfg["mask_eta"] not in srcs + (None,) or mask_mode_cfg["mask_dirinv"] not in srcs + (None,):
+                raise ValueError(f"mask_eta / mask_dirinv must be one of {srcs} or None (reference eta_inversion.py:164-187)")
+            # the engine stores and aggregates exactly what the reference's defaults read: the five (L/4)^2 up + down cross layers
+            if mask_mode_cfg["attn_res"] != model.engine.L // 4 or sorted(mask_mode_cfg["attn_from_where"]) != ["down", "up"]:
+                raise NotImplementedError(f"attn_res must be L/4 = {model.engine.L // 4} and attn_from_where ['up', 'down']: the native attention-map "
+                                          "store only keeps those layers")
         else:
             mask_mode_cfg = None
         self.mask_mode_cfg = mask_mode_cfg
@@ -47,7 +51,7 @@ class EtaInversion(DiffusionInversion):
         self.L = model.engine.L
         self._loop = EtaLoop(model.engine, S=self.num_inference_steps, guidance_scale_bwd=self.guidance_scale_bwd,
                              guidance_scale_fwd=self._g_fwd_pair or self.guidance_scale_fwd, eta=eta, noise_sample_count=noise_sample_count,
-                             use_mask=use_mask, mask_thres=(mask_mode_cfg or {}).get("thres", 0.2),
+                             use_mask=use_mask and mask_mode_cfg["mask_eta"] is not None, mask_thres=(mask_mode_cfg or {}).get("thres", 0.2),
                              mask_eta=(mask_mode_cfg or {}).get("mask_eta", "fwd_mean"), mask_pow=(mask_mode_cfg or {}).get("pow"),
                              target_dirinv=(mask_mode_cfg or {}).get("target_dirinv"), mask_dirinv=(mask_mode_cfg or {}).get("mask_dirinv"))
 
@@ -58,17 +62,29 @@ class EtaInversion(DiffusionInversion):
         return torch.randn((n, 1, 4, self.L, self.L), generator=generator).to(self.model.device)
 
     def get_mask(self, key, mask, t, edit_word_idx):
+        """reference eta_inversion.py:159-205: the raw map of the configured source, then thres / pow.  The bwd_* sources read the
+        backward-pass store of the active prompt-to-prompt controller (its running average over the steps done, this one included)."""
         if self.mask_mode_cfg is None or self.mask_mode_cfg[key] is None:
             return None
-        mode = self.mask_mode_cfg[key]                                 # reference eta_inversion.py:159-205
-        if mode.startswith("bwd"):
-            raise NotImplementedError("bwd_* eta masks are built for the fused loop (etainv + ptp editor), not for the per-step API")
+        mode = self.mask_mode_cfg[key]
         if mode == "gt":
             m = mask
         elif mode == "fwd":
             m = self.attn_maps_forward[int(t)][edit_word_idx[0]]
-        else:
+        elif mode == "fwd_mean":
             m = self.attn_maps_forward["mean"][edit_word_idx[0]]
+        else:
+            if not hasattr(self.controller, "get_attention_map"):
+                raise RuntimeError(f"mask source '{mode}' needs a prompt-to-prompt controller (its attention store), got {type(self.controller).__name__}")
+            cfg = self.mask_mode_cfg
+            amap = lambda word, prompt: self.controller.get_attention_map(mask_idx=word, res=cfg["attn_res"], from_where=cfg["attn_from_where"],
+                                                                          prompt_idx=prompt, num_prompts=2, resize=self.L)
+            if mode == "bwd_source":
+                m = amap(edit_word_idx[0], 0)
+            elif mode == "bwd_target":
+                m = amap(edit_word_idx[1], 1)
+            else:
+                m = torch.maximum(amap(edit_word_idx[0], 0), amap(edit_word_idx[1], 1))
         if self.mask_mode_cfg["thres"] is not None:
             m = (m > self.mask_mode_cfg["thres"]).to(m.dtype)
         if self.mask_mode_cfg["pow"] is not None:
@@ -78,6 +94,8 @@ class EtaInversion(DiffusionInversion):
     # ------------------------------------------------------------------ inversion
     def _word_tokens(self, prompt):
         words = prompt.split(" ")
+        if len(words) + 1 > 76:                                         # token index word + 1 must stay inside the 77-token context
+            raise IndexError(f"prompt has {len(words)} whitespace words: word maps index the 77-token context (ptp.py:296)")
         return torch.tensor([[words.index(w) + 1 for w in words]], dtype=torch.int32, device=self.model.device)   # ptp_editor.py:72
 
     def invert(self, image, prompt=None, context=None, guidance_scale_fwd=None, inv_cfg: Optional[Dict[str, Any]] = None):
@@ -119,12 +137,16 @@ class EtaInversion(DiffusionInversion):
         return None, None, False
 
     def diffusion_backward(self, latent, context, inv_result):
+        if latent.shape[0] != 2:
+            raise NotImplementedError("etainv / dirinv replay the source row next to the target row: the backward pass needs the [source, target] "
+                                      "pair (no_source_backward editors only make sense with the plain inverters, e.g. diffinv)")
         S, L = self.num_inference_steps, self.L
         inv_cfg = inv_result.get("inv_cfg") or {}
         edit_word_idx = inv_cfg.get("edit_word_idx", None)
         ptp, masa, fast = self._tables_from_controller()
         generator = torch.Generator().manual_seed(self.seed) if self.seed is not None else None
-        if fast and latent.shape[0] == 2 and "_native" in inv_result:
+        # force_per_step (attribute, default off): run the reference-style callback-per-step path also for the built-in controllers
+        if fast and latent.shape[0] == 2 and "_native" in inv_result and not getattr(self, "force_per_step", False):
             noise = torch.stack([self.sample_variance_noise(self.noise_sample_count, generator) for _ in range(S)])
             noise = noise.reshape(S, self.noise_sample_count, 4, L, L).contiguous()
             ctx = context.reshape(2, 2, *context.shape[1:])            # [half][role]
@@ -148,26 +170,29 @@ class EtaInversion(DiffusionInversion):
 
     def predict_step_backward(self, latent, t, context, guidance_scale_bwd=None, source_latent_prev=None, generator=None, mask=None,
                               edit_word_idx=None):
+        """One backward step with the reference's call order (eta_inversion.py:207-273): controller.begin_step -> UNet (+ the controller's
+        attention control) -> get_mask -> fused CFG + best-of-n + masked eta update + source replay -> controller.end_step."""
         guidance_scale_bwd = guidance_scale_bwd or self.guidance_scale_bwd
         latent = self.controller.begin_step(latent=latent, t=t)
         assert latent.shape[0] == 2 and context.shape[0] == 4, "one (source, target) pair"
         eps_all = self.unet(torch.cat([latent] * 2), t, encoder_hidden_states=context)["sample"].float().contiguous()
-        self._step_mask = mask
-        res = self.get_eta_variance_noise(source_latent_prev, latent, t, eps_all, generator, _fused=True, edit_word_idx=edit_word_idx)
+        res = self._fused_eta_step(source_latent_prev, latent, t, eps_all, generator, mask, edit_word_idx, guidance_scale_bwd)
         new_latent = self.controller.end_step(latent=res["latent"], noise_pred=res["noise_pred"], t=t)
         return new_latent, res["noise_pred"]
 
-    def get_eta_variance_noise(self, latent_prev, latent, t, noise_pred, generator=None, _fused=False, edit_word_idx=None):
-        """Fused CFG + best-of-n + masked eta step (etainv_eta_backward_step).  `noise_pred` = raw UNet output rows
-        [u_s,u_t,c_s,c_t]; returns eta, the chosen variance noise, its index and the updated latents."""
+    def _fused_eta_step(self, latent_prev, latent, t, eps_all, generator, mask, edit_word_idx, guidance_scale_bwd=None):
+        """etainv_eta_backward_step_ex on one pair: `eps_all` = raw UNet output rows [u_s,u_t,c_s,c_t], `latent` = [source, target]."""
         t = int(t)
         S, L = self.num_inference_steps, self.L
         cand = self.sample_variance_noise(self.noise_sample_count, generator).reshape(self.noise_sample_count, 4, L, L).float().contiguous()
         sch = self.scheduler_bwd
         p = t - sch.config.num_train_timesteps // S
         a_t, a_p, var = sch._alpha(t), sch._alpha(p), sch._get_variance(t, p)
+        m_eta = self.get_mask("mask_eta", mask, t, edit_word_idx) if self.mask_mode_cfg is not None else None
         use_mask = self.mask_mode_cfg is not None
-        mask_map = self.get_mask("mask_eta", self._step_mask, t, edit_word_idx).float().reshape(1, L, L).contiguous() if use_mask else None
+        if use_mask and m_eta is None:                                     # mask_eta None inside a mask_mode_cfg: eta everywhere (:239-240)
+            m_eta = torch.ones(1, L, L, dtype=torch.float32, device=latent.device)
+        mask_map = m_eta.float().reshape(1, L, L).contiguous() if use_mask else None
         x = latent.float().contiguous()
         out_x, out_eps = torch.empty_like(x), torch.empty_like(x)
         best = torch.zeros(1, dtype=torch.int32, device=x.device)
@@ -176,12 +201,46 @@ class EtaInversion(DiffusionInversion):
         tdir = (self.mask_mode_cfg or {}).get("target_dirinv")
         dmap = None
         if tdir is not None and self.mask_mode_cfg["mask_dirinv"] is not None:
-            dmap = (1.0 - self.get_mask("mask_dirinv", self._step_mask, t, edit_word_idx).float().reshape(1, L, L)).contiguous()
+            dmap = (1.0 - self.get_mask("mask_dirinv", mask, t, edit_word_idx).float().reshape(1, L, L)).contiguous()
         _capi.check(_capi.load().etainv_eta_backward_step_ex(
-            _capi.ptr(x), _capi.ptr(noise_pred), float(self.guidance_scale_bwd), _capi.ptr(latent_prev.float().contiguous()),
+            _capi.ptr(x), _capi.ptr(eps_all), float(guidance_scale_bwd or self.guidance_scale_bwd), _capi.ptr(latent_prev.float().contiguous()),
             _capi.ptr(cand), self.noise_sample_count, float(self.etas[t]), _capi.ptr(mask_map),
             0.0, 2 if use_mask else 0, a_t, a_p, var, 1, 4, L * L, _capi.ptr(out_x),   # 2: get_mask already applied thres / pow
             _capi.ptr(out_eps), _capi.ptr(best), _capi.ptr(losses), _capi.ptr(scratch), _capi.F32, float(tdir or 0.0), _capi.ptr(dmap),
             _capi.stream_ptr()))
         return {"eta": float(self.etas[t]), "variance_noise_candidates": cand, "best_idx": best, "losses": losses, "latent": out_x,
                 "noise_pred": out_eps, "latent_prev": latent_prev}
+
+    def compute_optimal_variance_noise(self, latent_prev, latent, t, eta, noise_pred):
+        """(latent_prev - DDIM-eta mean) / (eta sqrt(var)) -- reference eta_inversion.py:296-317 (eta == 0 gives inf / NaN like there)"""
+        mean = self.step_backward(noise_pred, t, latent, eta=eta, variance_noise=torch.zeros_like(noise_pred)).prev_sample
+        sch = self.scheduler_bwd
+        var = sch._get_variance(int(t), int(t) - sch.config.num_train_timesteps // self.num_inference_steps)
+        return (latent_prev - mean) / torch.tensor(eta * var ** 0.5, dtype=latent_prev.dtype, device=latent_prev.device)
+
+    def get_eta_variance_noise(self, latent_prev, latent, t, noise_pred, generator=None):
+        """Reference signature and result keys (eta_inversion.py:330-375): `latent` = the source row (1,4,L,L), `noise_pred` = its GUIDED
+        noise.  Best-of-n selection runs in the fused kernel (fed with u = c = noise_pred so that its CFG combine is the identity); the
+        chosen candidate is gathered on the device (no host sync)."""
+        tt = int(t)
+        S, L = self.num_inference_steps, self.L
+        cand5 = self.sample_variance_noise(self.noise_sample_count, generator)                     # (n,1,4,L,L)
+        cand = cand5.reshape(self.noise_sample_count, 4, L, L).float().contiguous()
+        sch = self.scheduler_bwd
+        p = tt - sch.config.num_train_timesteps // S
+        a_t, a_p, var = sch._alpha(tt), sch._alpha(p), sch._get_variance(tt, p)
+        x = torch.cat([latent, latent]).float().contiguous()
+        eps4 = torch.cat([noise_pred] * 4).float().contiguous()
+        out_x = torch.empty_like(x)
+        best = torch.zeros(1, dtype=torch.int32, device=x.device)
+        losses = torch.zeros(1, self.noise_sample_count, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(16 * 64, dtype=torch.float32, device=x.device)
+        eta = float(self.etas[tt])
+        _capi.check(_capi.load().etainv_eta_backward_step(
+            _capi.ptr(x), _capi.ptr(eps4), 1.0, _capi.ptr(latent_prev.float().contiguous()), _capi.ptr(cand), self.noise_sample_count, eta,
+            None, 0.0, 0, a_t, a_p, var, 1, 4, L * L, _capi.ptr(out_x), None, _capi.ptr(best), _capi.ptr(losses), _capi.ptr(scratch), _capi.F32,
+            _capi.stream_ptr()))
+        variance_noise = cand5.index_select(0, best.long()).reshape(1, 4, L, L)
+        latent_prev_rec = self.step_backward(noise_pred, t, latent, eta=eta, variance_noise=variance_noise).prev_sample
+        return {"eta": eta, "variance_noise": variance_noise, "delta": latent_prev - latent_prev_rec, "latent_prev": latent_prev,
+                "latent_prev_rec": latent_prev_rec, "loss": losses[0].index_select(0, best.long())[0], "best_idx": best, "losses": losses}

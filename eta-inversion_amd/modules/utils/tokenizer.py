@@ -135,7 +135,14 @@ class ClipBPETokenizer:
 
 
 def load_tokenizer():
+    """CLIP BPE tokenizer of the snapshot named by ETAINV_SD_PATH.  The word-level stand-in is only for runs WITHOUT a snapshot
+    (synthetic weights): real CLIP / UNet weights fed with stand-in token ids would edit silently wrong, so a snapshot without its
+    tokenizer files is an error."""
     path = os.environ.get("ETAINV_SD_PATH")
-    if path and os.path.isfile(os.path.join(path, "tokenizer", "vocab.json")):
-        return ClipBPETokenizer(os.path.join(path, "tokenizer", "vocab.json"), os.path.join(path, "tokenizer", "merges.txt"))
-    return WordLevelTokenizer()
+    if not path:
+        return WordLevelTokenizer()
+    vocab, merges = os.path.join(path, "tokenizer", "vocab.json"), os.path.join(path, "tokenizer", "merges.txt")
+    for f in (vocab, merges):
+        if not os.path.isfile(f):
+            raise FileNotFoundError(f"ETAINV_SD_PATH={path} is set but {f} is missing: the snapshot's text encoder needs its own BPE tokenizer")
+    return ClipBPETokenizer(vocab, merges)

@@ -160,34 +160,54 @@ class EtaInversionOracle:
         best = int(torch.argmin(losses).item())
         return eta, noise_choices[best], best, losses
 
+    # eta_inversion.py:159-205: raw map of one mask source (before thres / pow)
+    def source_map(self, source, t, inv, gt_mask, controller):
+        ew = self._edit_word_idx
+        if source == "gt":
+            return gt_mask                                                    # already at latent resolution (eta_inversion.py:286-287)
+        if source == "fwd":
+            return inv["attn_maps_per_t"][int(t)][ew[0]]                      # eta_inversion.py:168
+        if source == "fwd_mean":
+            return inv["attn_maps_mean"][ew[0]]                               # eta_inversion.py:171
+        # eta_inversion.py:176-183: maps of the backward-pass controller, averaged over the steps done so far (this one included)
+        amap = lambda word, sel: optp.attention_map(controller, word + 1, res=self.attn_res, from_where=("up", "down"), resize=self.L,
+                                                    num_prompts=2, select=sel)
+        if source == "bwd_source":
+            return amap(ew[0], 0)
+        if source == "bwd_target":
+            return amap(ew[1], 1)
+        assert source == "bwd_source_target", source
+        return torch.maximum(amap(ew[0], 0), amap(ew[1], 1))
+
+    def _shape_mask(self, m):
+        if self.thres is not None:
+            m = (m > self.thres).to(m.dtype)                                  # eta_inversion.py:196-198
+        if self.mask_pow is not None:
+            m = torch.pow(m, self.mask_pow)                                   # eta_inversion.py:200-201
+        return m
+
     # eta_inversion.py:207-273
-    def step_backward(self, latent, t, context, source_latent_prev, noise_choices, mask_map, controller):
+    def step_backward(self, latent, t, context, source_latent_prev, noise_choices, mask_map, controller, dirinv_map=None, inv=None, gt_mask=None):
+        """mask_map / dirinv_map: raw maps of the mask_eta / mask_dirinv sources for sources that do not depend on this step's UNet call
+        (gt, fwd, fwd_mean); bwd_* sources are read from the controller AFTER the UNet call, like the reference (get_mask runs after
+        predict_noise, eta_inversion.py:225-237).  dirinv_map None with a mask_dirinv configured = the same map as mask_eta."""
         eps = self.predict_noise(latent, t, context, self.g_bwd)
-        if self.use_mask and self.mask_eta.startswith("bwd"):                # eta_inversion.py:176-183: maps of the backward-pass controller,
-            ew = self._edit_word_idx                                          # averaged over the steps done so far (this one included)
-            amap = lambda word, sel: optp.attention_map(controller, word + 1, res=self.attn_res, from_where=("up", "down"), resize=self.L,
-                                                        num_prompts=2, select=sel)
-            if self.mask_eta == "bwd_source":
-                mask_map = amap(ew[0], 0)
-            elif self.mask_eta == "bwd_target":
-                mask_map = amap(ew[1], 1)
-            else:
-                mask_map = torch.maximum(amap(ew[0], 0), amap(ew[1], 1))
+        if self.use_mask and self.mask_eta.startswith("bwd"):
+            mask_map = self.source_map(self.mask_eta, t, inv, gt_mask, controller)
+        if self.use_mask and self.mask_dirinv is not None and self.mask_dirinv.startswith("bwd"):
+            dirinv_map = self.source_map(self.mask_dirinv, t, inv, gt_mask, controller)
         eta, z, best, losses = self.eta_variance_noise(source_latent_prev, latent[:1], t, eps[:1], noise_choices)
         eta_map = torch.full_like(z, eta)
         if self.use_mask:
-            m = mask_map
-            if self.thres is not None:
-                m = (m > self.thres).to(mask_map.dtype)                     # eta_inversion.py:196-198
-            if self.mask_pow is not None:
-                m = torch.pow(m, self.mask_pow)                               # eta_inversion.py:200-201
+            m = self._shape_mask(mask_map)
             eta_map = m * eta_map
             new = sch.ddim_eta_step(latent, eps, self.ac, int(t), self.S, eta_map, noise=z)
             delta = source_latent_prev[:1] - new[:1]
             new[:1] = new[:1] + delta                                      # eta_inversion.py:247-249
-            if self.target_dirinv is not None:                             # eta_inversion.py:251-256 (mask_dirinv: same source map, thres, pow)
+            if self.target_dirinv is not None:                             # eta_inversion.py:251-256
                 if self.mask_dirinv is not None:
-                    delta = (1 - m) * delta
+                    md = m if dirinv_map is None else self._shape_mask(dirinv_map)
+                    delta = (1 - md) * delta
                 new[1:] = new[1:] + self.target_dirinv * delta
         else:
             new = sch.ddim_eta_step(latent, eps, self.ac, int(t), self.S, eta_map, noise=z)
@@ -205,26 +225,66 @@ class EtaInversionOracle:
         context = torch.stack([ctx_src, ctx_tgt], 1).reshape(4, *ctx_src.shape[1:])   # [u_s,u_t,c_s,c_t]
         self._edit_word_idx = edit_word_idx
         latent = torch.cat([inv["latents"][-1]] * 2)
-        mask_map = None
-        if self.use_mask and not self.mask_eta.startswith("bwd"):
-            mask_map = inv["attn_maps_mean"][edit_word_idx[0]]            # eta_inversion.py:171
         if controller is not None:
             self.unet.set_ctrl(ptp_hook(controller))
         elif masactrl is not None:
             self.unet.set_ctrl(masactrl)
         try:
             for i, t in enumerate(self.t_bwd):
-                if self.use_mask and self.mask_eta == "gt":
-                    mask_map = gt_mask                                        # already at latent resolution (eta_inversion.py:286-287)
-                elif self.use_mask and self.mask_eta == "fwd":
-                    mask_map = inv["attn_maps_per_t"][int(t)][edit_word_idx[0]]   # eta_inversion.py:168
+                mask_map = dirinv_map = None
+                if self.use_mask and not self.mask_eta.startswith("bwd"):
+                    mask_map = self.source_map(self.mask_eta, t, inv, gt_mask, controller)
+                if self.use_mask and self.mask_dirinv is not None and self.mask_dirinv != self.mask_eta and not self.mask_dirinv.startswith("bwd"):
+                    dirinv_map = self.source_map(self.mask_dirinv, t, inv, gt_mask, controller)
                 latent, eps, best, losses = self.step_backward(
-                    latent, t, context, inv["latents"][-(i + 2)], noise_table[i].to(latent.dtype), mask_map, controller)
+                    latent, t, context, inv["latents"][-(i + 2)], noise_table[i].to(latent.dtype), mask_map, controller,
+                    dirinv_map=dirinv_map, inv=inv, gt_mask=gt_mask)
                 if trace is not None:
                     trace.append({"t": int(t), "latent": latent.clone(), "eps": eps.clone(), "best": best,
                                   "losses": losses.clone()})
         finally:
             self.unet.set_ctrl(None)
+        return latent
+
+
+class DiffusionInversionOracle:
+    """`diffinv`: plain DDIM inversion and deterministic DDIM sampling, no source replay (reference
+    modules/inversion/diffusion_inversion.py:314-341 predict_step_forward, :343-371 predict_step_backward, :388-436 loops, :493-528
+    sample).  `step_fwd` / `step_bwd` default to the DDIM closed forms; the DPM-Solver++ inverse pair plugs in through them."""
+
+    def __init__(self, unet, S=50, guidance_scale_bwd=7.5, guidance_scale_fwd=1, step_fwd=None, step_bwd=None):
+        self.unet, self.S, self.g_bwd, self.g_fwd = unet, S, guidance_scale_bwd, guidance_scale_fwd
+        self.ac = sch.alphas_cumprod()
+        self.t_fwd, self.t_bwd = sch.timesteps_forward(S), sch.timesteps_backward(S)
+        self.step_fwd, self.step_bwd = step_fwd, step_bwd
+
+    def predict_noise(self, latent, t, context, g):
+        x = torch.cat([latent] * 2) if latent.shape[0] != context.shape[0] else latent
+        u, c = self.unet(x, torch.tensor(int(t)), encoder_hidden_states=context)["sample"].chunk(2)
+        return u + g * (c - u)
+
+    def invert(self, z0, context):
+        latent, latents = z0.clone(), [z0]
+        for i, t in enumerate(self.t_fwd):
+            eps = self.predict_noise(latent, t, context, self.g_fwd)
+            if self.step_fwd is not None:
+                latent = self.step_fwd(eps, int(t), latent, i)
+            else:
+                latent = sch.ddim_step(latent, eps, *sch.ddim_inverse_coeffs(self.ac, int(t), self.S))
+            latents.append(latent)
+        return {"latents": latents, "zT_inv": latents[-1]}
+
+    def sample(self, inv, contexts):
+        """contexts: list of (2,77,768) [uncond, cond] -- [source, target] or [target] (no_source_backward, editor.py:108-116)"""
+        n = len(contexts)
+        context = torch.stack(contexts, 1).reshape(2 * n, *contexts[0].shape[1:])     # cat_context (diffusion_inversion.py:438-460)
+        latent = torch.cat([inv["latents"][-1]] * n)
+        for i, t in enumerate(self.t_bwd):
+            eps = self.predict_noise(latent, t, context, self.g_bwd)
+            if self.step_bwd is not None:
+                latent = self.step_bwd(eps, int(t), latent, i)
+            else:
+                latent = sch.ddim_eta_step(latent, eps, self.ac, int(t), self.S, 0.0, noise=None)
         return latent
 
 

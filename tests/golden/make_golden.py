@@ -306,7 +306,7 @@ def gen_eta_step_modes():
 def gen_eta_step_dirinv():
     """the reference's target_dirinv / mask_dirinv options of predict_step_backward (eta_inversion.py:236-256)"""
     from modules.inversion.eta_inversion import EtaInversion
-    from tests.golden.recipes import ETA_DIRINV_CASES, eta_case_inputs, crc
+    from tests.golden.recipes import ETA_DIRINV_CASES, eta_case_inputs, crc, dirinv_gt_mask
     out, t = {}, 980
     for name, mode in ETA_DIRINV_CASES.items():
         inp = eta_case_inputs(name)
@@ -317,7 +317,7 @@ def gen_eta_step_dirinv():
         inv.attn_maps_forward = {"mean": [mask_map, mask_map], t: [mask_map, mask_map]}
         with inv.use_controller(None):
             new, eps = inv.predict_step_backward(latent.clone(), torch.tensor(t), torch.zeros(4, 77, 8), source_latent_prev=src_prev,
-                                                 generator=torch.Generator().manual_seed(5), mask=mask_map, edit_word_idx=(0, 0))
+                                                 generator=torch.Generator().manual_seed(5), mask=dirinv_gt_mask(mask_map), edit_word_idx=(0, 0))
         out.update({f"{name}/new": new.float(), f"{name}/crc": np.array([crc(latent), crc(unet_out), crc(src_prev), crc(mask_map), crc(noise)])})
     save("eta_step_dirinv", **out)
 
@@ -496,6 +496,34 @@ def gen_e2e_dirinv(S=2):
          latent_inv=res["latent_inv"], latent=res["latent"])
 
 
+def gen_e2e_diffinv(S=3):
+    """Reference DiffusionInversion (`diffinv`, modules/inversion/diffusion_inversion.py) + SimpleEditor on the toy UNet, with and without
+    the source row in the backward pass (no_source_backward, simple_editor.py:45-51)."""
+    from modules.inversion.diffusion_inversion import DiffusionInversion
+    from modules.editing.simple_editor import SimpleEditor
+    src, tgt = PROMPT_PAIRS[0]
+    unet = toy_unet(0)
+    z0 = 0.8 * torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(2027))
+    out = {"z0": z0, "S": np.array(S)}
+    for tag, nsb in (("pair", False), ("target_only", True)):
+        inv = DiffusionInversion(make_pipe(unet), scheduler="ddim", num_inference_steps=S)
+        captured = {}
+        orig_inv = inv.invert
+
+        def wrapped_inv(*a, _o=orig_inv, **k):
+            r = _o(*a, **k)
+            captured["inv"] = r
+            return r
+        inv.invert = wrapped_inv
+        res = SimpleEditor(inv, no_source_backward=nsb).edit(z0 / 0.18215, src, tgt, inv_cfg=None)
+        out[f"{tag}/latent"] = res["latent"]
+        if not nsb:
+            out["ctx_src"], out["ctx_tgt"] = captured["inv"]["context"], inv.create_context(tgt)
+            out["inv_latents"] = torch.cat(captured["inv"]["latents"])
+            out[f"{tag}/latent_inv"] = res["latent_inv"]
+    save("e2e_diffinv", **out)
+
+
 def gen_e2e_bwdmask(S=2):
     """EtaInversion with the eta mask taken from the BACKWARD-pass controller maps (mask_eta = bwd_source / bwd_source_target,
     eta_inversion.py:176-183) + ptp editor on the toy UNet."""
@@ -583,7 +611,7 @@ def gen_resnet_block():
 
 GENS = {"schedule": gen_schedule, "ddim_inverse": gen_ddim_inverse, "eta_step": gen_eta_step, "eta_step_modes": gen_eta_step_modes, "eta_step_dirinv": gen_eta_step_dirinv,
         "ptp_tables": gen_ptp_tables, "ptp_algebra": gen_ptp_algebra, "masactrl": gen_masactrl, "e2e": gen_e2e, "e2e_dirinv": gen_e2e_dirinv, "e2e_bwdmask": gen_e2e_bwdmask, "pie_bench": gen_pie_bench,
-        "resnet_block": gen_resnet_block}
+        "resnet_block": gen_resnet_block, "e2e_diffinv": gen_e2e_diffinv}
 
 
 if __name__ == "__main__":

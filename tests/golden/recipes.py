@@ -29,7 +29,15 @@ ETA_DIRINV_CASES = {  # target_dirinv (eta_inversion.py:251-256) with / without 
     "tdir": dict(mask_eta="fwd_mean", thres=0.2, target_dirinv=0.5),
     "tdir_masked": dict(mask_eta="fwd_mean", mask_dirinv="fwd_mean", thres=0.4, target_dirinv=0.8),
     "tdir_soft": dict(mask_eta="fwd_mean", mask_dirinv="fwd_mean", thres=None, pow=2.0, target_dirinv=0.3),
+    # mask_dirinv from a DIFFERENT source than mask_eta (eta_inversion.py:234-236): the `mask` argument (gt) is the eta map rolled by 7 pixels
+    "tdir_gt": dict(mask_eta="fwd_mean", mask_dirinv="gt", thres=0.4, target_dirinv=0.6),
+    "tdir_gt_eta_fwd": dict(mask_eta="gt", mask_dirinv="fwd", thres=0.3, pow=2.0, target_dirinv=0.7),
 }
+
+
+def dirinv_gt_mask(mask_map: torch.Tensor) -> torch.Tensor:
+    """the ground-truth `mask` argument of the ETA_DIRINV_CASES (differs from the forward maps so that a swapped source shows)"""
+    return torch.roll(mask_map, 7, dims=-1)
 
 
 def eta_case_inputs(name: str, L: int = 64):

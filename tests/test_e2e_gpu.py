@@ -207,8 +207,10 @@ def test_bwd_mask_sources_vs_oracle(setup, mode):
     assert relerr(out[:B].cpu(), ref[:B]) < 5e-3 and relerr(out[B:].cpu(), ref[B:]) < 3e-2
 
 
-def test_target_dirinv_vs_oracle(setup):
-    """target_dirinv with a mask_dirinv (eta_inversion.py:251-256) end to end, etainv + simple"""
+@pytest.mark.parametrize("mask_eta,mask_dirinv", [("fwd_mean", "fwd_mean"), ("fwd_mean", "gt"), ("gt", "fwd")])
+def test_target_dirinv_vs_oracle(setup, mask_eta, mask_dirinv):
+    """target_dirinv with a mask_dirinv (eta_inversion.py:234-256) end to end, etainv + simple; mask_dirinv may name a different map
+    source than mask_eta"""
     from oracle import loop as oloop
     from etainv.pipeline import EtaLoop
     unet, get_engine = setup
@@ -216,22 +218,23 @@ def test_target_dirinv_vs_oracle(setup):
     eng = get_engine(L, torch.float16)
     pairs, z0, ctx_src, ctx_tgt = _inputs(L)
     noise = oloop.noise_table(S, 10, L, seed=0)
-    kw = dict(thres=0.3, mask_eta="fwd_mean", target_dirinv=0.6, mask_dirinv="fwd_mean")
+    gt = torch.rand(B, L, L, generator=torch.Generator().manual_seed(19))
+    kw = dict(thres=0.3, mask_eta=mask_eta, target_dirinv=0.6, mask_dirinv=mask_dirinv)
     ref = []
     with torch.no_grad():
         for i, (src, tgt) in enumerate(pairs):
             o = oloop.EtaInversionOracle(unet, S=S, eta=(0.0, 0.4), L=L, use_mask=True, **kw)
             inv = o.invert(z0[i:i + 1], ctx_src[i], src)
-            ref.append(o.sample(inv, ctx_src[i], ctx_tgt[i], noise, edit_word_idx=(1, 1)))
+            ref.append(o.sample(inv, ctx_src[i], ctx_tgt[i], noise, edit_word_idx=(1, 1), gt_mask=gt[i:i + 1]))
     ref = torch.cat([torch.stack([r[0] for r in ref]), torch.stack([r[1] for r in ref])])
     W = max(len(s.split(" ")) for s, _ in pairs)
     tokens = torch.ones(B, W, dtype=torch.int32)
     for i, (src, _) in enumerate(pairs):
         ws = src.split(" ")
         tokens[i, :len(ws)] = torch.tensor([ws.index(w) + 1 for w in ws], dtype=torch.int32)
-    loop = EtaLoop(eng, S=S, eta=(0.0, 0.4), use_mask=True, mask_thres=0.3, mask_eta="fwd_mean", target_dirinv=0.6, mask_dirinv="fwd_mean")
+    loop = EtaLoop(eng, S=S, eta=(0.0, 0.4), use_mask=True, mask_thres=0.3, mask_eta=mask_eta, target_dirinv=0.6, mask_dirinv=mask_dirinv)
     inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
-    out = loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), noise.reshape(S, 10, 4, L, L).cuda(), edit_word=torch.tensor([1, 1]))
+    out = loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), noise.reshape(S, 10, 4, L, L).cuda(), edit_word=torch.tensor([1, 1]), gt_mask=gt)
     assert relerr(out[:B].cpu(), ref[:B]) < 5e-3 and relerr(out[B:].cpu(), ref[B:]) < 3e-2
 
 

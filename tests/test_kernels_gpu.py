@@ -120,7 +120,7 @@ def test_eta_backward_step_mask_modes_vs_reference_golden(capi, golden, name):
     np.testing.assert_allclose(out_x.cpu().numpy(), g[f"{name}/new"], rtol=1e-4, atol=5e-5)
 
 
-@pytest.mark.parametrize("name", ["tdir", "tdir_masked", "tdir_soft"])
+@pytest.mark.parametrize("name", ["tdir", "tdir_masked", "tdir_soft", "tdir_gt", "tdir_gt_eta_fwd"])
 def test_eta_backward_step_target_dirinv_vs_reference_golden(capi, golden, name):
     """etainv_eta_backward_step_ex: the reference's target_dirinv / mask_dirinv options (eta_inversion.py:251-256)"""
     from oracle import schedule as sch
@@ -129,12 +129,16 @@ def test_eta_backward_step_target_dirinv_vs_reference_golden(capi, golden, name)
     mode = recipes.ETA_DIRINV_CASES[name]
     inp = recipes.eta_case_inputs(name)
     assert [recipes.crc(inp[k]) for k in ("latent", "unet_out", "src_prev", "mask_map", "noise")] == list(g[f"{name}/crc"])
-    m = inp["mask_map"].float()
-    if mode.get("thres", 0.2) is not None:
-        m = (m > mode.get("thres", 0.2)).float()
-    if mode.get("pow") is not None:
-        m = torch.pow(m, mode["pow"])
-    dmap = (1 - m).contiguous().cuda() if mode.get("mask_dirinv") else None
+    def shaped(m):                                                    # get_mask tail (eta_inversion.py:196-201)
+        m = m.float()
+        if mode.get("thres", 0.2) is not None:
+            m = (m > mode.get("thres", 0.2)).float()
+        if mode.get("pow") is not None:
+            m = torch.pow(m, mode["pow"])
+        return m
+    src = {"gt": recipes.dirinv_gt_mask(inp["mask_map"]), "fwd": inp["mask_map"], "fwd_mean": inp["mask_map"]}   # mask_dirinv may name another source
+    m = shaped(src[mode["mask_eta"]])
+    dmap = (1 - shaped(src[mode["mask_dirinv"]])).contiguous().cuda() if mode.get("mask_dirinv") else None
     lib = capi.load()
     ac, t, S = sch.alphas_cumprod(), 980, 50
     eta = float(sch.eta_table([[0.6, 0], [1, 0.7]])[t])
@@ -389,6 +393,63 @@ def test_self_attention_plain(capi, dtype, n, d):
     out = torch.empty(b, n, heads * d, dtype=dtype, device="cuda")
     capi.check(lib.etainv_op_self_attention(capi.ptr(qkv), capi.ptr(out), b, n, heads, d, 0, 1, capi.dtype_code(dtype), capi.stream_ptr()))
     assert relerr(out, ref_self_attention(qkv, heads)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,b,heads,gain", [(256, 2, 8, 1.0), (64, 1, 8, 1.0), (144, 1, 4, 1.0), (200, 3, 4, 1.0), (576, 1, 8, 1.0), (1024, 2, 8, 3.0),
+                                            (2304, 1, 8, 0.05), (9216, 1, 8, 1.0)])
+def test_self_attention_d40(capi, dtype, n, b, heads, gain):
+    """head_dim 40 kernel (32x32x16 MFMAs, deferred reference maximum): token counts of every latent size incl. 96^2 = 9216, ragged
+    key tiles (144, 200), grids with and without the XCD remap (b * heads % 8), and score scales that make the rare
+    move-the-maximum branch fire in most tiles (gain 3: logits with a standard deviation of ~9 nats) or never after the first (0.05)."""
+    lib = capi.load()
+    d = 40
+    qkv = rnd(b, n, 3 * heads * d, seed=n + b, dtype=dtype)
+    qkv[..., : 2 * heads * d] *= gain
+    out = torch.empty(b, n, heads * d, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_self_attention(capi.ptr(qkv), capi.ptr(out), b, n, heads, d, 0, 1, capi.dtype_code(dtype), capi.stream_ptr()))
+    assert torch.isfinite(out).all()
+    assert relerr(out, ref_self_attention(qkv, heads)) < TOL[dtype] * (2 if gain > 1 else 1)
+
+
+def test_self_attention_d40_maximum_jumps_late(capi):
+    """A key whose score exceeds everything before it by far more than the deferral threshold, placed in a LATE tile, for a few queries
+    only (the branch is wave-uniform, the update per query), plus a first tile whose scores are all very negative for other queries."""
+    lib = capi.load()
+    b, heads, n, d, dtype = 1, 8, 512, 40, torch.float16
+    qkv = rnd(b, n, 3 * heads * d, seed=77, dtype=dtype)
+    q, k = qkv[..., : heads * d], qkv[..., heads * d: 2 * heads * d]
+    k[0, 300] = (q[0, 5] * 6).to(dtype)          # key 300 (tile 4) aligned with query 5: a score far above its running maximum
+    k[0, 450] = (q[0, 130] * 8).to(dtype)
+    k[0, :64] = (k[0, :64] - 4 * q[0, 200:201]).to(dtype)   # first tile strongly negative for query 200
+    out = torch.empty(b, n, heads * d, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_self_attention(capi.ptr(qkv), capi.ptr(out), b, n, heads, d, 0, 1, capi.dtype_code(dtype), capi.stream_ptr()))
+    ref = ref_self_attention(qkv, heads)
+    assert torch.isfinite(out).all()
+    assert relerr(out, ref) < TOL[dtype]
+    assert relerr(out[0, [5, 130, 200]], ref[0, [5, 130, 200]]) < 2 * TOL[dtype]
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_self_attention_d40_remaps(capi, mode, dtype):
+    lib = capi.load()
+    n_img, heads, n, d = 2, 8, 320, 40
+    b = 4 * n_img
+    qkv = rnd(b, n, 3 * heads * d, seed=3, dtype=dtype)
+    out = torch.empty(b, n, heads * d, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_self_attention(capi.ptr(qkv), capi.ptr(out), b, n, heads, d, mode, n_img, capi.dtype_code(dtype), capi.stream_ptr()))
+    ident = torch.arange(b)
+    qm, km, vm = ident.clone(), ident.clone(), ident.clone()
+    for img in range(n_img):
+        u_s, u_t, c_s, c_t = img, n_img + img, 2 * n_img + img, 3 * n_img + img
+        if mode == 1:
+            qm[c_t] = c_s
+            km[c_t] = c_s
+        else:
+            km[u_t], vm[u_t] = u_s, u_s
+            km[c_t], vm[c_t] = c_s, c_s
+    assert relerr(out, ref_self_attention(qkv, heads, qm, km, vm)) < TOL[dtype]
 
 
 @pytest.mark.parametrize("mode", [1, 2])

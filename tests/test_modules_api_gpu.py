@@ -97,6 +97,68 @@ def test_per_step_plugin_path_matches_fast_path(pipe):
     assert inverter.invert(image, prompt=SRC, context=ctx_s, inv_cfg=dict(edit_word_idx=(None, None))) is None
 
 
+@pytest.mark.parametrize("editor_name,mask_cfg", [("ptp", None), ("ptp", dict(mask_eta="bwd_source_target", thres=0.15)),
+                                                  ("ptp", dict(mask_eta="fwd_mean", mask_dirinv="bwd_target", target_dirinv=0.5, thres=0.25)),
+                                                  ("masactrl", None)])
+def test_per_step_api_with_builtin_controllers(pipe, editor_name, mask_cfg):
+    """The reference-style per-step path (controller.begin_step -> UNet -> get_mask -> eta step -> controller.end_step, one pair at a
+    time) with the BUILT-IN prompt-to-prompt / MasaCtrl controllers, including the bwd_* mask sources that read the controller's
+    attention store (eta_inversion.py:176-183) and a mask_dirinv from another source: must agree with the fused device loop."""
+    import modules
+    p, pre, post = pipe
+    S = 5
+    kw = dict(model=p, scheduler="ddim", num_inference_steps=S, eta=(0.3, 0.6))
+    if mask_cfg is not None:
+        kw["mask_mode_cfg"] = mask_cfg
+    inverter = modules.load_inverter("etainv", **kw)
+    editor = modules.load_editor(editor_name, inverter=inverter)
+    image = _image()
+    cfg = {**PTP_CFG} if editor_name == "ptp" else None
+    fast = editor.edit(image, SRC, TGT, cfg=None if cfg is None else {**cfg}, inv_cfg=dict(edit_word_idx=(1, 1)))
+    inverter.force_per_step = True
+    slow = editor.edit(image, SRC, TGT, cfg=None if cfg is None else {**cfg}, inv_cfg=dict(edit_word_idx=(1, 1)))
+    inverter.force_per_step = False
+    torch.testing.assert_close(slow["latent_inv"], fast["latent_inv"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(slow["latent"], fast["latent"], rtol=1e-4, atol=1e-4)
+    assert p.unet.attn_ctrl is None
+
+
+def test_get_eta_variance_noise_reference_signature(pipe):
+    """get_eta_variance_noise(latent_prev, latent, t, noise_pred, generator) with the reference's arguments and result keys
+    (eta_inversion.py:330-375) vs the oracle's restatement (pinned by tests/golden/eta_step.npz)."""
+    import modules
+    from oracle import loop as oloop, schedule as sch
+    p, pre, post = pipe
+    S, L = 50, 16
+    inverter = modules.load_inverter("etainv", model=p, scheduler="ddim", num_inference_steps=S, eta=[[0.6, 0], [1, 0.7]])
+    g = torch.Generator().manual_seed(8)
+    latent, eps = torch.randn(1, 4, L, L, generator=g), torch.randn(1, 4, L, L, generator=g)
+    prev = 0.98 * latent + 0.05 * torch.randn(1, 4, L, L, generator=g)
+    t = torch.tensor(860)
+    res = inverter.get_eta_variance_noise(prev.cuda(), latent.cuda(), t, eps.cuda(), torch.Generator().manual_seed(5))
+    assert {"eta", "variance_noise", "delta", "latent_prev", "latent_prev_rec", "loss"} <= set(res)
+    cand = torch.randn((10, 1, 4, L, L), generator=torch.Generator().manual_seed(5))
+    o = oloop.EtaInversionOracle(None, S=S, eta=[[0.6, 0], [1, 0.7]], L=L)
+    eta, z, best, losses = o.eta_variance_noise(prev, latent, 860, eps, cand)
+    rec = sch.ddim_eta_step(latent, eps, o.ac, 860, S, eta, noise=z)
+    assert int(res["best_idx"].item()) == best and abs(res["eta"] - eta) < 1e-7
+    torch.testing.assert_close(res["variance_noise"].cpu(), z, rtol=0, atol=0)
+    torch.testing.assert_close(res["latent_prev_rec"].cpu(), rec, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(res["delta"].cpu(), prev - rec, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(res["loss"].cpu(), losses[best], rtol=1e-4, atol=0)
+
+
+def test_mask_cfg_validation(pipe):
+    import modules
+    p, pre, post = pipe
+    with pytest.raises(NotImplementedError):
+        modules.load_inverter("etainv", model=p, num_inference_steps=4, mask_mode_cfg=dict(attn_res=8))
+    with pytest.raises(NotImplementedError):
+        modules.load_inverter("etainv", model=p, num_inference_steps=4, mask_mode_cfg=dict(attn_from_where=["up"]))
+    with pytest.raises(ValueError):
+        modules.load_inverter("etainv", model=p, num_inference_steps=4, mask_mode_cfg=dict(mask_eta="nope"))
+
+
 def test_edit_image_cli(tmp_path):
     from PIL import Image
     src = tmp_path / "in.png"
@@ -135,3 +197,37 @@ def test_dirinv_plugin_vs_oracle():
         z = o.sample(oinv, ctx_s, ctx_t, oloop.noise_table(S, 1, L, seed=0), edit_word_idx=(1, 1))
     rel = lambda a, b: ((a.float().cpu() - b).norm() / b.norm()).item()
     assert rel(res["latent_inv"], z[:1]) < 5e-3 and rel(res["latent"], z[1:]) < 3e-2
+    # DirectInversion.invert honours the per-call guidance_scale_fwd (direct_inversion.py:60-62): CFG 3 in the inversion pass
+    inv_res = inv.invert(z0, prompt=src, context=inv.create_context(src), guidance_scale_fwd=3.0)
+    with torch.no_grad():
+        o3 = oloop.EtaInversionOracle(build_unet(0), S=S, eta=(0.0, 0.0), noise_sample_count=1, use_mask=False, L=L, guidance_scale_fwd=3.0)
+        ref3 = torch.cat(o3.invert(z0, ctx_s, src)["latents"])
+    assert rel(torch.cat(inv_res["latents"]), ref3) < 5e-3
+    assert rel(torch.cat(inv_res["latents"]), torch.cat(oinv["latents"])) > 1e-2      # and it really differs from the scale-1 trajectory
+
+
+@pytest.mark.parametrize("no_source_backward", [False, True])
+def test_diffinv_plugin_vs_oracle(no_source_backward):
+    """`load_inverter("diffinv")` + simple editor (with and without the source row in the backward pass) through the per-step plugin API
+    vs the CPU oracle's restatement of the reference loops (diffusion_inversion.py:388-436, pinned by tests/golden/e2e_diffinv.npz)."""
+    from modules import load_diffusion_model, load_inverter, load_editor
+    from oracle import loop as oloop
+    from oracle.unet import build_unet
+    S, L = 4, 16
+    pipe, _ = load_diffusion_model("CompVis/stable-diffusion-v1-4", "cuda", variant="fp16", latent_size=L, max_img=1)
+    inv = load_inverter(type="diffinv", model=pipe, scheduler="ddim", num_inference_steps=S)
+    ed = load_editor(type="simple", inverter=inv, no_source_backward=no_source_backward)
+    src, tgt = "a cat sitting on a chair", "a tiger sitting on a chair"
+    z0 = 0.8 * torch.randn(1, 4, L, L, generator=torch.Generator().manual_seed(4))
+    inv.encode = lambda image: image.to("cuda").float()          # feed the latent directly: the VAE is tested elsewhere
+    res = ed.edit(z0, src, tgt)
+    ctx_s, ctx_t = inv.create_context(src).cpu(), inv.create_context(tgt).cpu()
+    with torch.no_grad():
+        o = oloop.DiffusionInversionOracle(build_unet(0), S=S)
+        z = o.sample(o.invert(z0, ctx_s), [ctx_t] if no_source_backward else [ctx_s, ctx_t])
+    rel = lambda a, b: ((a.float().cpu() - b).norm() / b.norm()).item()
+    if no_source_backward:
+        assert set(res) == {"image", "latent"} and rel(res["latent"], z) < 3e-2
+    else:
+        assert rel(res["latent_inv"], z[:1]) < 3e-2 and rel(res["latent"], z[1:]) < 3e-2
+    pipe.engine.close()

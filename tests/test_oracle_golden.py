@@ -114,7 +114,10 @@ def test_eta_step_target_dirinv(golden, name):
             pass
     o = oloop.EtaInversionOracle(U(), S=50, eta=[[0.6, 0], [1, 0.7]], use_mask=True, thres=mode.get("thres", 0.2), mask_eta=mode["mask_eta"],
                                  mask_pow=mode.get("pow"), target_dirinv=mode["target_dirinv"], mask_dirinv=mode.get("mask_dirinv"))
-    new, eps, best, losses = o.step_backward(inp["latent"].clone(), 980, torch.zeros(4, 77, 8), inp["src_prev"], inp["noise"], inp["mask_map"], None)
+    gt = recipes.dirinv_gt_mask(inp["mask_map"])
+    src = {"gt": gt, "fwd": inp["mask_map"], "fwd_mean": inp["mask_map"]}
+    new, eps, best, losses = o.step_backward(inp["latent"].clone(), 980, torch.zeros(4, 77, 8), inp["src_prev"], inp["noise"], src[mode["mask_eta"]], None,
+                                             dirinv_map=src[mode["mask_dirinv"]] if mode.get("mask_dirinv") else None)
     np.testing.assert_allclose(new.numpy(), g[f"{name}/new"], rtol=1e-5, atol=2e-5)
 
 
@@ -308,3 +311,21 @@ def test_resnet_block_matches_reference_restatement(golden, tag, cin, cout, hw):
         y = blk(x, temb)
     ref = torch.from_numpy(g[f"{tag}_y"])
     assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5), float((y - ref).abs().max())
+
+
+def test_diffinv_vs_reference(golden, toy_unet):
+    """`diffinv` (plain DDIM inversion + deterministic sampling, no source replay): oracle.loop.DiffusionInversionOracle vs the reference's
+    DiffusionInversion + SimpleEditor on the toy UNet, with and without the source row in the backward pass (make_golden.gen_e2e_diffinv)"""
+    g = golden("e2e_diffinv")
+    S = int(g["S"])
+    z0 = torch.from_numpy(g["z0"])
+    ctx_s, ctx_t = torch.from_numpy(g["ctx_src"]), torch.from_numpy(g["ctx_tgt"])
+    with torch.no_grad():
+        o = oloop.DiffusionInversionOracle(toy_unet, S=S)
+        inv = o.invert(z0, ctx_s)
+        np.testing.assert_allclose(torch.cat(inv["latents"]).numpy(), g["inv_latents"], rtol=1e-4, atol=2e-5)
+        z = o.sample(inv, [ctx_s, ctx_t])
+        zt = o.sample(inv, [ctx_t])
+    np.testing.assert_allclose(z[:1].numpy(), g["pair/latent_inv"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(z[1:].numpy(), g["pair/latent"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(zt.numpy(), g["target_only/latent"], rtol=1e-3, atol=2e-4)
