@@ -367,11 +367,11 @@ constexpr int A40_KBUF = A40_KV * A40_KROW, A40_VBUF = A40_KV * A40_VROW;
 constexpr size_t A40_LDS = (size_t)(2 * A40_KBUF + 3 * A40_VBUF) * 2;   // 2 K + 2 V buffers + one all-zero V image (rows 48..63 of V^T)
 constexpr float A40_THR = 8.0f;
 
-template <typename T, bool XCD_REMAP>
-__global__ void __launch_bounds__(256, 2) self_attn40_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads, float q_scale,
-                                                             int mode, int n_img, int nqb) {
+template <typename T, bool XCD_REMAP, int QB, int OCC>
+__global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads,
+                                                               float q_scale, int mode, int n_img, int nqb, int stagger) {
   typedef typename Frag<T>::v8 v8;
-  constexpr int D = 40, KV = A40_KV, QB = 2, KROW = A40_KROW, VROW = A40_VROW, KBUF = A40_KBUF, VBUF = A40_VBUF;
+  constexpr int D = 40, KV = A40_KV, KROW = A40_KROW, VROW = A40_VROW, KBUF = A40_KBUF, VBUF = A40_VBUF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* sK = reinterpret_cast<T*>(smem);      // [2][KV][KROW]
   T* sV = sK + 2 * KBUF;                   // [2][KV][VROW]
@@ -402,7 +402,11 @@ __global__ void __launch_bounds__(256, 2) self_attn40_kernel(const T* __restrict
     if (mode == 1 && half == 1 && role == 1) { bq = b - n_img; bk = b - n_img; }
     if (mode == 2 && role == 1) { bk = b - n_img; bv = b - n_img; }
   }
-  const int q_base = qblk * 256 + wid * 64;
+  const int q_base = qblk * (128 * QB) + wid * (32 * QB);
+  // experiment (ETAINV_A40_STAGGER, 64-cycle ticks): delay the second co-resident block of each CU (ids 256 .. 511 of every 512 under
+  // round-robin dispatch) so that its matrix phases meet the first block's softmax phases
+  if (stagger > 0 && ((blockIdx.x >> 8) & 1))
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
 
   // ---- one-time LDS constants: pad chunks (1, 0 x 7) of every K and V row of both buffers, the all-zero V image
   {
@@ -543,11 +547,16 @@ __global__ void __launch_bounds__(256, 2) self_attn40_kernel(const T* __restrict
 #pragma unroll
       for (int e = 3; e + 1 < 32; e += 2) m = fmaxf(fmaxf(m, s[qb][e >> 4][e & 15]), s[qb][(e + 1) >> 4][(e + 1) & 15]);
       m = fmaxf(m, s[qb][1][15]);
-      const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
-      mx[qb] = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));   // both key halves of the query
+      // the other 32 keys of the query live in lane ^ 32: v_permlane32_swap exchanges lanes 32-63 of the first operand with lanes 0-31 of
+      // the second (VALU, no LDS).  Inline asm: with this toolchain the builtin's SECOND result comes back as a copy of the first
+      // (hipcc 7.2 folds max(sw[0], sw[1]) to sw[0]), which left a maximum over half of the keys -- still a valid softmax reference, but
+      // no overflow guard: fp16 P overflowed on wide score ranges (tests/test_kernels_gpu.py::test_self_attention_d40_maximum_jumps_late)
+      float ma = m, mb = m;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
+      mx[qb] = fmaxf(ma, mb);   // both key halves of the query
     }
     const bool first = j == 0;
-    if (first || __builtin_amdgcn_ballot_w64(fmaxf(mx[0], mx[1]) > A40_THR) != 0) {
+    if (first || __builtin_amdgcn_ballot_w64(fmaxf(mx[0], mx[QB - 1]) > A40_THR) != 0) {
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
         const float d = first ? mx[qb] : fmaxf(mx[qb], 0.f);
@@ -837,22 +846,23 @@ bool self_attn40_v2_enabled() {
   return on;
 }
 
-template <typename T>
+template <typename T, int QB, int OCC>
 static int launch_self40(const void* qkv, void* out, int b, int n, int heads, int mode, int n_img, int q_prescaled, hipStream_t s) {
-  static bool attr[2] = {false, false};
-  const int nqb = cdiv(n, 256);
+  const int nqb = cdiv(n, 128 * QB);
   const bool remap = ((b * heads) % 8) == 0;
-  if (!attr[remap]) {
-    if (remap) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn40_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)A40_LDS);
-    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn40_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)A40_LDS);
-    attr[remap] = true;
-  }
   const float q_scale = q_prescaled ? 1.0f : (1.0f / sqrtf(40.f)) * 1.4426950408889634f;
   ProfScope prof(PROF_SELF_ATTN, 4.0 * (double)b * heads * (double)n * (double)n * 40, s);
+  static const int stagger = getenv("ETAINV_A40_STAGGER") ? atoi(getenv("ETAINV_A40_STAGGER")) : 0;
+  static const size_t lds_pad = getenv("ETAINV_A40_LDSPAD") ? (size_t)atoi(getenv("ETAINV_A40_LDSPAD")) : 0;   // experiment: fewer resident blocks
+  const size_t lds = A40_LDS + lds_pad;
+  if (lds_pad) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn40_kernel<T, true, QB, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn40_kernel<T, false, QB, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   if (remap)
-    hipLaunchKernelGGL((self_attn40_kernel<T, true>), dim3(nqb * heads * b), dim3(256), A40_LDS, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb);
+    hipLaunchKernelGGL((self_attn40_kernel<T, true, QB, OCC>), dim3(nqb * heads * b), dim3(256), lds, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb, stagger);
   else
-    hipLaunchKernelGGL((self_attn40_kernel<T, false>), dim3(nqb, heads, b), dim3(256), A40_LDS, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb);
+    hipLaunchKernelGGL((self_attn40_kernel<T, false, QB, OCC>), dim3(nqb, heads, b), dim3(256), lds, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb, stagger);
   ETAINV_LAUNCH_CHECK();
   return 0;
 }
@@ -864,7 +874,11 @@ int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int hea
   ETAINV_CHECK(!q_prescaled || d == 40, "pre-scaled queries: head_dim 40 only");
   ETAINV_CHECK(!q_prescaled || self_attn40_v2_enabled(), "pre-scaled queries need the d = 40 kernel");
   if (d == 40 && self_attn40_v2_enabled()) {
-    ETAINV_DISPATCH_HALF(dtype, T, return launch_self40<T>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s));
+    // A/B (ETAINV_ATT_QB): 2 = two 32-query blocks per wave, 2 waves per SIMD (default); 1 = one block, 4 waves per SIMD; 13 = one block, 3 waves
+    static const int qb = getenv("ETAINV_ATT_QB") ? atoi(getenv("ETAINV_ATT_QB")) : 2;
+    if (qb == 1) { ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 1, 4>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s))); }
+    if (qb == 13) { ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 1, 3>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s))); }
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 2, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s)));
   }
   ETAINV_DISPATCH_HALF(dtype, T, switch (d) {
     case 40: return launch_self_t<T, 40>(qkv, out, b, n, heads, mode, n_img, s);

@@ -21,3 +21,10 @@ pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libetainv_hip.so" "$HERE"/obj/{step_kernels,igemm,norm,attention,misc,maps,aux_nets,engine}.o
 echo "built $OUT/libetainv_hip.so"
+# diagnostic variant (STAMPS=1): igemm with in-kernel s_memtime stamps -> lib/libetainv_hip_stamps.so (load it with ETAINV_LIB=<path>;
+# tools/experiments/*: reads SHARES of a K step, never a run time)
+if [ "${STAMPS:-0}" = "1" ]; then
+  hipcc $FLAGS -DETAINV_IGEMM_STAMPS -c "$HERE/igemm.hip" -o "$HERE/obj/igemm_stamps.o"
+  hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libetainv_hip_stamps.so" "$HERE"/obj/{step_kernels,igemm_stamps,norm,attention,misc,maps,aux_nets,engine}.o
+  echo "built $OUT/libetainv_hip_stamps.so"
+fi

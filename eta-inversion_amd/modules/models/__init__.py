@@ -49,8 +49,9 @@ class EtaPipeline:
 
 
 class StablePreprocess:
-    """image file / uint8 array -> (1,3,size,size) float32 in [-1,1] (reference :12-76; PIL replaces cv2, which is not in
-    the image: bilinear resize, RGB order)."""
+    """image file / uint8 array -> (1,3,size,size) float32 in [-1,1] (reference :12-76).  cv2 is not in this image: the file is decoded
+    with PIL (RGB, what cv2.imread + COLOR_BGR2RGB yields) and `cv2.resize` (INTER_LINEAR on uint8, no antialiasing) is restated in
+    modules/models/resize.py; `pil_resize=True` is PIL's default resize filter (bicubic) like the reference."""
 
     def __init__(self, device, size=512, return_np=False, center_crop=False, pil_resize=False):
         self.device, self.size, self.return_np, self.center_crop, self.pil_resize = device, size, return_np, center_crop, pil_resize
@@ -71,8 +72,11 @@ class StablePreprocess:
                 y2 = h - w - y1
                 if y2 > 0:
                     image = image[y1:-y2]
-        resample = Image.BICUBIC if self.pil_resize else Image.BILINEAR
-        image = np.array(Image.fromarray(image).resize((self.size, self.size), resample))
+        if self.pil_resize:
+            image = np.array(Image.fromarray(image).resize((self.size, self.size)))
+        else:
+            from .resize import resize_linear_u8
+            image = resize_linear_u8(np.ascontiguousarray(image), (self.size, self.size))
         image_pt = (torch.from_numpy(image).float() / 127.5 - 1).permute(2, 0, 1).unsqueeze(0).to(self.device)
         return (image_pt, image) if self.return_np else image_pt
 
@@ -84,11 +88,19 @@ class StablePostProc:
 
 
 def load_diffusion_model(model="CompVis/stable-diffusion-v1-4", device="cuda", preproc_args=None, variant=None, **kwargs):
-    variant = variant or "fp32"
+    """reference modules/models/__init__.py:100-138.  Precision: this engine computes with fp16 or bf16 MFMA operands and fp32 accumulation
+    (latents, contexts, scheduler state and the attention softmax stay fp32).  The reference's default `variant=None` means fp32 there;
+    here None selects fp16 and SAYS so, and an explicit "fp32" raises: there is no fp32-operand path (v_mfma_f32_16x16x4_f32 runs at 1/16
+    of the fp16 rate and is not built), and silently narrowing an explicit request would be worse than refusing it."""
+    if variant == "fp32":
+        raise NotImplementedError("variant='fp32': the MI355X engine has no fp32-operand compute path; use 'fp16' or 'bf16' (fp32 accumulation, "
+                                  "fp32 latents / scheduler state) -- measured UNet error vs an fp32 reference: 1.1e-3 (fp16), 9e-3 (bf16) rel L2")
+    if variant is None:
+        variant = "fp16"
+        print("precision: fp16 MFMA operands with fp32 accumulation (the reference's fp32 default has no counterpart on this engine)")
     print(f"Loading model {model} ({variant}) ...")
     if model not in ("sd14", "sd15", "CompVis/stable-diffusion-v1-4", "runwayml/stable-diffusion-v1-5"):
         raise Exception(model)
-    # fp32 is not an MFMA operand type: "fp32" keeps fp32 latents/contexts at the boundary with fp16 operands + fp32 accumulate
-    dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float16}[variant]
+    dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[variant]
     pipe = EtaPipeline(device=device, dtype=dtype, **kwargs)
     return pipe, (StablePreprocess(pipe.device, size=8 * pipe.engine.L, **(preproc_args or {})), StablePostProc())

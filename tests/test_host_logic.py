@@ -208,3 +208,32 @@ def test_clip_bpe_tokenizer_matches_transformers(tmp_path):
     assert (nat.bos_token_id, nat.eos_token_id) == (ref.bos_token_id, ref.eos_token_id)
     ids = nat.encode("a wooden chair")
     assert [nat.decode([i]) for i in ids[1:-1]] == [ref.decode([i]) for i in ids[1:-1]]      # ptp_utils.get_word_inds decodes single ids
+
+
+def test_cv2_linear_resize_restatement():
+    """modules/models/resize.py vs values worked out by hand from OpenCV's fixed-point INTER_LINEAR (11-bit coefficients, taps at pixel
+    centres, edge clamping, no antialiasing) -- the reference preprocesses with cv2.resize (modules/models/__init__.py:64)."""
+    from modules.models.resize import resize_linear_u8
+    # 1 x 2 -> 1 x 4: f = (d + .5) / 2 - .5 = -.25, .25, .75, 1.25 -> clamp, (1536, 512), (512, 1536), clamp
+    #   H = 255 * 512 = 130560; (2048 * (130560 >> 4)) >> 16 = 255; (255 + 2) >> 2 = 64;   255 * 1536 -> 765 -> 191
+    out = resize_linear_u8(np.array([[0, 255]], np.uint8), (4, 1))
+    assert out.tolist() == [[0, 64, 191, 255]]
+    # down-scale 1 x 6 -> 1 x 2 (factor 3): f = 1.0 and 4.0 exactly -> single taps on pixels 1 and 4: NO averaging of the neighbours
+    out = resize_linear_u8(np.array([[10, 200, 30, 40, 90, 60]], np.uint8), (2, 1))
+    assert out.tolist() == [[200, 90]]
+    # 4 x 4 -> 2 x 2 is the exact-2x case: box mean with rounding
+    img = np.arange(16, dtype=np.uint8).reshape(4, 4) * 10
+    assert resize_linear_u8(img, (2, 2)).tolist() == [[(0 + 10 + 40 + 50 + 2) >> 2, (20 + 30 + 60 + 70 + 2) >> 2],
+                                                      [(80 + 90 + 120 + 130 + 2) >> 2, (100 + 110 + 140 + 150 + 2) >> 2]]
+    # 2 x 2 -> 3 x 3, vertical and horizontal coefficients together: f = (d + .5) * 2/3 - .5 = -1/6, 1/2, 7/6 -> (0, 0), (0, .5), (1, 0)
+    #   centre: H rows = (0*1024 + 100*1024, 200*1024 + 40*1024) = (102400, 245760); >> 4 = (6400, 15360); * 1024 >> 16 = (100, 240); (340 + 2) >> 2 = 85
+    out = resize_linear_u8(np.array([[0, 100], [200, 40]], np.uint8), (3, 3))
+    assert out.tolist() == [[0, 50, 100], [100, 85, 70], [200, 120, 40]]
+    # multi-channel images keep their channel order; identity size is a copy
+    rgb = np.random.default_rng(0).integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    up = resize_linear_u8(rgb, (14, 10))
+    assert up.shape == (10, 14, 3) and all(np.array_equal(up[..., c], resize_linear_u8(rgb[..., c], (14, 10))) for c in range(3))
+    assert np.array_equal(resize_linear_u8(rgb, (7, 5)), rgb)
+    # float bilinear (align_corners=False, no antialias) agrees within one grey level
+    ref = torch.nn.functional.interpolate(torch.from_numpy(rgb).permute(2, 0, 1)[None].float(), size=(10, 14), mode="bilinear", align_corners=False)
+    assert np.abs(up.astype(np.int32) - ref[0].permute(1, 2, 0).round().numpy().astype(np.int32)).max() <= 1
