@@ -578,6 +578,19 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
       }
     }
 
+    // ---- V^T fragments of the tile (shared by the query blocks), requested BEFORE the exponentials: 16 transposed reads whose LDS latency
+    // is then covered by ~300 cycles of v_exp instead of standing in front of every MFMA
+    v8 vf[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const T* vp_ = (dt ? tV1 : tV0) + ks * 16 * VROW;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp_));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp_ + 8 * VROW));
+        vf[ks][dt] = __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+    __builtin_amdgcn_sched_barrier(0);   // keep the reads up here (the scheduler otherwise sinks each pair to just before its MFMA)
     // ---- P = exp2(S') packed straight into the PV operands, O^T += V^T P^T
     v8 pf[QB][4];
 #pragma unroll
@@ -589,13 +602,7 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const T* vp_ = (dt ? tV1 : tV0) + ks * 16 * VROW;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp_));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp_ + 8 * VROW));
-          const v8 vf = __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-          o[qb][dt] = Frag32<T>::mfma(vf, pf[qb][ks], o[qb][dt]);
-        }
+        for (int dt = 0; dt < 2; ++dt) o[qb][dt] = Frag32<T>::mfma(vf[ks][dt], pf[qb][ks], o[qb][dt]);
     }
 
     if (j + 1 < ntiles) store_kv(cur ^ 1);   // buffer cur^1 was last read in iteration j-1, a barrier ago

@@ -170,9 +170,34 @@ __global__ void ddim_eta_step_kernel(const T* __restrict__ x, const T* __restric
   out[i] = from_f32<T>(xn);
 }
 
+// out = a x + b y + c z (z optional): the update of the multistep DPM-Solver++ schedulers (x_t = (sigma_t / sigma_s) x - c0 m0 - c1 (m0 - m1))
+template <typename T>
+__global__ void lincomb3_kernel(const T* __restrict__ x, float a, const T* __restrict__ y, float b, const T* __restrict__ z, float c,
+                                T* __restrict__ out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float v = a * to_f32(x[i]) + b * to_f32(y[i]);
+    if (z) v += c * to_f32(z[i]);
+    out[i] = from_f32<T>(v);
+  }
+}
+
 }  // namespace etainv
 
 using namespace etainv;
+
+extern "C" int etainv_lincomb3(const void* x, float a, const void* y, float b, const void* z, float c, void* out, int64_t n, int io_dtype,
+                               void* stream) {
+  ETAINV_CHECK(x && y && out && n >= 0, "null pointer or negative size");
+  if (n == 0) return 0;
+  const int grid = (int)std::min<int64_t>(cdiv(n, 256), 2048);
+  ETAINV_DISPATCH_DTYPE(io_dtype, T,
+                        hipLaunchKernelGGL(lincomb3_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, a, (const T*)y, b,
+                                           (const T*)z, c, (T*)out, n));
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int etainv_ddim_eta_step(const void* x, const void* eps, float eta, const void* eta_mask, int n_mask, const void* noise,
                                     float a_t, float a_p, float var, int rows, int c, int hw, void* out, int io_dtype, void* stream) {

@@ -38,6 +38,7 @@ SIGNATURES = {
     "etainv_ddim_eta_step": [_p, _p, _f, _p, _i, _p, _f, _f, _f, _i, _i, _i, _p, _i, _p],
     "etainv_eta_backward_step": [_p, _p, _f, _p, _p, _i, _f, _p, _f, _i, _f, _f, _f, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
     "etainv_eta_backward_step_ex": [_p, _p, _f, _p, _p, _i, _f, _p, _f, _i, _f, _f, _f, _i, _i, _i, _p, _p, _p, _p, _p, _i, _f, _p, _p],
+    "etainv_lincomb3": [_p, _f, _p, _f, _p, _f, _p, _i64, _i, _p],
     "etainv_engine_create": [C.POINTER(EngineConfig), C.POINTER(_p)],
     "etainv_engine_destroy": [_p],
     "etainv_engine_num_weights": [_p],

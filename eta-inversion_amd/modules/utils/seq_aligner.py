@@ -1,4 +1,7 @@
 """Token alignment between source and target prompt (host side, a few hundred integer ops per image).
+The alignment conventions (word -> token counting rule, replacement matrix, refinement mapper) are those of prompt-to-prompt's
+seq_aligner.py (github.com/google/prompt-to-prompt, Copyright 2022 Google LLC, Apache License 2.0), which the reference vendors as
+modules/utils/seq_aligner.py; this file re-implements them and is checked against tables produced by that code (tests/golden/ptp_tables.npz).
 Interface of the reference's modules/utils/seq_aligner.py: get_refinement_mapper (:127-134), get_mapper (:113-124),
 get_replacement_mapper (:195-201), get_word_inds (:137-155).  The global alignment is Needleman-Wunsch with
 gap 0 / match +1 / mismatch -1 and the reference's tie order (left, then up, then diagonal; :67-82)."""
@@ -57,52 +60,62 @@ def get_refinement_mapper(prompts, tokenizer, max_len=77):
     return torch.stack([m for m, _ in out]), torch.stack([a for _, a in out])
 
 
+def word_token_spans(text: str, tokenizer):
+    """For every whitespace word of `text`: the positions (1-based, after BOS) of its tokens.  A word owns the following token pieces until
+    their decoded characters cover its length -- the counting rule of prompt-to-prompt's get_word_inds."""
+    words = text.split(" ")
+    pieces = [tokenizer.decode([t]).strip("#") for t in tokenizer.encode(text)][1:-1]
+    spans = [[] for _ in words]
+    word = covered = 0
+    for pos, piece in enumerate(pieces, start=1):
+        spans[word].append(pos)
+        covered += len(piece)
+        if covered >= len(words[word]):
+            word, covered = word + 1, 0
+    return words, spans
+
+
 def get_word_inds(text: str, word_place, tokenizer) -> np.ndarray:
-    """token positions (1-based, after BOS) of a word given by string or by word index"""
+    """token positions of a word given by string (every occurrence), by word index or by a list of word indices"""
     words = text.split(" ")
     if isinstance(word_place, str):
-        wanted = {i for i, w in enumerate(words) if w == word_place}
+        wanted = [i for i, w in enumerate(words) if w == word_place]
     elif isinstance(word_place, int):
-        wanted = {word_place}
+        wanted = [word_place]
     else:
-        wanted = set(word_place)
-    out = []
-    if wanted:
-        pieces = [tokenizer.decode([t]).strip("#") for t in tokenizer.encode(text)][1:-1]
-        word, consumed = 0, 0
-        for pos, piece in enumerate(pieces):
-            consumed += len(piece)
-            if word in wanted:
-                out.append(pos + 1)
-            if consumed >= len(words[word]):
-                word, consumed = word + 1, 0
-    return np.array(out, dtype=np.int64)
+        wanted = list(word_place)
+    if not wanted:
+        return np.array([], dtype=np.int64)
+    _, spans = word_token_spans(text, tokenizer)
+    return np.array(sorted(p for w in set(wanted) for p in spans[w]), dtype=np.int64)
 
 
 def get_replacement_mapper_(x: str, y: str, tokenizer, max_len=77) -> torch.Tensor:
-    wx, wy = x.split(" "), y.split(" ")
+    """(max_len, max_len) matrix M of AttentionReplace: target probabilities = source probabilities @ M.  Tokens of unchanged words map
+    one to one (in running source / target positions), a replaced word spreads its source tokens over the target word's tokens (1 each
+    for equal token counts, else 1 / #target tokens), and everything after the last replaced word is the identity on the TARGET position
+    (prompt-to-prompt's convention, including its stop when either running position reaches max_len)."""
+    (wx, sx), (wy, sy) = word_token_spans(x, tokenizer), word_token_spans(y, tokenizer)
     if len(wx) != len(wy):
         raise ValueError(f"attention replacement edit can only be applied on prompts with the same length"
                          f" but prompt A has {len(wx)} words and prompt B has {len(wy)} words.")
-    changed = [i for i in range(len(wy)) if wy[i] != wx[i]]
-    src = [get_word_inds(x, i, tokenizer) for i in changed]
-    tgt = [get_word_inds(y, i, tokenizer) for i in changed]
     m = np.zeros((max_len, max_len))
-    i = j = k = 0
-    while i < max_len and j < max_len:
-        if k < len(src) and src[k][0] == i:
-            if len(src[k]) == len(tgt[k]):
-                m[src[k], tgt[k]] = 1
-            else:
-                for jt in tgt[k]:
-                    m[src[k], jt] = 1 / len(tgt[k])
-            i, j, k = i + len(src[k]), j + len(tgt[k]), k + 1
-        elif k < len(src):
-            m[i, j] = 1
-            i, j = i + 1, j + 1
+    i = j = 0                                        # running source / target token position
+    for w in range(len(wy)):
+        if wy[w] == wx[w]:
+            continue
+        src, tgt = np.array(sx[w]), np.array(sy[w])
+        same = int(src[0]) - i                       # unchanged tokens in front of this word
+        if same > 0:
+            m[np.arange(i, i + same), np.arange(j, j + same)] = 1
+            i, j = i + same, j + same
+        if len(src) == len(tgt):
+            m[src, tgt] = 1
         else:
-            m[j, j] = 1
-            i, j = i + 1, j + 1
+            m[np.ix_(src, tgt)] = 1 / len(tgt)
+        i, j = i + len(src), j + len(tgt)
+    tail = np.arange(j, j + max(0, max_len - max(i, j)))
+    m[tail, tail] = 1
     return torch.from_numpy(m).float()
 
 

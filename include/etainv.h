@@ -84,6 +84,11 @@ int etainv_eta_backward_step_ex(const void* x, const void* eps_all, float g, con
                                 void* out_x, void* out_eps, int32_t* best_idx, float* losses, float* scratch, int io_dtype,
                                 float target_dirinv, const void* dirinv_map, void* stream);
 
+/* out = a x + b y + c z over n elements (z may be NULL): the latent update of the multistep DPM-Solver++ scheduler pair
+ * (reference modules/inverse_schedulers/scheduling_dpmsolver_multistep_inverse.py:83-159 and the [3P] diffusers
+ * DPMSolverMultistepScheduler.step behind DiffusionInversion.step_backward, modules/inversion/diffusion_inversion.py:279-312) */
+int etainv_lincomb3(const void* x, float a, const void* y, float b, const void* z, float c, void* out, int64_t n, int io_dtype, void* stream);
+
 /* ---------------------------------------------------------------- engine */
 typedef struct etainv_engine etainv_engine_t;
 

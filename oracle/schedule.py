@@ -98,3 +98,81 @@ def eta_table(eta=(0.0, 0.4)) -> np.ndarray:
     else:
         etas = np.linspace(eta[0], eta[1], NUM_TRAIN)
     return np.clip(etas, 0, None)
+
+
+# ----------------------------------------------------------------------------- DPM-Solver++ (2M), forward and inverse
+# [3P] diffusers 0.21.1 DPMSolverMultistepScheduler / DPMSolverMultistepInverseScheduler with the configuration the reference builds
+# (diffusion_inversion.py:130-165: `from_config({**model.scheduler.config})` -> solver_order 2, algorithm_type "dpmsolver++", solver_type
+# "midpoint", epsilon prediction, lower_order_final, no Karras sigmas, timestep_spacing "leading" inherited from the DDIM scheduler
+# config of modules/models/__init__.py:134).  diffusers is not vendored in /root/reference and not installed: these functions restate the
+# published scheduler from its documented formulas (DPM-Solver++ arXiv:2211.01095, eqs. 11-13) -- PARITY UNPINNED against diffusers
+# itself; what IS checked: the first-order update equals the DDIM step exactly, the 2M update reproduces the exact solution for a
+# noise prediction that is linear in lambda, and the native scheduler classes agree with these functions.
+def dpm_tables(ac: np.ndarray):
+    ac = np.asarray(ac, dtype=np.float64)
+    alpha_t, sigma_t = np.sqrt(ac), np.sqrt(1.0 - ac)
+    return alpha_t, sigma_t, np.log(alpha_t) - np.log(sigma_t)
+
+
+def dpm_timesteps_backward(S: int, spacing: str = "leading", steps_offset: int = 0) -> np.ndarray:
+    """DPMSolverMultistepScheduler.set_timesteps: S + 1 grid points over [0, 1000), reversed, the last one (0) dropped"""
+    if spacing == "linspace":
+        t = np.linspace(0, NUM_TRAIN - 1, S + 1).round()[::-1][:-1]
+    else:
+        t = (np.arange(0, S + 1) * (NUM_TRAIN // (S + 1))).round()[::-1][:-1] + steps_offset
+    return t.astype(np.int64).copy()
+
+
+def dpm_timesteps_forward(S: int, spacing: str = "leading", steps_offset: int = 0) -> np.ndarray:
+    """DPMSolverMultistepInverseScheduler.set_timesteps: the same grid ascending from 0; the step after the last goes to the noisiest
+    timestep 999"""
+    if spacing == "linspace":
+        t = np.linspace(0, NUM_TRAIN - 1, S + 1).round()[:-1]
+    else:
+        t = (np.arange(0, S + 1) * (NUM_TRAIN // (S + 1))).round()[:-1] + steps_offset
+    return t.astype(np.int64).copy()
+
+
+def dpm_x0(x, eps, tabs, t: int):
+    """convert_model_output, epsilon prediction, dpmsolver++: the data prediction"""
+    alpha_t, sigma_t, _ = tabs
+    return (x - sigma_t[t] * eps) / alpha_t[t]
+
+
+def dpm_first_order(x, m0, tabs, s: int, t: int):
+    """x_t from x_s with data prediction m0 (DPM-Solver++ eq. 11); identical to a deterministic DDIM step s -> t"""
+    alpha_t, sigma_t, lam = tabs
+    h = lam[t] - lam[s]
+    return (sigma_t[t] / sigma_t[s]) * x - (alpha_t[t] * (np.exp(-h) - 1.0)) * m0
+
+
+def dpm_second_order(x, m0, m1, tabs, s1: int, s0: int, t: int):
+    """multistep 2M midpoint update s0 -> t with the previous data prediction m1 taken at s1"""
+    alpha_t, sigma_t, lam = tabs
+    h, h0 = lam[t] - lam[s0], lam[s0] - lam[s1]
+    r0 = h0 / h
+    d1 = (1.0 / r0) * (m0 - m1)
+    c = alpha_t[t] * (np.exp(-h) - 1.0)
+    return (sigma_t[t] / sigma_t[s0]) * x - c * m0 - 0.5 * c * d1
+
+
+class DpmStepper:
+    """One direction of the multistep recursion with the scheduler's history (model_outputs, lower_order_nums).  `grid` = the loop
+    timesteps, `last` = where the step after the last grid point lands (0 backward, 999 forward)."""
+
+    def __init__(self, ac, grid, last: int, lower_order_final: bool = True):
+        self.tabs, self.grid, self.last, self.lof = dpm_tables(ac), [int(t) for t in grid], int(last), lower_order_final
+        self.prev_m, self.n_lower = None, 0
+
+    def step(self, eps, t: int, x, i: int):
+        """scheduler.step at loop index i (timestep t == grid[i])"""
+        nxt = self.last if i == len(self.grid) - 1 else self.grid[i + 1]
+        m0 = dpm_x0(x, eps, self.tabs, t)
+        final = i == len(self.grid) - 1 and self.lof and len(self.grid) < 15
+        if self.n_lower < 1 or final:
+            out = dpm_first_order(x, m0, self.tabs, t, nxt)
+        else:
+            out = dpm_second_order(x, m0, self.prev_m, self.tabs, self.grid[i - 1], t, nxt)
+        self.prev_m = m0
+        self.n_lower = min(self.n_lower + 1, 2)
+        return out
