@@ -45,10 +45,14 @@ def parse_args(argv=None):
 def main(argv=None):
     a = parse_args(argv)
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    # "nccl" = RCCL over xGMI on the GPU box; ETAINV_DIST_BACKEND=gloo runs the same sharding / gather / resume plumbing on CPU (tests)
+    backend = os.environ.get("ETAINV_DIST_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend)
     data = PieBenchData(a.data_path, skip_img_load=True, limit=a.limit, categories=a.categories)
     out_dir = Path(a.output) / "imgs"
     out_dir.mkdir(parents=True, exist_ok=True)
@@ -58,7 +62,7 @@ def main(argv=None):
         f = out_dir / f"{edit_image_name(i, s['source_prompt'], s['edit']['target_prompt'])}.png"
         if a.override or not f.exists():                           # skip-existing resume (eval_utils.py:256-258)
             todo.append((i, s, f))
-    pipe, (preproc, postproc) = load_diffusion_model(a.model, f"cuda:{local}" if world > 1 else "cuda", variant=a.prec,
+    pipe, (preproc, postproc) = load_diffusion_model(a.model, f"cuda:{local}" if world > 1 and backend == "nccl" else "cuda", variant=a.prec,
                                                      latent_size=a.size // 8, max_img=a.batch)
     editor = BatchEditor(pipe, num_inference_steps=a.steps, edit_method=a.edit_method)
     from PIL import Image

@@ -8,8 +8,8 @@ import torch
 
 from etainv import _capi
 from ..editing.controller import ControllerBase, ControllerEmpty
-from ..inverse_schedulers import DDIMInverseScheduler
-from ..schedulers import DDIMScheduler
+from ..inverse_schedulers import DDIMInverseScheduler, DPMSolverMultistepInverseScheduler
+from ..schedulers import DDIMScheduler, DPMSolverMultistepScheduler
 
 
 class DiffusionInversion:
@@ -52,8 +52,16 @@ class DiffusionInversion:
                 scheduler_inv_kwargs["inv_steps"] = kw.pop("inv_steps")
         else:
             raise Exception(type(scheduler))
+        if name == "dpm":                                                  # DPM-Solver++(2M) pair (reference :139-165)
+            sched = DPMSolverMultistepScheduler.from_config({**model.scheduler.config, **kw})
+            sched.set_timesteps(num_inference_steps)
+            fwd = DPMSolverMultistepInverseScheduler.from_scheduler(sched, **scheduler_inv_kwargs)
+            fwd.set_timesteps(num_inference_steps)
+            assert fwd.timesteps[0] < fwd.timesteps[1], "wrong timestamp order, not increasing"
+            return sched, sched, fwd
         if name != "ddim":
-            raise NotImplementedError(f"scheduler '{name}' is not built in the MI355X engine yet (only 'ddim'; SURVEY 8f-4)")
+            raise NotImplementedError(f"scheduler '{name}' is not built in the MI355X engine (built: 'ddim', 'dpm'; 'ddpm' needs the stochastic "
+                                      "DDPM inverse scheduler, outside the etainv hot path)")
         kw = {"clip_sample": False, "set_alpha_to_one": False, **kw}
         sched = DDIMScheduler.from_config({**model.scheduler.config, **kw})
         sched.set_timesteps(num_inference_steps)

@@ -38,6 +38,9 @@ class EtaInversion(DiffusionInversion):
         if isinstance(guidance_scale_fwd, (tuple, list)):                  # per-timestep table (reference :108-110): handled by the native loop
             assert len(guidance_scale_fwd) == 2
             g_fwd_pair, guidance_scale_fwd = tuple(guidance_scale_fwd), None
+        name = scheduler if isinstance(scheduler, str) or scheduler is None else scheduler.get("type")
+        if name not in (None, "ddim"):                                     # the backward step passes eta / variance_noise (reference :245): DDIM only
+            raise NotImplementedError(f"etainv / dirinv step the backward pass with DDIM(eta); scheduler '{name}' has no eta (use diffinv for 'dpm')")
         super().__init__(model, scheduler, num_inference_steps, guidance_scale_bwd, guidance_scale_fwd, verbose)
         self._g_fwd_pair = g_fwd_pair
         if eta_start is not None:

@@ -237,3 +237,32 @@ def test_cv2_linear_resize_restatement():
     # float bilinear (align_corners=False, no antialias) agrees within one grey level
     ref = torch.nn.functional.interpolate(torch.from_numpy(rgb).permute(2, 0, 1)[None].float(), size=(10, 14), mode="bilinear", align_corners=False)
     assert np.abs(up.astype(np.int32) - ref[0].permute(1, 2, 0).round().numpy().astype(np.int32)).max() <= 1
+
+
+def test_dpm_solver_oracle_properties():
+    """oracle.schedule DPM-Solver++ restatement ([3P] diffusers is absent: these are the checks that stand in for a pin): the first-order
+    update IS the deterministic DDIM step; with a data prediction that is linear in lambda the 2M update is exact (it integrates
+    alpha_t * int e^{-lambda} x0(lambda) dlambda with x0 linear), i.e. it beats first order by orders of magnitude; timestep grids."""
+    from oracle import schedule as sch
+    ac = sch.alphas_cumprod()
+    tabs = sch.dpm_tables(ac)
+    alpha, sigma, lam = tabs
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64)
+    eps = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64)
+    for s, t in ((500, 480), (20, 0), (300, 320), (980, 999)):
+        a = sch.dpm_first_order(x, sch.dpm_x0(x, eps, tabs, s), tabs, s, t)
+        assert torch.allclose(a, sch.ddim_step(x, eps, float(ac[s]), float(ac[t])), rtol=0, atol=1e-12)
+    # exact solution of dx/dlambda for x0(lambda) = A + B lambda:  x_t = (sigma_t/sigma_s) x_s + alpha_t [ (A + B lambda_t) - e^{-h} (A + B lambda_s) ] - alpha_t B (1 - e^{-h})
+    A, B = torch.randn(4, generator=g, dtype=torch.float64), 0.3 * torch.randn(4, generator=g, dtype=torch.float64)
+    x0 = lambda t: A + B * lam[t]
+    s1, s0, t = 700, 680, 660
+    xs = torch.randn(4, generator=g, dtype=torch.float64)
+    h = lam[t] - lam[s0]
+    exact = (sigma[t] / sigma[s0]) * xs + alpha[t] * ((x0(t) - B) - np.exp(-h) * (x0(s0) - B))
+    e2 = (sch.dpm_second_order(xs, x0(s0), x0(s1), tabs, s1, s0, t) - exact).abs().max()
+    e1 = (sch.dpm_first_order(xs, x0(s0), tabs, s0, t) - exact).abs().max()
+    assert e2 < 0.05 * e1 and e2 < 1e-3
+    assert sch.dpm_timesteps_backward(50).tolist()[:3] == [950, 931, 912] and sch.dpm_timesteps_backward(50)[-1] == 19
+    assert sch.dpm_timesteps_forward(50).tolist()[:3] == [0, 19, 38] and len(sch.dpm_timesteps_forward(50)) == 50
+    assert sch.dpm_timesteps_backward(10, "linspace").tolist() == [999, 899, 799, 699, 599, 500, 400, 300, 200, 100]

@@ -231,3 +231,60 @@ def test_diffinv_plugin_vs_oracle(no_source_backward):
     else:
         assert rel(res["latent_inv"], z[:1]) < 3e-2 and rel(res["latent"], z[1:]) < 3e-2
     pipe.engine.close()
+
+
+def test_dpm_solver_schedulers_vs_oracle():
+    """The native DPM-Solver++(2M) pair (modules/schedulers.py, modules/inverse_schedulers/scheduling_dpmsolver_multistep_inverse.py; latent
+    updates through etainv_lincomb3) vs the oracle's independent restatement, forward and backward, on a synthetic noise prediction."""
+    from modules.schedulers import DDIMScheduler, DPMSolverMultistepScheduler
+    from modules.inverse_schedulers import DPMSolverMultistepInverseScheduler
+    from oracle import schedule as sch
+    S = 12
+    base = DDIMScheduler()
+    bwd = DPMSolverMultistepScheduler.from_config(base.config)
+    bwd.set_timesteps(S)
+    fwd = DPMSolverMultistepInverseScheduler.from_scheduler(bwd)
+    fwd.set_timesteps(S)
+    assert fwd.timesteps.tolist() == sch.dpm_timesteps_forward(S).tolist() and bwd.timesteps.tolist() == sch.dpm_timesteps_backward(S).tolist()
+    ac = sch.alphas_cumprod()
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.randn(1, 4, 16, 16, generator=g)
+    model = lambda x, t: torch.tanh(0.7 * x) * (0.5 + t / 1000.0)                 # any deterministic eps(x, t)
+    of, ob = sch.DpmStepper(ac, fwd.timesteps, 999), sch.DpmStepper(ac, bwd.timesteps, 0)
+    xr, xn = x0.double(), x0.cuda()
+    for i, t in enumerate(fwd.timesteps):
+        xr = of.step(model(xr, int(t)), int(t), xr, i)
+        xn = fwd.step(model(xn, int(t)), t, xn).prev_sample
+        torch.testing.assert_close(xn.cpu().double(), xr, rtol=2e-5, atol=2e-5)
+    for i, t in enumerate(bwd.timesteps):
+        xr = ob.step(model(xr, int(t)), int(t), xr, i)
+        xn = bwd.step(model(xn, int(t)), t, xn).prev_sample
+        torch.testing.assert_close(xn.cpu().double(), xr, rtol=1e-4, atol=1e-4)
+
+
+def test_diffinv_dpm_plugin_vs_oracle():
+    """`diffinv --scheduler dpm` + simple editor through the plugin API vs the oracle loop driven by the oracle's DPM steppers"""
+    from modules import load_diffusion_model, load_inverter, load_editor
+    from oracle import loop as oloop, schedule as sch
+    from oracle.unet import build_unet
+    S, L = 4, 16
+    pipe, _ = load_diffusion_model("CompVis/stable-diffusion-v1-4", "cuda", variant="fp16", latent_size=L, max_img=1)
+    inv = load_inverter(type="diffinv", model=pipe, scheduler="dpm", num_inference_steps=S)
+    with pytest.raises(NotImplementedError):
+        load_inverter(type="etainv", model=pipe, scheduler="dpm", num_inference_steps=S)
+    ed = load_editor(type="simple", inverter=inv)
+    src, tgt = "a cat sitting on a chair", "a tiger sitting on a chair"
+    z0 = 0.8 * torch.randn(1, 4, L, L, generator=torch.Generator().manual_seed(6))
+    inv.encode = lambda image: image.to("cuda").float()
+    res = ed.edit(z0, src, tgt)
+    ctx_s, ctx_t = inv.create_context(src).cpu(), inv.create_context(tgt).cpu()
+    ac = sch.alphas_cumprod()
+    tf, tb = sch.dpm_timesteps_forward(S), sch.dpm_timesteps_backward(S)
+    sf, sb = sch.DpmStepper(ac, tf, 999), sch.DpmStepper(ac, tb, 0)
+    with torch.no_grad():
+        o = oloop.DiffusionInversionOracle(build_unet(0), S=S, step_fwd=sf.step, step_bwd=sb.step)
+        o.t_fwd, o.t_bwd = tf, tb
+        z = o.sample(o.invert(z0, ctx_s), [ctx_s, ctx_t])
+    rel = lambda a, b: ((a.float().cpu() - b.float()).norm() / b.float().norm()).item()
+    assert rel(res["latent_inv"], z[:1]) < 3e-2 and rel(res["latent"], z[1:]) < 3e-2
+    pipe.engine.close()

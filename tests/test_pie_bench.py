@@ -84,3 +84,67 @@ def test_eval_driver_host_logic(tmp_path, monkeypatch):
     n_calls = len(calls)
     pie_eval.main(argv)                                   # resume: only the samples without an output (the None ones) are retried
     assert sum(len(c) for c in calls[n_calls:]) == len(g["records"]) - len(want)
+
+
+def _eval_rank(rank, world, port, root, out, q):
+    """one rank of eval.py under gloo with a fake engine: sharding, skip-existing, None results, latent gather, latents.pt on rank 0"""
+    import sys
+    import torch
+    for p in (str(Path(__file__).resolve().parents[1]), str(Path(__file__).resolve().parents[1] / "eta-inversion_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      ETAINV_DIST_BACKEND="gloo")
+    import eval as pie_eval
+    seen = []
+
+    class FakePipe:
+        device = "cpu"
+
+    class FakeEditor:
+        def __init__(self, pipe, num_inference_steps=50, edit_method="ptp"):
+            pass
+
+        def edit(self, samples):
+            seen.extend(s["source_prompt"] for s in samples)
+            return [None if None in s["edit_word_idx"] else
+                    {"image": torch.zeros(1, 3, 16, 16), "latent": torch.full((1, 4, 2, 2), float(len(s["source_prompt"])))} for s in samples]
+    pie_eval.load_diffusion_model = lambda *a, **k: (FakePipe(), (lambda f: torch.zeros(1, 3, 16, 16), lambda img: np.zeros((16, 16, 3), np.uint8)))
+    pie_eval.BatchEditor = FakeEditor
+    pie_eval.main(["--data_path", root, "--output", out, "--batch", "2", "--steps", "2", "--size", "16", "--save_latents"])
+    q.put((rank, seen))
+
+
+def test_eval_two_ranks_gloo(tmp_path):
+    """eval.py end to end with WORLD_SIZE = 2 (gloo, fake engine): what the 8-GPU sweep runs apart from the kernels -- image i on rank
+    i % 2, every output written exactly once, edited latents of both ranks gathered in image order into latents.pt on rank 0."""
+    import torch
+    import torch.multiprocessing as mp
+    from PIL import Image
+    g = json.loads((GOLD / "pie_bench.json").read_text())
+    root = tmp_path / "pie"
+    (root / "annotation_images" / "0_random_140").mkdir(parents=True)
+    (root / "mapping_file.json").write_text(json.dumps(g["mapping"]))
+    for rec in g["records"]:
+        Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(str(root / rec["image_rel"]))
+    out = tmp_path / "res"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_eval_rank, args=(r, 2, port, str(root), str(out), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    recs = g["records"]
+    for r in (0, 1):
+        assert res[r] == [recs[i]["source_prompt"] for i in range(r, len(recs), 2)]          # rank r edits images r, r + 2, ...
+    names = sorted(f.name for f in (out / "imgs").glob("*.png"))
+    assert names == sorted(f"{i:04d}_{r['source_prompt']}_{r['target_prompt']}.png" for i, r in enumerate(recs) if None not in r["edit_word_idx"])
+    lat = torch.load(str(out / "latents.pt"))
+    assert lat.shape == (len(recs), 4, 2, 2)
+    for i, r in enumerate(recs):
+        want = 0.0 if None in r["edit_word_idx"] else float(len(r["source_prompt"]))
+        assert float(lat[i, 0, 0, 0]) == want
