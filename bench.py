@@ -205,6 +205,9 @@ def main():
     ca_ms, ca_flop, ca_n = prof(2)
     gn_ms, gn_bytes, gn_n = prof(3)
     ln_ms, ln_bytes, ln_n = prof(4)
+    split, split_n = (C.c_double * 6)(), (C.c_int64 * 2)()
+    ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)          # 312.5 FLOP per byte
+    _capi.check(lib.etainv_prof_split(0, ridge, split, split_n))
     traffic = None          # fabric-side bytes per igemm launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     tfile = ROOT / "profiles" / "r01e_pmc_traffic_rows128.json"   # (tools/unet_call.py --rows 128, tools/pmc_traffic.py)
     if tfile.exists():
@@ -227,6 +230,13 @@ def main():
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "launches": ig_n, "avg_launch_ms": ig_ms / max(ig_n, 1), "share_of_wall": ig_ms * 1e-3 / dt_prof,
                          "measured_on": "one extra step after the timed region, HIP events on the launch stream"},
+            # the same igemm launches split by which roofline bounds them (algorithmic intensity of the launch vs the 312.5 FLOP/B ridge): the
+            # K <= 640 projections of the transformer blocks move more bytes than the MFMA peak could consume
+            "igemm_by_bound": {
+                "mfma_bound": {"launches": split_n[0], "tflops": split[1] / max(split[0], 1e-9) / 1e9, "frac_of_mfma_peak": split[1] / max(split[0], 1e-9) / 1e9 / MFMA_PEAK_TFLOPS,
+                               "share_of_igemm_time": split[0] / max(split[0] + split[3], 1e-9)},
+                "hbm_bound": {"launches": split_n[1], "algorithmic_gbs": split[5] / max(split[3], 1e-9) / 1e6, "frac_of_hbm_peak": split[5] / max(split[3], 1e-9) / 1e6 / HBM_PEAK_GBS,
+                              "tflops": split[4] / max(split[3], 1e-9) / 1e9, "share_of_igemm_time": split[3] / max(split[0] + split[3], 1e-9)}},
             "other_kernels": {
                 "self_attention": {"tflops": sa_flop / max(sa_ms, 1e-9) / 1e9, "share_of_wall": sa_ms * 1e-3 / dt_prof, "launches": sa_n},
                 "cross_attention": {"tflops": ca_flop / max(ca_ms, 1e-9) / 1e9, "share_of_wall": ca_ms * 1e-3 / dt_prof, "launches": ca_n},

@@ -108,12 +108,14 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 enum ProfClass { PROF_IGEMM = 0, PROF_SELF_ATTN = 1, PROF_CROSS_ATTN = 2, PROF_GROUPNORM = 3, PROF_LAYERNORM = 4, PROF_OTHER = 5, PROF_NCLASS = 6 };
 bool prof_enabled();
 void prof_pause(bool on);   // nested launchers: the outer scope times the whole operation
-void prof_begin(int cls, double work, hipStream_t s);
+void prof_begin(int cls, double work, hipStream_t s, double bytes = 0.0);
 void prof_end(hipStream_t s);
 struct ProfScope {
   hipStream_t s;
   bool on;
-  ProfScope(int cls, double work, hipStream_t st) : s(st), on(prof_enabled()) { if (on) prof_begin(cls, work, s); }
+  // bytes: algorithmic HBM bytes of the launch (every operand read once, the result written once) -- with `work` = FLOPs it gives the
+  // launch's arithmetic intensity, i.e. which roofline bounds it
+  ProfScope(int cls, double work, hipStream_t st, double bytes = 0.0) : s(st), on(prof_enabled()) { if (on) prof_begin(cls, work, s, bytes); }
   ~ProfScope() { if (on) prof_end(s); }
 };
 

@@ -25,7 +25,7 @@ static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 
 // ---- profiler
-struct ProfRec { int cls; double work; hipEvent_t a, b; };
+struct ProfRec { int cls; double work, bytes; hipEvent_t a, b; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
@@ -33,7 +33,7 @@ static size_t g_prof_used = 0;
 static bool g_prof_paused = false;
 bool prof_enabled() { return g_prof_on && !g_prof_paused; }
 void prof_pause(bool on) { g_prof_paused = on; }
-void prof_begin(int cls, double work, hipStream_t s) {
+void prof_begin(int cls, double work, hipStream_t s, double bytes) {
   if (g_prof_used == g_prof_pool.size()) {
     hipEvent_t a, b;
     (void)hipEventCreate(&a);
@@ -41,7 +41,7 @@ void prof_begin(int cls, double work, hipStream_t s) {
     g_prof_pool.emplace_back(a, b);
   }
   auto& ev = g_prof_pool[g_prof_used++];
-  g_prof.push_back({cls, work, ev.first, ev.second});
+  g_prof.push_back({cls, work, bytes, ev.first, ev.second});
   (void)hipEventRecord(ev.first, s);
 }
 void prof_end(hipStream_t s) { (void)hipEventRecord(g_prof.back().b, s); }
@@ -746,6 +746,26 @@ extern "C" int etainv_prof_records(int cls, double* ms, double* work, int64_t ca
       ++n;
     }
   *launches = n;
+  return 0;
+}
+
+/* Roofline split of one class: launches whose arithmetic intensity work / bytes is at least `ridge` (FLOP per byte; MFMA peak / HBM peak) are
+ * MFMA-bound, the rest HBM-bound.  out[0..2] = ms, FLOPs, bytes of the MFMA-bound launches; out[3..5] = the same of the HBM-bound ones. */
+extern "C" int etainv_prof_split(int cls, double ridge, double* out6, int64_t* launches2) {
+  ETAINV_CHECK(cls >= 0 && cls < PROF_NCLASS && out6 && launches2, "bad arguments");
+  ETAINV_HIP(hipDeviceSynchronize());
+  for (int k = 0; k < 6; ++k) out6[k] = 0.0;
+  launches2[0] = launches2[1] = 0;
+  for (auto& r : g_prof)
+    if (r.cls == cls && r.bytes > 0.0) {
+      float f = 0.f;
+      ETAINV_HIP(hipEventElapsedTime(&f, r.a, r.b));
+      const int o = (r.work / r.bytes >= ridge) ? 0 : 3;
+      out6[o] += f;
+      out6[o + 1] += r.work;
+      out6[o + 2] += r.bytes;
+      ++launches2[o / 3];
+    }
   return 0;
 }
 

@@ -735,6 +735,16 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   }
 }
 
+// algorithmic HBM bytes of one launch: every activation element, weight and residual read once, the result written once (2-byte
+// elements; a 3x3 conv reads its input once, not nine times; the fused upsample reads the SMALL source)
+static double igemm_algo_bytes(const IGemmParams& p) {
+  const double batch = (double)p.M / (double)p.rows_per_batch;
+  const double in_px = p.taps == 9 ? batch * (double)p.H * (double)p.W : (double)p.M;
+  const double out_el = (double)p.M * (double)(p.geglu ? p.N / 2 : p.N);
+  return 2.0 * (in_px * (double)(p.c1 + p.c2) + (double)p.N * (double)p.taps * (double)(p.c1 + p.c2) + out_el * (p.out_f32 ? 2.0 : 1.0) +
+                (p.residual ? out_el : 0.0));
+}
+
 template <typename T, int BM, int BN, int WAVES_M, int STAGES = 2, bool UPS = false>
 static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
   const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN) * (STAGES == 2 && p.ksplit > 1 ? p.ksplit : 1);   // virtual tiles with split-K
@@ -776,7 +786,7 @@ static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
   }
   return 0;
 #endif
-  ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s);
+  ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s, igemm_algo_bytes(p));
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS>), dim3(grid), dim3(WAVES_M * 128), lds, s, p);
   ETAINV_LAUNCH_CHECK();
   return 0;
@@ -866,7 +876,7 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
       pk.rowvec = nullptr;
       pk.residual = nullptr;
     }
-    ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s);
+    ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s, igemm_algo_bytes(p));
     prof_pause(true);
     int rc = 0;
     ETAINV_DISPATCH_HALF(dtype, T, rc = cfg == 0 ? launch_igemm_t<T, 128, 160, 2>(pk, s) : cfg == 1 ? launch_igemm_t<T, 128, 128, 2>(pk, s)

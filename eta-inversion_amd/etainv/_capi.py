@@ -56,6 +56,7 @@ SIGNATURES = {
     "etainv_prof_reset": [],
     "etainv_prof_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)],
     "etainv_prof_records": [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), _i64, C.POINTER(_i64)],
+    "etainv_prof_split": [_i, C.c_double, C.POINTER(C.c_double), C.POINTER(_i64)],
     "etainv_op_gemm": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "etainv_op_conv3x3": [_p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "etainv_op_conv3x3_ex": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -184,6 +184,11 @@ int etainv_prof_read(int cls, double* ms, double* work, int64_t* launches);
  * returns n through *launches (per-shape breakdown of a UNet call: tools/unet_call.py --shapes). */
 int etainv_prof_records(int cls, double* ms, double* work, int64_t cap, int64_t* launches);
 
+/* Roofline split of the launches of one class by arithmetic intensity (algorithmic FLOPs / algorithmic HBM bytes of each launch): out6 =
+ * {ms, FLOPs, bytes} of the launches at or above `ridge` FLOP/byte (MFMA-bound), then of those below it (HBM-bound); launches2 = their counts.
+ * Only the implicit-GEMM class records bytes. */
+int etainv_prof_split(int cls, double ridge, double* out6, int64_t* launches2);
+
 /* Per-op entry points used by the parity tests (tests/test_kernels_gpu.py) -- the same launchers the
  * executor uses, exposed so every kernel is checked against a plain fp32 reference in isolation.
  * Activations NHWC in the compute dtype; weights in the engine layouts described in DESIGN.md. */
