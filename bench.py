@@ -208,10 +208,13 @@ def main():
     split, split_n = (C.c_double * 6)(), (C.c_int64 * 2)()
     ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)          # 312.5 FLOP per byte
     _capi.check(lib.etainv_prof_split(0, ridge, split, split_n))
-    traffic = None          # fabric-side bytes per igemm launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    tfile = ROOT / "profiles" / "r01e_pmc_traffic_rows128.json"   # (tools/unet_call.py --rows 128, tools/pmc_traffic.py)
-    if tfile.exists():
-        traffic = json.load(open(tfile))["igemm"]["hbm_bytes_per_launch"]
+    # fabric-side bytes per igemm launch: a PMC figure (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/unet_call.py
+    # --rows 128, FETCH_SIZE x2 per MI355X_MICROARCH.md, aggregated by tools/pmc_traffic.py), NOT measured by this run: the file is named
+    # in the JSON and belongs to the kernels of the round it was taken in
+    traffic, traffic_src = None, None
+    for cand in sorted((ROOT / "profiles").glob("r*_pmc_traffic_rows128.json"), reverse=True):
+        traffic, traffic_src = json.load(open(cand))["igemm"]["hbm_bytes_per_launch"], f"profiles/{cand.name} (one 128-row UNet call)"
+        break
     images = B * world * a.steps
     value = images / dt
     if rank == 0:
@@ -227,7 +230,7 @@ def main():
                        "tflop_per_image": FWD_PER_IMAGE * F_UNET_TFLOP, "sharding": f"batch-shard x{world}, final all_gather of latents"},
             "end_to_end_mfma_frac": value / world * FWD_PER_IMAGE * F_UNET_TFLOP / MFMA_PEAK_TFLOPS,
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv3x3 / conv1x1 / linear)", "achieved": achieved,
-                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": ig_n, "avg_launch_ms": ig_ms / max(ig_n, 1), "share_of_wall": ig_ms * 1e-3 / dt_prof,
                          "measured_on": "one extra step after the timed region, HIP events on the launch stream"},
             # the same igemm launches split by which roofline bounds them (algorithmic intensity of the launch vs the 312.5 FLOP/B ridge): the

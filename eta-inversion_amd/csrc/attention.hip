@@ -628,277 +628,6 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
   }
 }
 
-// ------------------------------------------------------------------------------------------------ self, head_dim 40, software-pipelined
-// Same arithmetic as self_attn40_kernel, other schedule.  In that kernel a wave alternates MFMA-only stretches (QK^T of both query blocks,
-// the last P V) with VALU-only ones (maximum, the first exponentials): alone on its SIMD it needs ~2400 cycles per 64-key tile for ~900
-// cycles of matrix work and ~1000 of vector issue, and two such waves per SIMD only reach 1.36x of one.  Here the tile loop is skewed by one
-// 32-key sub-tile so that every stretch pairs matrix work with independent vector work of the SAME wave:
-//     [A]  S(u+1) = K Q^T - m'  (6 MFMAs)            ||  P0 = exp2(S(u), query block 0)
-//     [B]  O0 += V^T P0         (4 MFMAs)            ||  P1 = exp2(S(u), query block 1)
-//     [C]  O1 += V^T P1         (4 MFMAs)            ||  maximum of S(u+1), rare move of m'
-// K / V are still staged 64 keys at a time (one barrier per 64 keys) into a ring of three LDS buffers: the scores of sub-tile 2T+2 are
-// computed during tile T, so tile T+1 has to be resident then, and the buffer being refilled must not be the one tile T-1's V reads used.
-constexpr size_t A40P_LDS = (size_t)(3 * A40_KBUF + 4 * A40_VBUF) * 2;
-
-template <typename T, bool XCD_REMAP>
-__global__ void __launch_bounds__(256, 2) self_attn40p_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads, float q_scale,
-                                                              int mode, int n_img, int nqb) {
-  typedef typename Frag<T>::v8 v8;
-  constexpr int D = 40, KV = A40_KV, QB = 2, KROW = A40_KROW, VROW = A40_VROW, KBUF = A40_KBUF, VBUF = A40_VBUF, NBUF = 3;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* sK = reinterpret_cast<T*>(smem);      // [3][KV][KROW]
-  T* sV = sK + NBUF * KBUF;                // [3][KV][VROW]
-  T* sZ = sV + NBUF * VBUF;                // [KV][VROW] zeros
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  int qblk, hd, b;
-  if (XCD_REMAP) {
-    const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
-    const int set = (slot / nqb) * 8 + xcd;
-    qblk = slot - (slot / nqb) * nqb;
-    hd = set % heads;
-    b = set / heads;
-  } else {
-    qblk = blockIdx.x;
-    hd = blockIdx.y;
-    b = blockIdx.z;
-  }
-  const int C = heads * D, C3 = 3 * C;
-  int bq = b, bk = b, bv = b;
-  if (mode != 0) {
-    int half, role, img;
-    row_roles(b, n_img, half, role, img);
-    if (mode == 1 && half == 1 && role == 1) { bq = b - n_img; bk = b - n_img; }
-    if (mode == 2 && role == 1) { bk = b - n_img; bv = b - n_img; }
-  }
-  const int q_base = qblk * 256 + wid * 64;
-
-  {   // one-time LDS constants: pad chunks (1, 0 x 7) of every K and V row of the three buffers, the all-zero V image
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    u32x4 one4 = zero4;
-    {
-      T one[2] = {(T)1.0f, (T)0.0f};
-      one4[0] = *reinterpret_cast<unsigned*>(one);
-    }
-    for (int idx = tid; idx < NBUF * KV; idx += 256) {
-      *reinterpret_cast<u32x4*>(sK + idx * KROW + D) = one4;
-      *reinterpret_cast<u32x4*>(sK + idx * KROW + D + 8) = zero4;
-      *reinterpret_cast<u32x4*>(sV + idx * VROW + D) = one4;
-    }
-    for (int idx = tid; idx < VBUF / 8; idx += 256) *reinterpret_cast<u32x4*>(sZ + idx * 8) = zero4;
-  }
-
-  v8 qf[QB][3];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    int query = q_base + qb * 32 + r;
-    query = query < N ? query : N - 1;
-    const T* qp = qkv + ((int64_t)bq * N + query) * C3 + hd * D;
-#pragma unroll
-    for (int st = 0; st < 3; ++st) {
-      const int d0 = st * 16 + h * 8;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (d0 < D) v = *reinterpret_cast<const u32x4*>(qp + d0);
-      v8 q = *reinterpret_cast<v8*>(&v);
-      if (q_scale != 1.0f) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) q[j] = (T)((float)q[j] * q_scale);
-      }
-      qf[qb][st] = q;
-    }
-  }
-
-  u32x4 rk[2], rv[2];
-  const T* kbase = qkv + (int64_t)bk * N * C3 + C + hd * D;
-  const T* vbase = qkv + (int64_t)bv * N * C3 + 2 * C + hd * D;
-  int st_row[2], st_ch[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = tid + 256 * i;
-    st_row[i] = c / 5;
-    st_ch[i] = c - st_row[i] * 5;
-  }
-  auto load_kv = [&](int kv0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      u32x4 a = {0u, 0u, 0u, 0u}, c = {0u, 0u, 0u, 0u};
-      if (tid + 256 * i < KV * 5 && kv0 + st_row[i] < N) {
-        const int64_t off = (int64_t)(kv0 + st_row[i]) * C3 + st_ch[i] * 8;
-        a = *reinterpret_cast<const u32x4*>(kbase + off);
-        c = *reinterpret_cast<const u32x4*>(vbase + off);
-      }
-      rk[i] = a;
-      rv[i] = c;
-    }
-  };
-  auto store_kv = [&](int bufi) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      if (tid + 256 * i < KV * 5) {
-        *reinterpret_cast<u32x4*>(sK + bufi * KBUF + st_row[i] * KROW + st_ch[i] * 8) = rk[i];
-        *reinterpret_cast<u32x4*>(sV + bufi * VBUF + st_row[i] * VROW + st_ch[i] * 8) = rv[i];
-      }
-  };
-
-  const int kA = r * KROW + h * 8;
-  const int gi = lane & 15, vg = (lane >> 4) & 1, vq = gi >> 2, vp = gi & 3;
-  const int vA = (4 * h + vq) * VROW + 16 * vg + 4 * vp;
-
-  float mref[QB];
-  f32x16 o[QB][2];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    mref[qb] = 0.f;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) o[qb][dt][i] = 0.f;
-  }
-
-  const int ntiles = (N + KV - 1) / KV;
-  const int nsub = (N + 31) / 32;                       // 32-key sub-tiles
-
-  // S(u)^T = K Q^T - m' of sub-tile u (keys 32u .. 32u+31): buffer (u >> 1) % 3, rows (u & 1) * 32
-  auto qk = [&](int u, f32x16 (&s)[QB]) __attribute__((always_inline)) {
-    const T* tK = sK + ((u >> 1) % NBUF) * KBUF + (u & 1) * 32 * KROW + kA;
-#pragma unroll
-    for (int st = 0; st < 3; ++st) {
-      const v8 kf = *reinterpret_cast<const v8*>(tK + st * 16);
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        if (st == 0) {
-          f32x16 z;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) z[i] = 0.f;
-          s[qb] = Frag32<T>::mfma(kf, qf[qb][st], z);
-        } else {
-          s[qb] = Frag32<T>::mfma(kf, qf[qb][st], s[qb]);
-        }
-      }
-    }
-    if (u * 32 + 32 > N) {   // the last sub-tile of a sequence that is not a multiple of 32 keys (wave-uniform)
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-          if (u * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= N) s[qb][i] = NEG_BIG;
-    }
-  };
-  // reference maximum (see self_attn40_kernel): moves when a query of the wave exceeds it by 2^THR, always on the first sub-tile
-  auto maxfix = [&](f32x16 (&s)[QB], bool first) __attribute__((always_inline)) {
-    float mx[QB];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      float m = fmaxf(fmaxf(s[qb][0], s[qb][1]), s[qb][2]);
-#pragma unroll
-      for (int e = 3; e + 1 < 16; e += 2) m = fmaxf(fmaxf(m, s[qb][e]), s[qb][e + 1]);
-      m = fmaxf(m, s[qb][15]);
-      float ma = m, mb = m;
-      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
-      mx[qb] = fmaxf(ma, mb);
-    }
-    if (first || __builtin_amdgcn_ballot_w64(fmaxf(mx[0], mx[1]) > A40_THR) != 0) {
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        const float d = first ? mx[qb] : fmaxf(mx[qb], 0.f);
-        const T mt = (T)(mref[qb] + d);
-        const float mnew = (float)mt, de = mnew - mref[qb];
-        mref[qb] = mnew;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[qb][i] -= de;
-        if (!first) {
-          const float f = __builtin_amdgcn_exp2f(-de);
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o[qb][dt][i] *= f;
-        }
-        if (h == 1) qf[qb][2][0] = (T)(-mnew);
-      }
-    }
-  };
-
-  // ---- prologue: tiles 0 and 1 resident, scores of sub-tile 0
-  load_kv(0);
-  store_kv(0);
-  if (ntiles > 1) {
-    load_kv(KV);
-    store_kv(1);
-  }
-  __syncthreads();
-  f32x16 sc[QB], sn[QB];
-  qk(0, sc);
-  maxfix(sc, true);
-
-  for (int tile = 0; tile < ntiles; ++tile) {
-    if (tile > 0) __syncthreads();                       // tile + 1 is visible to every wave; the buffer of tile - 1 is free
-    if (tile + 2 < ntiles) load_kv((tile + 2) * KV);
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int u = 2 * tile + half;
-      if (u < nsub) {
-        const bool has_next = u + 1 < nsub;
-        // V^T fragments of sub-tile u: 2 K steps of 16 keys x 2 dim tiles
-        const T* tV0 = sV + (tile % NBUF) * VBUF + half * 32 * VROW + vA;
-        const T* tV1 = vg ? (sZ + vA - 16) : (tV0 + 32);
-        v8 vf[2][2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            const T* vp_ = (dt ? tV1 : tV0) + ks * 16 * VROW;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp_));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp_ + 8 * VROW));
-            vf[ks][dt] = __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-          }
-        // [A] scores of the next sub-tile || exponentials of query block 0
-        if (has_next) qk(u + 1, sn);
-        v8 pf[QB][2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) pf[0][ks][e] = (T)__builtin_amdgcn_exp2f(sc[0][ks * 8 + e]);
-        // [B] O0 += V^T P0 || exponentials of query block 1
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) o[0][dt] = Frag32<T>::mfma(vf[ks][dt], pf[0][ks], o[0][dt]);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) pf[1][ks][e] = (T)__builtin_amdgcn_exp2f(sc[1][ks * 8 + e]);
-        // [C] O1 += V^T P1 || maximum of the next scores
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) o[1][dt] = Frag32<T>::mfma(vf[ks][dt], pf[1][ks], o[1][dt]);
-        if (has_next) {
-          maxfix(sn, false);
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb) sc[qb] = sn[qb];
-        }
-      }
-    }
-    if (tile + 2 < ntiles) store_kv((tile + 2) % NBUF);
-  }
-
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    const float l = __shfl(o[qb][1][4], r, 64);
-    const float inv = 1.f / l;
-    const int query = q_base + qb * 32 + r;
-    if (query >= N) continue;
-    T* op = out + ((int64_t)b * N + query) * C + hd * D + 4 * h;
-#pragma unroll
-    for (int g4 = 0; g4 < 5; ++g4) {
-      const int dt = g4 >> 2, i0 = (g4 & 3) * 4;
-      T v[4] = {(T)(o[qb][dt][i0] * inv), (T)(o[qb][dt][i0 + 1] * inv), (T)(o[qb][dt][i0 + 2] * inv), (T)(o[qb][dt][i0 + 3] * inv)};
-      *reinterpret_cast<u32x2*>(op + 8 * g4) = *reinterpret_cast<u32x2*>(v);
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ cross
 template <typename T, int D, int QT>
 __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ kv, T* __restrict__ out,
@@ -1152,18 +881,6 @@ int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int hea
   ETAINV_CHECK(!q_prescaled || d == 40, "pre-scaled queries: head_dim 40 only");
   ETAINV_CHECK(!q_prescaled || self_attn40_v2_enabled(), "pre-scaled queries need the d = 40 kernel");
   if (d == 40 && self_attn40_v2_enabled()) {
-    static const bool pipe = getenv("ETAINV_ATT_PIPE") ? atoi(getenv("ETAINV_ATT_PIPE")) != 0 : true;   // A/B: software-pipelined schedule
-    if (pipe) {
-      const int nqb = cdiv(n, 256);
-      const bool remap = ((b * heads) % 8) == 0;
-      const float q_scale = q_prescaled ? 1.0f : (1.0f / sqrtf(40.f)) * 1.4426950408889634f;
-      ProfScope prof(PROF_SELF_ATTN, 4.0 * (double)b * heads * (double)n * (double)n * 40, s);
-      ETAINV_DISPATCH_HALF(dtype, T,
-        if (remap) hipLaunchKernelGGL((self_attn40p_kernel<T, true>), dim3(nqb * heads * b), dim3(256), A40P_LDS, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb);
-        else hipLaunchKernelGGL((self_attn40p_kernel<T, false>), dim3(nqb, heads, b), dim3(256), A40P_LDS, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb));
-      ETAINV_LAUNCH_CHECK();
-      return 0;
-    }
     // A/B (ETAINV_ATT_QB): 2 = two 32-query blocks per wave, 2 waves per SIMD (default); 1 = one block, 4 waves per SIMD; 13 = one block, 3 waves
     static const int qb = getenv("ETAINV_ATT_QB") ? atoi(getenv("ETAINV_ATT_QB")) : 2;
     if (qb == 1) { ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 1, 4>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s))); }
