@@ -28,3 +28,17 @@ if [ "${STAMPS:-0}" = "1" ]; then
   hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libetainv_hip_stamps.so" "$HERE"/obj/{step_kernels,igemm_stamps,norm,attention,misc,maps,aux_nets,engine}.o
   echo "built $OUT/libetainv_hip_stamps.so"
 fi
+# A/B variant of one kernel file (same-box comparisons; boxes of the pool differ by several percent):
+#   VARIANT=name VARIANT_FILE=igemm VARIANT_FLAGS="-DETAINV_RES_PREFETCH=0" bash build.sh   ->  lib/libetainv_hip_name.so  (load with ETAINV_LIB)
+if [ -n "${VARIANT:-}" ]; then
+  vf="${VARIANT_FILE:-igemm}"
+  EXTRA=""
+  if [ "$vf" = "attention" ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans"; fi
+  hipcc $FLAGS $EXTRA ${VARIANT_FLAGS:-} -c "$HERE/$vf.hip" -o "$HERE/obj/${vf}_$VARIANT.o"
+  objs=""
+  for f in step_kernels igemm norm attention misc maps aux_nets engine; do
+    if [ "$f" = "$vf" ]; then objs="$objs $HERE/obj/${vf}_$VARIANT.o"; else objs="$objs $HERE/obj/$f.o"; fi
+  done
+  hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libetainv_hip_$VARIANT.so" $objs
+  echo "built $OUT/libetainv_hip_$VARIANT.so"
+fi

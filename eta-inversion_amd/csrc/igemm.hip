@@ -276,20 +276,42 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
           if (p.bias) bv[j] = *reinterpret_cast<const f32x4*>(tile_bias + wn * WN + j * 16 + fq * 4);
           if (p.rowvec && n < p.N) bv[j] += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)batch * p.rowvec_stride + n);
         }
-        // residual: one batch of loads per 16-row group (holding the whole tile's residual would need 40 more registers
-        // than the kernel has) -> 4 load/store alternations per tile instead of 20
+#ifndef ETAINV_RES_PREFETCH
+#define ETAINV_RES_PREFETCH 1
+#endif
+#if ETAINV_RES_PREFETCH
+        // residual: ALL of the tile's residual loads go out before the first store (MT * NT 8-byte loads per lane; the fragment registers
+        // of the finished K step are dead here).  Issued per 16-row group right before that group's stores, every group exposed a full
+        // memory latency with nothing else in flight: in-kernel stamps put the epilogue of a 320 -> 320 + residual GEMM at 22.6k cycles
+        // per tile for 80 KB in + 80 KB out, twice its main loop.
+        u32x2 rv[MT][NT];
+        if (res) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const int m = mw + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              const int n = n0 + wn * WN + j * 16 + fq * 4;
+              rv[i][j] = (u32x2){0u, 0u};
+              if (m < p.M && n < p.N) rv[i][j] = *reinterpret_cast<const u32x2*>(res + (int64_t)m * p.N + n);
+            }
+          }
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           const int m = mw + i * 16 + fr;
-          u32x2 rv[NT];
+#if !ETAINV_RES_PREFETCH
+          u32x2 rvi[NT];
           if (res) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
               const int n = n0 + wn * WN + j * 16 + fq * 4;
-              rv[j] = (u32x2){0u, 0u};
-              if (m < p.M && n < p.N) rv[j] = *reinterpret_cast<const u32x2*>(res + (int64_t)m * p.N + n);
+              rvi[j] = (u32x2){0u, 0u};
+              if (m < p.M && n < p.N) rvi[j] = *reinterpret_cast<const u32x2*>(res + (int64_t)m * p.N + n);
             }
           }
+#endif
           u32x2 po[NT];
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
@@ -297,7 +319,11 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
             acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (res) {
               T r[4];
-              *reinterpret_cast<u32x2*>(r) = rv[j];
+#if ETAINV_RES_PREFETCH
+              *reinterpret_cast<u32x2*>(r) = rv[i][j];
+#else
+              *reinterpret_cast<u32x2*>(r) = rvi[j];
+#endif
               v[0] += to_f32(r[0]); v[1] += to_f32(r[1]); v[2] += to_f32(r[2]); v[3] += to_f32(r[3]);
             }
             T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
