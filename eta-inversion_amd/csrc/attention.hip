@@ -629,9 +629,12 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ cross
-template <typename T, int D, int QT>
+// EDIT = false: no source-key tile and no source-probability scratch in LDS (a third of the footprint: 6 instead of 2 resident blocks per
+// CU for a kernel that waits on one dependent Q load per 16-query tile).  Only the cond-target rows of a prompt-to-prompt call need
+// EDIT = true; the launcher splits such a call into two launches over contiguous row ranges (row0 = first batch row of the launch).
+template <typename T, int D, int QT, bool EDIT>
 __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ kv, T* __restrict__ out,
-                                                         CrossParams p) {
+                                                         CrossParams p, int row0) {
   typedef typename Frag<T>::v8 v8;
   typedef typename Frag<T>::v4 v4;
   constexpr int DP = (D + 31) / 32 * 32;
@@ -646,13 +649,13 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* sK = reinterpret_cast<T*>(smem);            // [KC][KSTR]  keys of this row
-  T* sKs = sK + KC * KSTR;                       // [KC][KSTR]  keys of the source row (edit only)
-  T* sVt = sKs + KC * KSTR;                      // [DT*16][VSTR]
-  float* sP = reinterpret_cast<float*>(sVt + DT * 16 * VSTR);  // [4 waves][QT][16][PSTR] source probabilities
+  T* sKs = sK + KC * KSTR;                       // [KC][KSTR]  keys of the source row (EDIT only)
+  T* sVt = EDIT ? sKs + KC * KSTR : sKs;         // [DT*16][VSTR]
+  float* sP = reinterpret_cast<float*>(sVt + DT * 16 * VSTR);  // [4 waves][QT][16][PSTR] source probabilities (EDIT only)
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, q4 = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int b = row0 + blockIdx.z, h = blockIdx.y;
   const int N = p.N, C = p.heads * D, C2 = 2 * C;
 
   int img = 0, role = -1, is_cond = 0;
@@ -665,7 +668,7 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
     is_cond = (p.rows == p.n_img) ? 1 : (b / p.n_img);
     role = 0;
   }
-  const bool do_edit = p.edit && p.layout == 2 && is_cond && role == 1;
+  const bool do_edit = EDIT && p.edit && p.layout == 2 && is_cond && role == 1;
   const bool do_store = p.map_layer >= 0 && is_cond;
   const int bs = b - p.n_img;  // source cond row of a target cond row
 
@@ -678,7 +681,7 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
       if (do_edit) s = *reinterpret_cast<const u32x4*>(kv + ((int64_t)bs * p.n_ctx + key) * C2 + h * D + ch * 8);
     }
     *reinterpret_cast<u32x4*>(sK + key * KSTR + ch * 8) = a;
-    *reinterpret_cast<u32x4*>(sKs + key * KSTR + ch * 8) = s;
+    if (EDIT) *reinterpret_cast<u32x4*>(sKs + key * KSTR + ch * 8) = s;
   }
   for (int idx = tid; idx < KC * NCH; idx += 256) {
     const int key = idx % KC, ch = idx / KC;
@@ -900,17 +903,29 @@ template <typename T, int D>
 static int launch_cross_t(const void* q, const void* kv, void* out, int b, const CrossParams& p, hipStream_t s) {
   constexpr int QT = 2;
   constexpr int DP = (D + 31) / 32 * 32, DT = (D + 15) / 16;
-  const size_t lds = (size_t)(2 * 96 * (DP + 8) + DT * 16 * (96 + 8)) * sizeof(T) + (size_t)4 * QT * 16 * 81 * sizeof(float);
+  const size_t lds_edit = (size_t)(2 * 96 * (DP + 8) + DT * 16 * (96 + 8)) * sizeof(T) + (size_t)4 * QT * 16 * 81 * sizeof(float);
+  const size_t lds_plain = (size_t)(96 * (DP + 8) + DT * 16 * (96 + 8)) * sizeof(T);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn_kernel<T, D, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn_kernel<T, D, QT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_edit);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn_kernel<T, D, QT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_plain);
     attr = true;
   }
   ProfScope prof(PROF_CROSS_ATTN, 4.0 * (double)b * p.heads * (double)p.N * (double)p.n_ctx * D, s);
   const int nqb = cdiv(p.N, 64 * QT);
-  const int gx = std::max(1, std::min(nqb, cdiv(2048, b * p.heads)));   // ~2048+ blocks in flight, K/V staging amortised
-  hipLaunchKernelGGL((cross_attn_kernel<T, D, QT>), dim3(gx, p.heads, b), dim3(256), lds, s, (const T*)q,
-                     (const T*)kv, (T*)out, p);
+  auto launch = [&](bool edit, int row0, int rows) {
+    const int gx = std::max(1, std::min(nqb, cdiv(2048, rows * p.heads)));   // ~2048+ blocks in flight, K/V staging amortised
+    if (edit)
+      hipLaunchKernelGGL((cross_attn_kernel<T, D, QT, true>), dim3(gx, p.heads, rows), dim3(256), lds_edit, s, (const T*)q, (const T*)kv, (T*)out, p, row0);
+    else
+      hipLaunchKernelGGL((cross_attn_kernel<T, D, QT, false>), dim3(gx, p.heads, rows), dim3(256), lds_plain, s, (const T*)q, (const T*)kv, (T*)out, p, row0);
+  };
+  if (p.edit && p.layout == 2) {          // rows [u_s, u_t, c_s, c_t] x n_img: only the last quarter (cond target) is edited
+    launch(false, 0, 3 * p.n_img);
+    launch(true, 3 * p.n_img, b - 3 * p.n_img);
+  } else {
+    launch(false, 0, b);
+  }
   ETAINV_LAUNCH_CHECK();
   return 0;
 }

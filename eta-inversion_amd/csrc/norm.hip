@@ -11,6 +11,11 @@
 namespace etainv {
 
 constexpr int GN_MAX_VEC_PER_LANE = 5;  // C <= 2560 -> 320 vectors of 8 channels -> 5 per lane
+// pixels in flight per wave in the streaming loops (independent 16-byte loads; C = 320 only fills 40 of a wave's 64 lanes, so one pixel
+// per iteration leaves the memory system with too few requests in flight)
+#ifndef GN_UNROLL
+#define GN_UNROLL 4
+#endif
 
 template <typename T> struct Vec8;
 template <> struct Vec8<f16> { typedef f16x8 type; };
@@ -32,7 +37,10 @@ __device__ __forceinline__ void store8(T* p, const float (&v)[8]) {
 
 // grid (chunks, B); 256 threads = 4 waves; wave w takes pixels beg+w, beg+w+4, ...; lane l owns channel
 // vectors l, l+64, ... so per-channel sums stay in registers across pixels.
-template <typename T>
+// VPL = channel vectors per lane = ceil(C / 8 / 64): a template parameter, because the per-lane sums / scales live in registers (16 per
+// vector): sized for C = 2560 (VPL 5, 140 VGPRs, 3 waves per SIMD) the C = 320 / 640 launches -- most of the GroupNorm time -- ran with a
+// third of the waves, i.e. a third of the memory requests in flight, that their own register need allows
+template <typename T, int VPL>
 __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x1, const T* __restrict__ x2, int c1, int c2, int hw,
                                                        int groups, float* __restrict__ partial) {
   const int C = c1 + c2, nvec = C >> 3, nv1 = c1 >> 3, cpg = C / groups;
@@ -40,15 +48,16 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x1,
   const int per = (hw + chunks - 1) / chunks;
   const int beg = blockIdx.x * per, end = min(hw, beg + per);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  float s[GN_MAX_VEC_PER_LANE][8], q[GN_MAX_VEC_PER_LANE][8];
+  float s[VPL][8], q[VPL][8];
 #pragma unroll
-  for (int i = 0; i < GN_MAX_VEC_PER_LANE; ++i)
+  for (int i = 0; i < VPL; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[i][j] = q[i][j] = 0.f;
+#pragma unroll(VPL <= 2 ? GN_UNROLL : 1)
   for (int pix = beg + wid; pix < end; pix += 4) {
     const int64_t row = (int64_t)b * hw + pix;
 #pragma unroll
-    for (int i = 0; i < GN_MAX_VEC_PER_LANE; ++i) {
+    for (int i = 0; i < VPL; ++i) {
       const int v = lane + 64 * i;
       if (v < nvec) {
         float t[8];
@@ -61,7 +70,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x1,
   }
   extern __shared__ float sm[];  // [4][C][2]
 #pragma unroll
-  for (int i = 0; i < GN_MAX_VEC_PER_LANE; ++i) {
+  for (int i = 0; i < VPL; ++i) {
     const int v = lane + 64 * i;
     if (v < nvec) {
 #pragma unroll
@@ -89,7 +98,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x1,
 // grid (chunks, B), 4 waves; same pixel / vector ownership as gn_stats_kernel, so the per-channel scale and shift
 // (rstd*gamma, beta - mean*rstd*gamma) are computed once per lane and reused for every pixel: no integer
 // division and 2 FMAs per element in the streaming loop.
-template <typename T>
+template <typename T, int VPL>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x1, const T* __restrict__ x2, int c1, int c2, int hw,
                                                        int groups, const float* __restrict__ partial, int chunks_st, float count,
                                                        float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -126,9 +135,9 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x1,
     }
     __syncthreads();
   }
-  float sc[GN_MAX_VEC_PER_LANE][8], sh[GN_MAX_VEC_PER_LANE][8];
+  float sc[VPL][8], sh[VPL][8];
 #pragma unroll
-  for (int i = 0; i < GN_MAX_VEC_PER_LANE; ++i) {
+  for (int i = 0; i < VPL; ++i) {
     const int v = lane + 64 * i;
     if (v < nvec) {
       int g = (v * 8) / cpg, rem = v * 8 - g * cpg;
@@ -142,10 +151,11 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x1,
       }
     }
   }
+#pragma unroll(VPL <= 2 ? GN_UNROLL : 1)
   for (int pix = beg + wid; pix < end; pix += 4) {
     const int64_t row = (int64_t)b * hw + pix;
 #pragma unroll
-    for (int i = 0; i < GN_MAX_VEC_PER_LANE; ++i) {
+    for (int i = 0; i < VPL; ++i) {
       const int v = lane + 64 * i;
       if (v < nvec) {
         float t[8];
@@ -218,16 +228,27 @@ int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float
   // the apply pass has no cross-block reduction: use more, smaller chunks to fill the chip
   const int chunks_apply = std::max(1, std::min(hw / 4, std::max(chunks, 4096 / std::max(1, b))));
   ProfScope prof(PROF_GROUPNORM, 2.0 * 2.0 * (double)b * hw * C, s);  // algorithmic bytes: read + write once, 2-byte elements
-  ETAINV_DISPATCH_HALF(
-      dtype, T,
-      static bool attr = false;
-      if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_stats_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2560 * 2 * 4);
-        attr = true;
-      }
-      hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks, b), dim3(256), lds, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups, partial);
-      hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(chunks_apply, b), dim3(256), 0, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups, partial,
-                         chunks, (float)hw * (float)(C / groups), eps, gamma, beta, silu, (T*)out));
+  const int vpl = ((C >> 3) + 63) / 64;
+#define ETAINV_GN_LAUNCH(VPL_)                                                                                                             \
+  {                                                                                                                                        \
+    static bool attr_ = false;                                                                                                             \
+    if (!attr_) {                                                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_stats_kernel<T, VPL_>), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                4 * 64 * VPL_ * 8 * 2 * 4);                                                                                 \
+      attr_ = true;                                                                                                                        \
+    }                                                                                                                                      \
+    hipLaunchKernelGGL((gn_stats_kernel<T, VPL_>), dim3(chunks, b), dim3(256), lds, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups, partial); \
+    hipLaunchKernelGGL((gn_apply_kernel<T, VPL_>), dim3(chunks_apply, b), dim3(256), 0, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups,     \
+                       partial, chunks, (float)hw * (float)(C / groups), eps, gamma, beta, silu, (T*)out);                                  \
+  }
+  ETAINV_DISPATCH_HALF(dtype, T, switch (vpl) {
+    case 1: ETAINV_GN_LAUNCH(1) break;
+    case 2: ETAINV_GN_LAUNCH(2) break;
+    case 3: ETAINV_GN_LAUNCH(3) break;
+    case 4: ETAINV_GN_LAUNCH(4) break;
+    default: ETAINV_GN_LAUNCH(5) break;
+  });
+#undef ETAINV_GN_LAUNCH
   ETAINV_LAUNCH_CHECK();
   return 0;
 }

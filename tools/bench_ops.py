@@ -89,7 +89,27 @@ def main():
         ms = timeit(fn)
         fl = 4.0 * Rn * 8 * n * n * d
         print(f"{name:28s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s   x{cnt}")
-    for c, hw in ((320, 4096), (960, 4096), (1280, 256)):
+    import ctypes as C
+    for n, d in ((4096, 40), (1024, 80), (256, 160)):
+        for tag in ("plain", "ptp-edit"):
+            name = f"cross-attn N={n} d={d} {tag}"
+            if a.only and a.only not in name:
+                continue
+            n_img = R // 4
+            q = rnd(R, n, 8 * d)
+            kv = rnd(R, 77, 16 * d)
+            out = torch.empty(R, n, 8 * d, dtype=dt, device="cuda")
+            ctrl = None
+            if tag == "ptp-edit":
+                mapper = torch.arange(77, dtype=torch.int32, device="cuda").repeat(n_img, 1).contiguous()
+                ones = torch.ones(n_img, 77, device="cuda")
+                ctrl = _capi.AttnCtrl(mode=_capi.ATTN_PTP, n_img=n_img, store_maps=0, mapper=_capi.ptr(mapper), alphas=_capi.ptr(ones),
+                                      equalizer=_capi.ptr(ones), cross_alpha=_capi.ptr(ones))
+            fn = lambda: _capi.check(lib.etainv_op_cross_attention(_capi.ptr(q), _capi.ptr(kv), _capi.ptr(out), R, n, 8, d, 77,
+                                                                   C.byref(ctrl) if ctrl is not None else None, -1, n_img, None, code, st))
+            ms = timeit(fn)
+            print(f"{name:34s} {ms:8.3f} ms  {4.0 * R * 8 * n * 77 * d / ms / 1e9:8.1f} TFLOP/s")
+    for c, hw in ((320, 4096), (640, 1024), (640, 4096), (960, 4096), (1280, 256), (1280, 64), (2560, 256)):
         name = f"groupnorm C={c} hw={hw}"
         if a.only and a.only not in name:
             continue
