@@ -338,7 +338,10 @@ def test_conv3x3(capi, dtype, cfg):
 # ----------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("b,hw,c1,c2,silu", [(2, 1024, 320, 0, 1), (3, 256, 1280, 640, 1), (1, 4096, 640, 320, 1), (2, 64, 1280, 1280, 1),
-                                             (2, 256, 640, 0, 0), (1, 144, 320, 0, 1)])
+                                             (2, 256, 640, 0, 0), (1, 144, 320, 0, 1),
+                                             # one-pass kernel (chunks of an image held in registers, partial sums handed over inside the launch):
+                                             # several images per block group, dual source, ragged last chunk, groups that straddle a vector
+                                             (9, 4096, 320, 0, 1), (40, 1024, 320, 0, 0), (5, 1024, 320, 320, 1), (3, 200, 256, 64, 1), (12, 256, 640, 0, 1)])
 def test_groupnorm(capi, dtype, b, hw, c1, c2, silu):
     lib = capi.load()
     C_ = c1 + c2
