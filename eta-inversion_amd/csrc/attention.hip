@@ -360,18 +360,31 @@ template <> struct Frag32<bf16> {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int A40_KV = 64;                 // keys per tile
-constexpr int A40_KROW = 56;               // K row: 40 dims + pad chunk (1, 0 x 7) + 8 unused = 112 B (7 chunks: conflict-free ds_read_b128)
-constexpr int A40_VROW = 48;               // V row: 40 dims + pad chunk (1, 0 x 7) = 96 B
-constexpr int A40_KBUF = A40_KV * A40_KROW, A40_VBUF = A40_KV * A40_VROW;
-constexpr size_t A40_LDS = (size_t)(2 * A40_KBUF + 3 * A40_VBUF) * 2;   // 2 K + 2 V buffers + one all-zero V image (rows 48..63 of V^T)
+// geometry for head_dim D (40: the L^2-token levels; 80: the (L/2)^2 level).  Every K / V row carries a pad chunk (1, 0 x 7) at dim D.
+template <int D> struct A32 {
+  static constexpr int KV = 64;                              // keys per tile
+  static constexpr int KS = (D + 8 + 15) / 16;               // K = 16 steps of S^T = K Q^T, pad chunk included (40 -> 3, 80 -> 6)
+  static constexpr int KROW = (2 * KS + 1) * 8;              // K row in elements: an ODD number of 16-byte chunks (7 / 13): conflict-free ds_read_b128
+  static constexpr int VROW = (D + 8 + 15) / 16 * 16;        // V row: D dims + pad chunk, rounded to 16 (48 / 96)
+  static constexpr int DT = (D + 1 + 31) / 32;               // 32-row tiles of O^T incl. the denominator row D (2 / 3)
+  static constexpr bool ZBUF = DT * 32 > VROW;               // V^T rows past VROW are read from an all-zero image (D = 40: rows 48 .. 63)
+  static constexpr int KBUF = KV * KROW, VBUF = KV * VROW;
+  static constexpr size_t LDS = (size_t)(2 * KBUF + (ZBUF ? 3 : 2) * VBUF) * 2;
+  static constexpr int NCH = D / 8;                          // data chunks per row
+  static constexpr int NLD = (KV * NCH + 255) / 256;         // staging chunks per thread and tensor
+  static constexpr int MS = D / 16, MH = (D % 16) / 8;       // K step and lane half that hold the pad dimension D (where -m' enters)
+  static constexpr int LT = D / 32, LR = D % 32;             // O^T tile and row of the denominator
+  static constexpr int LI = (LR & 3) + 4 * (LR >> 3), LH = (LR >> 2) & 1;   // its accumulator register and lane half
+};
 constexpr float A40_THR = 8.0f;
 
-template <typename T, bool XCD_REMAP, int QB, int OCC>
+template <typename T, int D, bool XCD_REMAP, int QB, int OCC>
 __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads,
                                                                float q_scale, int mode, int n_img, int nqb, int stagger) {
   typedef typename Frag<T>::v8 v8;
-  constexpr int D = 40, KV = A40_KV, KROW = A40_KROW, VROW = A40_VROW, KBUF = A40_KBUF, VBUF = A40_VBUF;
+  typedef A32<D> GEO;
+  constexpr int KV = GEO::KV, KS = GEO::KS, KROW = GEO::KROW, VROW = GEO::VROW, KBUF = GEO::KBUF, VBUF = GEO::VBUF, DT = GEO::DT, NCH = GEO::NCH,
+                NLD = GEO::NLD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* sK = reinterpret_cast<T*>(smem);      // [2][KV][KROW]
   T* sV = sK + 2 * KBUF;                   // [2][KV][VROW]
@@ -418,22 +431,26 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
     }
     for (int idx = tid; idx < 2 * KV; idx += 256) {
       *reinterpret_cast<u32x4*>(sK + idx * KROW + D) = one4;
-      *reinterpret_cast<u32x4*>(sK + idx * KROW + D + 8) = zero4;
+#pragma unroll
+      for (int c = D + 8; c < KROW; c += 8) *reinterpret_cast<u32x4*>(sK + idx * KROW + c) = zero4;
       *reinterpret_cast<u32x4*>(sV + idx * VROW + D) = one4;
+#pragma unroll
+      for (int c = D + 8; c < VROW; c += 8) *reinterpret_cast<u32x4*>(sV + idx * VROW + c) = zero4;
     }
-    for (int idx = tid; idx < VBUF / 8; idx += 256) *reinterpret_cast<u32x4*>(sZ + idx * 8) = zero4;
+    if (GEO::ZBUF)
+      for (int idx = tid; idx < VBUF / 8; idx += 256) *reinterpret_cast<u32x4*>(sZ + idx * 8) = zero4;
   }
 
   // ---- Q fragments (B operand of S^T): lane (query r, half h) holds dims 16 s + 8 h .. + 7 of K step s; dims 40 .. 47 (step 2, h = 1)
   // are the pad dimensions: element 0 carries -m' (set below), the rest 0
-  v8 qf[QB][3];
+  v8 qf[QB][KS];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     int query = q_base + qb * 32 + r;
     query = query < N ? query : N - 1;
     const T* qp = qkv + ((int64_t)bq * N + query) * C3 + hd * D;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < KS; ++s) {
       const int d0 = s * 16 + h * 8;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (d0 < D) v = *reinterpret_cast<const u32x4*>(qp + d0);
@@ -447,21 +464,21 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
   }
 
   // ---- K / V staging through registers: 320 16-byte chunks each per tile (64 keys x 5 chunks), 2 per thread (threads >= 64 take one)
-  u32x4 rk[2], rv[2];
+  u32x4 rk[NLD], rv[NLD];
   const T* kbase = qkv + (int64_t)bk * N * C3 + C + hd * D;
   const T* vbase = qkv + (int64_t)bv * N * C3 + 2 * C + hd * D;
-  int st_row[2], st_ch[2];
+  int st_row[NLD], st_ch[NLD];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     const int c = tid + 256 * i;
-    st_row[i] = c / 5;
-    st_ch[i] = c - st_row[i] * 5;
+    st_row[i] = c / NCH;
+    st_ch[i] = c - st_row[i] * NCH;
   }
   auto load_kv = [&](int kv0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NLD; ++i) {
       u32x4 a = {0u, 0u, 0u, 0u}, c = {0u, 0u, 0u, 0u};
-      if (tid + 256 * i < KV * 5 && kv0 + st_row[i] < N) {          // keys past N: zeros (finite), masked in the scores
+      if (tid + 256 * i < KV * NCH && kv0 + st_row[i] < N) {        // keys past N: zeros (finite), masked in the scores
         const int64_t off = (int64_t)(kv0 + st_row[i]) * C3 + st_ch[i] * 8;
         a = *reinterpret_cast<const u32x4*>(kbase + off);
         c = *reinterpret_cast<const u32x4*>(vbase + off);
@@ -472,8 +489,8 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
   };
   auto store_kv = [&](int bufi) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      if (tid + 256 * i < KV * 5) {
+    for (int i = 0; i < NLD; ++i)
+      if (tid + 256 * i < KV * NCH) {
         *reinterpret_cast<u32x4*>(sK + bufi * KBUF + st_row[i] * KROW + st_ch[i] * 8) = rk[i];
         *reinterpret_cast<u32x4*>(sV + bufi * VBUF + st_row[i] * VROW + st_ch[i] * 8) = rv[i];
       }
@@ -486,12 +503,12 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
                                                                       // addresses row (key) q, columns (dims) 4p .. 4p+3 of a 4 x 16 block
 
   float mref[QB];
-  f32x16 o[QB][2];
+  f32x16 o[QB][DT];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     mref[qb] = 0.f;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[qb][dt][i] = 0.f;
   }
@@ -507,15 +524,21 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
     const int kv0 = j * KV, cur = j & 1;
     if (j + 1 < ntiles) load_kv(kv0 + KV);
     const T* tK = sK + cur * KBUF + kA;
-    const T* tV0 = sV + cur * VBUF + vA;                              // dims 0 .. 31
-    const T* tV1 = vg ? (sZ + vA - 16) : (sV + cur * VBUF + vA + 32);   // dims 32 .. 47 (incl. the ones column); rows 48 .. 63 of V^T are zero
+    // V^T row tiles of 32 dims: lanes with vg = 1 read dims 32 dt + 16 .. + 31, which lie past the row for the last tile of D = 40
+    // (rows 48 .. 63 of V^T are zero: read from the zero image)
+    const T* tV[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      tV[dt] = sV + cur * VBUF + vA + dt * 32;
+      if (dt * 32 + 16 >= VROW && vg) tV[dt] = sZ + vA - 16;
+    }
 
     // ---- S'^T = K Q^T - m' : s[qb][kb] register i = key kb*32 + (i&3) + 8(i>>2) + 4h, query r
     f32x16 s[QB][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int st = 0; st < 3; ++st) {
+      for (int st = 0; st < KS; ++st) {
         const v8 kf = *reinterpret_cast<const v8*>(tK + kb * 32 * KROW + st * 16);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
@@ -570,22 +593,22 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
         if (!first) {
           const float f = __builtin_amdgcn_exp2f(-de);
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt)
+          for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[qb][dt][i] *= f;
         }
-        if (h == 1) qf[qb][2][0] = (T)(-mnew);
+        if (h == GEO::MH) qf[qb][GEO::MS][0] = (T)(-mnew);
       }
     }
 
     // ---- V^T fragments of the tile (shared by the query blocks), requested BEFORE the exponentials: 16 transposed reads whose LDS latency
     // is then covered by ~300 cycles of v_exp instead of standing in front of every MFMA
-    v8 vf[4][2];
+    v8 vf[4][DT];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const T* vp_ = (dt ? tV1 : tV0) + ks * 16 * VROW;
+      for (int dt = 0; dt < DT; ++dt) {
+        const T* vp_ = tV[dt] + ks * 16 * VROW;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp_));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp_ + 8 * VROW));
         vf[ks][dt] = __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -602,7 +625,7 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) o[qb][dt] = Frag32<T>::mfma(vf[ks][dt], pf[qb][ks], o[qb][dt]);
+        for (int dt = 0; dt < DT; ++dt) o[qb][dt] = Frag32<T>::mfma(vf[ks][dt], pf[qb][ks], o[qb][dt]);
     }
 
     if (j + 1 < ntiles) store_kv(cur ^ 1);   // buffer cur^1 was last read in iteration j-1, a barrier ago
@@ -614,13 +637,13 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
   // ---- normalise and store: lane (query r, half h) holds dims (i&3) + 8(i>>2) + 4h (+32); the denominator is row 40 = tile 1, register 4, h = 0
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    const float l = __shfl(o[qb][1][4], r, 64);
+    const float l = __shfl(o[qb][GEO::LT][GEO::LI], r + 32 * GEO::LH, 64);
     const float inv = 1.f / l;
     const int query = q_base + qb * 32 + r;
     if (query >= N) continue;
     T* op = out + ((int64_t)b * N + query) * C + hd * D + 4 * h;
 #pragma unroll
-    for (int g4 = 0; g4 < 5; ++g4) {
+    for (int g4 = 0; g4 < D / 8; ++g4) {
       const int dt = g4 >> 2, i0 = (g4 & 3) * 4;
       T v[4] = {(T)(o[qb][dt][i0] * inv), (T)(o[qb][dt][i0 + 1] * inv), (T)(o[qb][dt][i0 + 2] * inv), (T)(o[qb][dt][i0 + 3] * inv)};
       *reinterpret_cast<u32x2*>(op + 8 * g4) = *reinterpret_cast<u32x2*>(v);
@@ -856,23 +879,24 @@ bool self_attn40_v2_enabled() {
   return on;
 }
 
-template <typename T, int QB, int OCC>
+template <typename T, int D, int QB, int OCC>
 static int launch_self40(const void* qkv, void* out, int b, int n, int heads, int mode, int n_img, int q_prescaled, hipStream_t s) {
   const int nqb = cdiv(n, 128 * QB);
   const bool remap = ((b * heads) % 8) == 0;
-  const float q_scale = q_prescaled ? 1.0f : (1.0f / sqrtf(40.f)) * 1.4426950408889634f;
-  ProfScope prof(PROF_SELF_ATTN, 4.0 * (double)b * heads * (double)n * (double)n * 40, s);
+  const float q_scale = q_prescaled ? 1.0f : (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+  constexpr size_t A40_LDS = A32<D>::LDS;
+  ProfScope prof(PROF_SELF_ATTN, 4.0 * (double)b * heads * (double)n * (double)n * D, s);
   static const int stagger = getenv("ETAINV_A40_STAGGER") ? atoi(getenv("ETAINV_A40_STAGGER")) : 0;
   static const size_t lds_pad = getenv("ETAINV_A40_LDSPAD") ? (size_t)atoi(getenv("ETAINV_A40_LDSPAD")) : 0;   // experiment: fewer resident blocks
   const size_t lds = A40_LDS + lds_pad;
   if (lds_pad) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn40_kernel<T, true, QB, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn40_kernel<T, false, QB, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn40_kernel<T, D, true, QB, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn40_kernel<T, D, false, QB, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   if (remap)
-    hipLaunchKernelGGL((self_attn40_kernel<T, true, QB, OCC>), dim3(nqb * heads * b), dim3(256), lds, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb, stagger);
+    hipLaunchKernelGGL((self_attn40_kernel<T, D, true, QB, OCC>), dim3(nqb * heads * b), dim3(256), lds, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb, stagger);
   else
-    hipLaunchKernelGGL((self_attn40_kernel<T, false, QB, OCC>), dim3(nqb, heads, b), dim3(256), lds, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb, stagger);
+    hipLaunchKernelGGL((self_attn40_kernel<T, D, false, QB, OCC>), dim3(nqb, heads, b), dim3(256), lds, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb, stagger);
   ETAINV_LAUNCH_CHECK();
   return 0;
 }
@@ -881,15 +905,17 @@ int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int hea
                                hipStream_t s, int q_prescaled) {
   ETAINV_CHECK(qkv && out && b > 0 && n > 0, "bad arguments");
   ETAINV_CHECK(mode == 0 || (n_img > 0 && b == 4 * n_img), "ptp / masactrl modes need the 4*n_img backward layout");
-  ETAINV_CHECK(!q_prescaled || d == 40, "pre-scaled queries: head_dim 40 only");
+  ETAINV_CHECK(!q_prescaled || d == 40 || d == 80, "pre-scaled queries: head_dim 40 / 80 only");
   ETAINV_CHECK(!q_prescaled || self_attn40_v2_enabled(), "pre-scaled queries need the d = 40 kernel");
   if (d == 40 && self_attn40_v2_enabled()) {
-    // A/B (ETAINV_ATT_QB): 2 = two 32-query blocks per wave, 2 waves per SIMD (default); 1 = one block, 4 waves per SIMD; 13 = one block, 3 waves
-    static const int qb = getenv("ETAINV_ATT_QB") ? atoi(getenv("ETAINV_ATT_QB")) : 2;
-    if (qb == 1) { ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 1, 4>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s))); }
-    if (qb == 13) { ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 1, 3>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s))); }
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 2, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s)));
+    // two 32-query blocks per wave, 2 waves per SIMD (measured: one block per wave with 3 or 4 waves per SIMD is 10-13 % slower)
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 40, 2, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s)));
   }
+  static const bool v2_80 = getenv("ETAINV_ATT80_OLD") == nullptr;   // A/B: head_dim 80 on the 32x32x16 kernel (one 32-query block per wave)
+  if (d == 80 && self_attn40_v2_enabled() && v2_80) {
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 80, 1, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s)));
+  }
+  ETAINV_CHECK(!q_prescaled, "pre-scaled queries need the 32x32x16 kernel");
   ETAINV_DISPATCH_HALF(dtype, T, switch (d) {
     case 40: return launch_self_t<T, 40>(qkv, out, b, n, heads, mode, n_img, s);
     case 80: return launch_self_t<T, 80>(qkv, out, b, n, heads, mode, n_img, s);

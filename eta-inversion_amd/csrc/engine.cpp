@@ -222,9 +222,11 @@ struct Builder {
     t.qkv.k = c;
     want(&t.qkv.w, (size_t)3 * c * c * 2);
     add_slot(tp + ".attn1.to_q.weight", {c, c}, &t.qkv.w, 0, PK_PLAIN, 1, e->dt);
-    // head_dim 40 (the L^2-token level): softmax scale * log2(e) folded into to_q, so that the self-attention kernel's score accumulator is
-    // directly the exponent argument of exp2 (attention.hip, self_attn40_kernel) -- one rounding of W_q * c instead of W_q, none added
-    if (c / etainv_engine::kHeads == 40 && self_attn40_v2_enabled()) e->slots.back().scale = (1.0f / std::sqrt(40.0f)) * 1.4426950408889634f;
+    // head_dim 40 / 80 (the L^2- and (L/2)^2-token levels): softmax scale * log2(e) folded into to_q, so that the self-attention kernel's
+    // score accumulator is directly the exponent argument of exp2 (attention.hip, self_attn40_kernel) -- one rounding of W_q * c instead of
+    // W_q, none added
+    if (c / etainv_engine::kHeads <= 80 && self_attn40_v2_enabled())
+      e->slots.back().scale = (1.0f / std::sqrt((float)(c / etainv_engine::kHeads))) * 1.4426950408889634f;
     add_slot(tp + ".attn1.to_k.weight", {c, c}, &t.qkv.w, (size_t)c * c * 2, PK_PLAIN, 1, e->dt);
     add_slot(tp + ".attn1.to_v.weight", {c, c}, &t.qkv.w, (size_t)2 * c * c * 2, PK_PLAIN, 1, e->dt);
     linear(tp + ".attn1.to_out.0", t.out1, c, c, true);
@@ -425,7 +427,7 @@ struct Fwd {
       if (ctrl->mode == ETAINV_ATTN_PTP && ctrl->self_replace_active && hw <= ctrl->self_max_tokens) mode = 1;
       if (ctrl->mode == ETAINV_ATTN_MASA && ctrl->masa_active && blk >= ctrl->masa_first_block) mode = 2;
     }
-    if (launch_self_attention_mode(e->qkvbuf, e->attnbuf, rows, hw, etainv_engine::kHeads, d, mode, n_img, e->dt, s, /*q_prescaled=*/d == 40 && self_attn40_v2_enabled())) return 1;
+    if (launch_self_attention_mode(e->qkvbuf, e->attnbuf, rows, hw, etainv_engine::kHeads, d, mode, n_img, e->dt, s, /*q_prescaled=*/d <= 80 && self_attn40_v2_enabled())) return 1;
     if (gemm(e->attnbuf, t.out1, e->hsB, M, e->hsA)) return 1;
     // cross-attention
     if (launch_layernorm(e->hsB, t.ln2.g, t.ln2.b, e->lnbuf, M, c, 1e-5f, e->dt, s)) return 1;

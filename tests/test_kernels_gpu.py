@@ -415,6 +415,20 @@ def test_self_attention_d40(capi, dtype, n, b, heads, gain):
     assert relerr(out, ref_self_attention(qkv, heads)) < TOL[dtype] * (2 if gain > 1 else 1)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,b,heads,gain", [(256, 2, 8, 1.0), (144, 1, 4, 1.0), (200, 3, 4, 1.0), (1024, 2, 8, 3.0), (2304, 1, 8, 0.05)])
+def test_self_attention_d80(capi, dtype, n, b, heads, gain):
+    """head_dim 80 on the same 32x32x16 kernel (one 32-query block per wave, three 32-row tiles of O^T, no zero image)"""
+    lib = capi.load()
+    d = 80
+    qkv = rnd(b, n, 3 * heads * d, seed=n + b + 1, dtype=dtype)
+    qkv[..., : 2 * heads * d] *= gain
+    out = torch.empty(b, n, heads * d, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_self_attention(capi.ptr(qkv), capi.ptr(out), b, n, heads, d, 0, 1, capi.dtype_code(dtype), capi.stream_ptr()))
+    assert torch.isfinite(out).all()
+    assert relerr(out, ref_self_attention(qkv, heads)) < TOL[dtype] * (2 if gain > 1 else 1)
+
+
 def test_self_attention_d40_maximum_jumps_late(capi):
     """A key whose score exceeds everything before it by far more than the deferral threshold, placed in a LATE tile, for a few queries
     only (the branch is wave-uniform, the update per query), plus a first tile whose scores are all very negative for other queries."""
