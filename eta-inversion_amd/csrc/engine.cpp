@@ -57,6 +57,7 @@ struct WeightSlot {
   int taps = 1;
   int dst_dtype = ETAINV_F32;  // F32 or the compute dtype (-1 placeholder replaced at build)
   float scale = 1.0f;          // constant folded into the values in fp32 before the rounding to the compute dtype
+  float* stage = nullptr;      // fp32 copy kept instead of packing at once: the consumer of a folded LayerNorm is packed when gamma / beta are known
   bool set = false;
   int64_t numel() const {
     int64_t n = 1;
@@ -78,6 +79,11 @@ struct TBlock {
   int c = 0;
   Norm gn, ln1, ln2, ln3;
   Lin proj_in, qkv, out1, q, kv, out2, ff1, ff2, proj_out;
+  // LayerNorm folded into its consumer (norm1 -> fused QKV, norm2 -> attn2.to_q, norm3 -> GEGLU projection): fp32 staging copies of the
+  // consumer weights, the row sums s of the packed gamma-scaled operand and c = beta W^T + bias (kernels.h, launch_ln_fold)
+  float *st_qkv = nullptr, *st_q = nullptr, *st_ff1 = nullptr;
+  float *s_qkv = nullptr, *c_qkv = nullptr, *s_q = nullptr, *c_q = nullptr, *s_ff1 = nullptr, *c_ff1 = nullptr;
+  float q_scale = 1.0f;
 };
 
 }  // namespace etainv
@@ -111,8 +117,13 @@ struct etainv_engine {
   void *skip[12] = {}, *tmp[3] = {}, *gnbuf = nullptr, *h1 = nullptr, *scbuf = nullptr;
   void *hsA = nullptr, *hsB = nullptr, *lnbuf = nullptr, *qkvbuf = nullptr, *attnbuf = nullptr, *qbuf = nullptr, *kvbuf = nullptr,
        *ffbuf = nullptr, *ctxT = nullptr, *tembuf = nullptr, *temb1 = nullptr, *temb2 = nullptr;
-  float *tprojbuf = nullptr, *gn_scratch = nullptr, *maps_acc = nullptr;
+  float *tprojbuf = nullptr, *gn_scratch = nullptr, *maps_acc = nullptr, *lnstat = nullptr, *lnfinal = nullptr;
   size_t maps_bytes = 0;
+  // norm1/2/3 of the transformer blocks folded into the GEMMs around them (no LayerNorm pass over HBM); ETAINV_LN_UNFUSED=1 keeps the
+  // standalone LayerNorm kernel (A/B switch, read at engine creation)
+  bool ln_fused = true;
+  bool ln_folded = false;   // the gamma-scaled consumer weights are packed (redone after any set_weight)
+  hipStream_t upload_stream = nullptr;   // stream of the last set_weight (the fold waits for it when the forward runs on another one)
 };
 
 namespace {
@@ -153,6 +164,12 @@ struct Builder {
     fixups.push_back([eng, idx, dst_field_holder, dst_off_bytes](char*) {
       eng->slots[idx].dst = reinterpret_cast<char*>(*dst_field_holder) + dst_off_bytes;
     });
+  }
+  // the slot keeps an fp32 copy at *holder + off (elements) instead of being packed by set_weight
+  void stage_slot(const std::string& name, float** holder, size_t off) {
+    const int idx = e->slot_by_name.at(name);
+    etainv_engine* eng = e;
+    fixups.push_back([eng, idx, holder, off](char*) { eng->slots[idx].stage = *holder + off; });
   }
   // fp32 vector parameter (bias / norm scale)
   void vec(const std::string& name, float** field, int n) {
@@ -227,6 +244,7 @@ struct Builder {
     // W_q, none added
     if (c / etainv_engine::kHeads <= 80 && self_attn40_v2_enabled())
       e->slots.back().scale = (1.0f / std::sqrt((float)(c / etainv_engine::kHeads))) * 1.4426950408889634f;
+    t.q_scale = e->slots.back().scale;
     add_slot(tp + ".attn1.to_k.weight", {c, c}, &t.qkv.w, (size_t)c * c * 2, PK_PLAIN, 1, e->dt);
     add_slot(tp + ".attn1.to_v.weight", {c, c}, &t.qkv.w, (size_t)2 * c * c * 2, PK_PLAIN, 1, e->dt);
     linear(tp + ".attn1.to_out.0", t.out1, c, c, true);
@@ -242,6 +260,23 @@ struct Builder {
     linear(tp + ".ff.net.0.proj", t.ff1, 8 * c, c, true, PK_GEGLU);
     linear(tp + ".ff.net.2", t.ff2, c, 4 * c, true);
     conv1x1(prefix + ".proj_out", t.proj_out, c, c);
+    if (e->ln_fused) {
+      const size_t cc = (size_t)c * c;
+      want(&t.st_qkv, 3 * cc * 4);
+      want(&t.st_q, cc * 4);
+      want(&t.st_ff1, 8 * cc * 4);
+      stage_slot(tp + ".attn1.to_q.weight", &t.st_qkv, 0);
+      stage_slot(tp + ".attn1.to_k.weight", &t.st_qkv, cc);
+      stage_slot(tp + ".attn1.to_v.weight", &t.st_qkv, 2 * cc);
+      stage_slot(tp + ".attn2.to_q.weight", &t.st_q, 0);
+      stage_slot(tp + ".ff.net.0.proj.weight", &t.st_ff1, 0);
+      want(&t.s_qkv, (size_t)3 * c * 4);
+      want(&t.c_qkv, (size_t)3 * c * 4);
+      want(&t.s_q, (size_t)c * 4);
+      want(&t.c_q, (size_t)c * 4);
+      want(&t.s_ff1, (size_t)8 * c * 4);
+      want(&t.c_ff1, (size_t)8 * c * 4);
+    }
   }
 };
 
@@ -338,6 +373,9 @@ int build_workspace(etainv_engine* e) {
   want(&e->temb2, B * 1280 * 2);
   want(reinterpret_cast<void**>(&e->tprojbuf), B * (size_t)e->tproj_total * 4);
   want(reinterpret_cast<void**>(&e->gn_scratch), B * (GN_MAX_CHUNKS + 1) * etainv_engine::kGroups * 2 * 4);
+  // LayerNorm partials [M][P][2]: P = C / (wave tile columns) <= C / 32, M * C <= B * hmax on every level
+  want(reinterpret_cast<void**>(&e->lnstat), B * hmax / 32 * 2 * 4);
+  want(reinterpret_cast<void**>(&e->lnfinal), B * hw[0] * 2 * 4);   // (mean, rstd) per token row
   const size_t res = L / 4;
   e->maps_bytes = (size_t)5 * e->max_img * 2 * etainv_engine::kHeads * res * res * 77 * 4;
   want(reinterpret_cast<void**>(&e->maps_acc), e->maps_bytes);
@@ -356,8 +394,11 @@ struct Fwd {
   const etainv_attn_ctrl* ctrl;
   int tblock_idx = 0;
 
+  struct LnIn { const float* s; const float* c; };   // folded LayerNorm of the input rows ((mean, rstd) per row in e->lnfinal)
+  // ln_out: this GEMM writes the input of a LayerNorm -- leave (mean, rstd) of its output rows in e->lnfinal (partials from the epilogue when
+  // the launch can, combined by a small pass; else a pass over the output)
   int gemm(const void* a, const Lin& l, void* out, int M, const void* residual = nullptr, int geglu = 0, const void* a2 = nullptr,
-           int c1 = 0, int c2 = 0) {
+           int c1 = 0, int c2 = 0, bool ln_out = false, const LnIn* ln = nullptr) {
     IGemmParams p;
     p.a1 = a;
     p.a2 = a2;
@@ -376,7 +417,17 @@ struct Fwd {
     p.taps = 1;
     p.geglu = geglu;
     p.rows_per_batch = M;
-    return launch_igemm(p, e->dt, s);
+    if (ln) {
+      p.bias = ln->c;
+      p.ln_stat = e->lnfinal;
+      p.ln_s = ln->s;
+    }
+    if (!ln_out) return launch_igemm(p, e->dt, s);
+    p.stat_out = e->lnstat;
+    int P = 0;
+    if (launch_igemm(p, e->dt, s, &P)) return 1;
+    if (P == 0) return launch_row_stats(out, e->lnfinal, M, l.n, 1e-5f, e->dt, s);
+    return launch_ln_finalize(e->lnstat, P, l.n / P, 1e-5f, e->lnfinal, M, s);
   }
   int conv(const void* a, const Lin& l, void* out, int H, int W, int stride, int ups, const float* rowvec, const void* residual) {
     IGemmParams p;
@@ -417,10 +468,16 @@ struct Fwd {
     const int hw = side * side, M = rows * hw, c = t.c, d = c / etainv_engine::kHeads;
     const int blk = tblock_idx++;
     if (launch_groupnorm(x, nullptr, c, 0, t.gn.g, t.gn.b, e->gnbuf, rows, hw, etainv_engine::kGroups, 1e-6f, 0, e->gn_scratch, e->dt, s)) return 1;
-    if (gemm(e->gnbuf, t.proj_in, e->hsA, M)) return 1;
+    const bool fold = e->ln_fused;
+    if (gemm(e->gnbuf, t.proj_in, e->hsA, M, nullptr, 0, nullptr, 0, 0, fold)) return 1;
     // self-attention
-    if (launch_layernorm(e->hsA, t.ln1.g, t.ln1.b, e->lnbuf, M, c, 1e-5f, e->dt, s)) return 1;
-    if (gemm(e->lnbuf, t.qkv, e->qkvbuf, M)) return 1;
+    if (fold) {
+      const LnIn ln1{t.s_qkv, t.c_qkv};
+      if (gemm(e->hsA, t.qkv, e->qkvbuf, M, nullptr, 0, nullptr, 0, 0, false, &ln1)) return 1;
+    } else {
+      if (launch_layernorm(e->hsA, t.ln1.g, t.ln1.b, e->lnbuf, M, c, 1e-5f, e->dt, s)) return 1;
+      if (gemm(e->lnbuf, t.qkv, e->qkvbuf, M)) return 1;
+    }
     int mode = 0, n_img = 1;
     if (ctrl) {
       n_img = ctrl->n_img;
@@ -428,10 +485,15 @@ struct Fwd {
       if (ctrl->mode == ETAINV_ATTN_MASA && ctrl->masa_active && blk >= ctrl->masa_first_block) mode = 2;
     }
     if (launch_self_attention_mode(e->qkvbuf, e->attnbuf, rows, hw, etainv_engine::kHeads, d, mode, n_img, e->dt, s, /*q_prescaled=*/d <= 80 && self_attn40_v2_enabled())) return 1;
-    if (gemm(e->attnbuf, t.out1, e->hsB, M, e->hsA)) return 1;
+    if (gemm(e->attnbuf, t.out1, e->hsB, M, e->hsA, 0, nullptr, 0, 0, fold)) return 1;
     // cross-attention
-    if (launch_layernorm(e->hsB, t.ln2.g, t.ln2.b, e->lnbuf, M, c, 1e-5f, e->dt, s)) return 1;
-    if (gemm(e->lnbuf, t.q, e->qbuf, M)) return 1;
+    if (fold) {
+      const LnIn ln2{t.s_q, t.c_q};
+      if (gemm(e->hsB, t.q, e->qbuf, M, nullptr, 0, nullptr, 0, 0, false, &ln2)) return 1;
+    } else {
+      if (launch_layernorm(e->hsB, t.ln2.g, t.ln2.b, e->lnbuf, M, c, 1e-5f, e->dt, s)) return 1;
+      if (gemm(e->lnbuf, t.q, e->qbuf, M)) return 1;
+    }
     if (gemm(e->ctxT, t.kv, e->kvbuf, rows * etainv_engine::kCtx)) return 1;
     CrossParams cp;
     cp.N = hw;
@@ -460,10 +522,15 @@ struct Fwd {
       }
     }
     if (launch_cross_attention_p(e->qbuf, e->kvbuf, e->attnbuf, rows, d, cp, e->dt, s)) return 1;
-    if (gemm(e->attnbuf, t.out2, e->hsA, M, e->hsB)) return 1;
+    if (gemm(e->attnbuf, t.out2, e->hsA, M, e->hsB, 0, nullptr, 0, 0, fold)) return 1;
     // feed-forward (GEGLU)
-    if (launch_layernorm(e->hsA, t.ln3.g, t.ln3.b, e->lnbuf, M, c, 1e-5f, e->dt, s)) return 1;
-    if (gemm(e->lnbuf, t.ff1, e->ffbuf, M, nullptr, 1)) return 1;
+    if (fold) {
+      const LnIn ln3{t.s_ff1, t.c_ff1};
+      if (gemm(e->hsA, t.ff1, e->ffbuf, M, nullptr, 1, nullptr, 0, 0, false, &ln3)) return 1;
+    } else {
+      if (launch_layernorm(e->hsA, t.ln3.g, t.ln3.b, e->lnbuf, M, c, 1e-5f, e->dt, s)) return 1;
+      if (gemm(e->lnbuf, t.ff1, e->ffbuf, M, nullptr, 1)) return 1;
+    }
     if (gemm(e->ffbuf, t.ff2, e->hsB, M, e->hsA)) return 1;
     return gemm(e->hsB, t.proj_out, out, M, x);
   }
@@ -495,6 +562,7 @@ extern "C" int etainv_engine_create(const etainv_engine_config* cfg, etainv_engi
   e->L = cfg->latent_size;
   e->maxB = cfg->max_unet_batch;
   e->max_img = cfg->max_img;
+  e->ln_fused = !getenv("ETAINV_LN_UNFUSED");
   if (build_model(e) || build_workspace(e)) {
     etainv_engine_destroy(e);
     return 1;
@@ -531,8 +599,31 @@ extern "C" int etainv_engine_set_weight(etainv_engine_t* e, const char* name, co
   ETAINV_CHECK(numel == s.numel(), std::string("size mismatch for ") + name);
   int64_t rows = s.shape[0], cols = s.numel() / s.shape[0];
   if (s.ndim == 1) { rows = s.shape[0]; cols = 1; }
-  if (launch_pack_weight(data, s.dst, rows, cols, s.pack, s.taps, s.dst_dtype, (hipStream_t)stream, s.scale)) return 1;
+  if (s.stage) {
+    ETAINV_HIP(hipMemcpyAsync(s.stage, data, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  } else if (launch_pack_weight(data, s.dst, rows, cols, s.pack, s.taps, s.dst_dtype, (hipStream_t)stream, s.scale)) {
+    return 1;
+  }
   s.set = true;
+  e->ln_folded = false;
+  e->upload_stream = (hipStream_t)stream;
+  return 0;
+}
+
+// gamma / beta of norm1/2/3 folded into the staged consumer weights of every transformer block (launch_ln_fold); runs on the forward's stream
+// before the first UNet call after the weights changed
+static int fold_layernorms(etainv_engine* e, hipStream_t s) {
+  if (e->upload_stream != s) ETAINV_HIP(hipStreamSynchronize(e->upload_stream));
+  for (const TBlock& t : e->tb) {
+    const int64_t c = t.c, cc = c * c;
+    for (int part = 0; part < 3; ++part)
+      if (launch_ln_fold(t.st_qkv + part * cc, t.ln1.g, t.ln1.b, nullptr, c, c, PK_PLAIN, part == 0 ? t.q_scale : 1.0f,
+                         reinterpret_cast<char*>(t.qkv.w) + (size_t)part * cc * 2, t.s_qkv + part * c, t.c_qkv + part * c, e->dt, s))
+        return 1;
+    if (launch_ln_fold(t.st_q, t.ln2.g, t.ln2.b, nullptr, c, c, PK_PLAIN, 1.0f, t.q.w, t.s_q, t.c_q, e->dt, s)) return 1;
+    if (launch_ln_fold(t.st_ff1, t.ln3.g, t.ln3.b, t.ff1.b, 8 * c, c, PK_GEGLU, 1.0f, t.ff1.w, t.s_ff1, t.c_ff1, e->dt, s)) return 1;
+  }
+  e->ln_folded = true;
   return 0;
 }
 
@@ -561,6 +652,7 @@ extern "C" int etainv_unet_forward(etainv_engine_t* e, const void* latent, int n
   }
   hipStream_t s = (hipStream_t)stream;
   const int L = e->L;
+  if (e->ln_fused && !e->ln_folded && fold_layernorms(e, s)) return 1;
   Fwd f{e, s, n_rows, ctrl};
 
   // timesteps (by value in the kernel arguments: no host buffer outlives this call) -> embedding, MLP, all 22 projections in one GEMM
@@ -788,6 +880,46 @@ extern "C" int etainv_op_gemm(const void* a, const void* w, const void* bias, co
   p.geglu = geglu;
   p.rows_per_batch = m;
   return launch_igemm(p, dtype, (hipStream_t)stream);
+}
+
+extern "C" int etainv_op_gemm_ln(const void* a, const void* w_folded, const float* c_vec, const float* s_vec, const float* stat,
+                                 const void* residual, void* out, float* stat_out, int* stat_p_out, int m, int n, int k, int geglu,
+                                 int dtype, void* stream) {
+  IGemmParams p;
+  p.a1 = a;
+  p.w = w_folded;
+  p.bias = c_vec;
+  p.residual = residual;
+  p.out = out;
+  p.M = m;
+  p.N = n;
+  p.c1 = k;
+  p.W = m;
+  p.Wo = m;
+  p.geglu = geglu;
+  p.rows_per_batch = m;
+  if (stat) {
+    p.ln_stat = stat;
+    p.ln_s = s_vec;
+  }
+  p.stat_out = stat_out;
+  return launch_igemm(p, dtype, (hipStream_t)stream, stat_p_out);
+}
+
+extern "C" int etainv_op_ln_fold(const float* w, const float* gamma, const float* beta, const float* bias, int n, int k, int geglu, float scale,
+                                 void* w_out, float* s_out, float* c_out, int dtype, void* stream) {
+  const int mode = geglu ? PK_GEGLU : PK_PLAIN;
+  // the bias goes through the same row permutation as the weight (into c_out, which the fold then reads and overwrites element by element)
+  if (bias && launch_pack_weight(bias, c_out, n, 1, mode, 1, ETAINV_F32, (hipStream_t)stream)) return 1;
+  return launch_ln_fold(w, gamma, beta, bias ? c_out : nullptr, n, k, mode, scale, w_out, s_out, c_out, dtype, (hipStream_t)stream);
+}
+
+extern "C" int etainv_op_row_stats(const void* x, float* stat, int rows, int c, float eps, int dtype, void* stream) {
+  return launch_row_stats(x, stat, rows, c, eps, dtype, (hipStream_t)stream);
+}
+
+extern "C" int etainv_op_ln_finalize(const float* partials, int p, int cw, float eps, float* stat, int rows, void* stream) {
+  return launch_ln_finalize(partials, p, cw, eps, stat, rows, (hipStream_t)stream);
 }
 
 extern "C" int etainv_op_conv3x3_ex(const void* x_nhwc, const void* w_okkc, const void* bias, const void* residual, void* out, int b, int h,

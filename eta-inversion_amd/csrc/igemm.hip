@@ -45,8 +45,41 @@ static inline int current_device() {
 }
 constexpr int64_t SPLITK_WS_BYTES = 64ll << 20;
 
-template <typename T, int BM, int BN, int WAVES_M, int STAGES, bool UPS = false>
+// ---- LayerNorm statistics carried between two GEMMs (IGemmParams::stat_out / ln_stat): partial (mean, M2) pairs of equal counts combined by
+// Chan's pairwise update -- no E[x^2] - E[x]^2 cancellation, fixed combination order
+// both sides hold `n` values each
+__device__ __forceinline__ void chan_merge_equal(float n, float& mean, float& m2, float mb, float m2b) {
+  const float d = mb - mean;
+  mean += 0.5f * d;
+  m2 += m2b + d * d * (0.5f * n);
+}
+// a <- the value of the even 16-lane row of each row pair, b <- the odd one (in both rows of the pair); inline asm: hipcc folds the second
+// result of the builtin into a copy of the first when both inputs are the same value
+__device__ __forceinline__ void pair_rows16(float x, float& a, float& b) {
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+// a <- the value of lanes 0-31, b <- the value of lanes 32-63 (in both halves)
+__device__ __forceinline__ void pair_halves32(float x, float& a, float& b) {
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+// combine the partials held by the four lanes fq = 0..3 (lane >> 4) that share a pixel row, `n` values each; every lane ends with the same pair
+__device__ __forceinline__ void chan_merge_fq_equal(float n, float& mean, float& m2) {
+  float ma, mb, qa, qb;
+  pair_rows16(mean, ma, mb); pair_rows16(m2, qa, qb);
+  chan_merge_equal(n, ma, qa, mb, qb);
+  pair_halves32(ma, mean, mb); pair_halves32(qa, m2, qb);
+  chan_merge_equal(2.f * n, mean, m2, mb, qb);
+}
+
+// LN: the folded-LayerNorm role of the launch as a compile-time constant -- the ring kernels sit exactly at 256 VGPRs, and a role read at
+// run time makes the register allocator keep all three epilogues' values apart (0 = none, 1 = producer: row statistics from the epilogue,
+// 2 = consumer: rstd (acc - mean s) + c)
+template <typename T, int BM, int BN, int WAVES_M, int STAGES, bool UPS = false, int LN = 0>
 __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) {
+  constexpr bool ln_emit = LN == 1;
+  constexpr bool ln_use = LN == 2;
   constexpr int NTHR = WAVES_M * 128;      // WAVES_M x 2 waves
   constexpr int RP = NTHR / 8;             // LDS rows staged per pass (8 lanes x 16 B per 128-B row)
   constexpr int WM = BM / WAVES_M, WN = BN / 2;  // wave tile
@@ -62,6 +95,12 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   // bias of the tiles in flight: filled by LDS-DMA together with a tile's first K step, read by its epilogue (a global bias
   // load in the epilogue waits behind every queued DMA: ~1.5 us per tile with the matrix pipe idle)
   float* sBias = reinterpret_cast<float*>(smem + (size_t)STAGES * (BM + BN) * BK * sizeof(T));   // [4][BN]
+  // LayerNorm consumer on the 256 x 128 ring (the GEGLU projection; 13 KB of LDS to spare): the s vector and the (mean, rstd) rows of the tiles in
+  // flight arrive by DMA with the bias -- read from global memory at the start of the epilogue they cost one exposed memory latency per tile
+  // (measured +1.5 us on a 7.4 us tile), and the 256 x 160 ring has neither the LDS nor the registers to fetch them early
+  constexpr bool LN_STAGED = LN == 2 && STAGES == 3 && BN == 128;
+  float* sLnS = sBias + 4 * BN + 256;        // [4][BN]   (after the bias ring and the 1-KiB dummy piece)
+  float* sLnStat = sLnS + 4 * BN;            // [4][BM][2]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -105,13 +144,14 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   // fast path (no upsample): element offset of tap (0,0) in source 1 / source 2 (lane chunk included) and 9-bit tap validity
   int a_e1[A_LOADS], a_e2[A_LOADS], a_mask[A_LOADS];
   const T* w_row[B_LOADS];
-  int it_n0 = 0, it_bias_buf = 0;
+  int it_n0 = 0, it_m0 = 0, it_bias_buf = 0;
   // position of the K tile being issued, advanced incrementally (no integer division in the loop); it_k0 = first K tile of the part
   int it_tap = 0, it_c0 = 0, it_ky = 0, it_kx = 0, it_k0 = 0;
   auto setup_issue = [&](int i) __attribute__((always_inline)) {   // geometry of the tile whose K tiles are being prefetched
     int m0, n0;
     const int part = tile_origin(i, m0, n0);
     it_n0 = n0;
+    it_m0 = m0;
     it_bias_buf = i & 3;
     if (ksplit > 1) {
       it_k0 = part * nk;
@@ -245,6 +285,50 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   };
   // returns the store class of the tile: 0 = unknown number of store instructions (partial tile / slow path),
   // 1 = exactly MT*ceil(NT/2) per wave, 2 = exactly MT*ceil(NT/4) per wave (GEGLU) -- see the counted vmcnt waits of the ring
+  // LayerNorm consumer: mean / rstd of this lane's MT pixel rows from the producer's partials.  The four lanes that share a row (fq) each
+  // combine every fourth partial, then merge among themselves.
+  // The LayerNorm fields are read through the kernel-argument segment at their point of use (scalar loads in the epilogue) instead of living in
+  // SGPRs across the main loop: the ring kernels are out of scalar registers too, and every SGPR spilled to a VGPR lane costs a vector register.
+  auto ln_args = [&]() __attribute__((always_inline)) {
+    typedef const __attribute__((address_space(4))) IGemmParams* KArgs;   // constant address space: scalar loads
+    KArgs kp = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+  };
+  auto ln_rows = [&](int mw, float (&mean)[MT], float (&rstd)[MT]) __attribute__((always_inline)) {
+    const float* ln_stat = ln_args()->ln_stat;   // finalized (mean, rstd) per row: norm.hip, ln_finalize_kernel / row_stats_kernel
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      int m = mw + i * 16 + fr;
+      m = m < p.M ? m : p.M - 1;
+      const f32x2 v = *reinterpret_cast<const f32x2*>(ln_stat + (int64_t)m * 2);
+      mean[i] = v[0];
+      rstd[i] = v[1];
+    }
+  };
+  // LayerNorm producer: (mean, M2) of the NT * 4 stored (rounded) values this lane holds of pixel row m, merged over the four fq lanes = the WN
+  // columns of the wave tile -> partial `pidx` of row m
+  auto emit_row_stat = [&](const u32x2 (&po)[NT], int m, int pidx) __attribute__((always_inline)) {
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      T o[4];
+      *reinterpret_cast<u32x2*>(o) = po[j];
+      sum += (to_f32(o[0]) + to_f32(o[1])) + (to_f32(o[2]) + to_f32(o[3]));
+    }
+    float mu = sum * (1.0f / (float)(NT * 4)), m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      T o[4];
+      *reinterpret_cast<u32x2*>(o) = po[j];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const float d = to_f32(o[q]) - mu; m2 += d * d; }
+    }
+    chan_merge_fq_equal((float)(NT * 4), mu, m2);
+    const auto kp = ln_args();
+    const int stat_P = kp->stat_P;
+    if (fq == 0 && m < p.M && pidx < stat_P) *reinterpret_cast<f32x2*>(kp->stat_out + ((int64_t)m * stat_P + pidx) * 2) = (f32x2){mu, m2};
+  };
   int ep_part = 0;   // K part of the tile in the epilogue (split-K)
   auto epilogue = [&](int m0, int n0, int tile) __attribute__((always_inline)) -> int {
     if (p.debug & 2) {   // ablation: no epilogue traffic
@@ -267,18 +351,48 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       if (p.debug & 8) mw &= 255;   // ablation: all tiles store into the same cache-resident rows
       const bool wide = (n0 + BN <= p.N) && (p.N % 16) == 0 && !(p.debug & 32);
       const float* tile_bias = sBias + (tile & 3) * BN;   // whole tile inside N: 16-byte stores after a lane swap
+      const bool ln = ln_use;   // folded LayerNorm: v = rstd[m] * (acc - mean[m] * s[n]) + c[n]  (c arrives as the bias)
+      float ln_mean[MT], ln_rstd[MT];
       if (!p.geglu) {
         f32x4 bv[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int n = n0 + wn * WN + j * 16 + fq * 4;
           bv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (p.bias) bv[j] = *reinterpret_cast<const f32x4*>(tile_bias + wn * WN + j * 16 + fq * 4);
+          if (p.bias && !ln) bv[j] = *reinterpret_cast<const f32x4*>(tile_bias + wn * WN + j * 16 + fq * 4);
           if (p.rowvec && n < p.N) bv[j] += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)batch * p.rowvec_stride + n);
         }
+        if (ln) ln_rows(mw, ln_mean, ln_rstd);
 #ifndef ETAINV_RES_PREFETCH
 #define ETAINV_RES_PREFETCH 1
 #endif
+        if (ln) {
+          // LayerNorm consumer (never has a residual): its own block, so that the s vector and the row statistics do not extend the register
+          // live ranges of the residual path below (256 VGPRs, no spill)
+          f32x4 sv[NT];
+          const float* ln_s = ln_args()->ln_s;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wn * WN + j * 16 + fq * 4;
+            sv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (n < p.N) sv[j] = *reinterpret_cast<const f32x4*>(ln_s + n);
+          }
+          ln_rows(mw, ln_mean, ln_rstd);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const int m = mw + i * 16 + fr;
+            u32x2 po[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              // (c re-read from LDS per row group: 20 registers less across the block than a copy held next to s)
+              const f32x4 v = (acc[i][j] - ln_mean[i] * sv[j]) * ln_rstd[i] + *reinterpret_cast<const f32x4*>(tile_bias + wn * WN + j * 16 + fq * 4);
+              acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+              T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+              po[j] = *reinterpret_cast<u32x2*>(o);
+            }
+            store_row_group(out + (int64_t)m * p.N + n0 + wn * WN, po, std::integral_constant<int, NT>{}, m < p.M, wide);
+          }
+        } else {
 #if ETAINV_RES_PREFETCH
         // residual: ALL of the tile's residual loads go out before the first store (MT * NT 8-byte loads per lane; the fragment registers
         // of the finished K step are dead here).  Issued per 16-row group right before that group's stores, every group exposed a full
@@ -298,6 +412,9 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
           }
         }
 #endif
+        // (a LayerNorm producer keeps the packed rows until every store is out: they take over the residual's registers row by row, and the
+        // statistics run when the bias registers are dead)
+        u32x2 po[MT][NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           const int m = mw + i * 16 + fr;
@@ -312,7 +429,6 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
             }
           }
 #endif
-          u32x2 po[NT];
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             f32x4 v = acc[i][j] + bv[j];
@@ -327,20 +443,48 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
               v[0] += to_f32(r[0]); v[1] += to_f32(r[1]); v[2] += to_f32(r[2]); v[3] += to_f32(r[3]);
             }
             T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
-            po[j] = *reinterpret_cast<u32x2*>(o);
+            po[i][j] = *reinterpret_cast<u32x2*>(o);
           }
-          store_row_group(out + (int64_t)m * p.N + n0 + wn * WN, po, std::integral_constant<int, NT>{}, m < p.M, wide);
+          store_row_group(out + (int64_t)m * p.N + n0 + wn * WN, po[i], std::integral_constant<int, NT>{}, m < p.M, wide);
+        }
+        if (ln_emit) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) emit_row_stat(po[i], mw + i * 16 + fr, n0 / WN + wn);
+        }
         }
       } else {
         const int No = p.N >> 1;
-        f32x4 ba[NT / 2 + 1], bg[NT / 2 + 1];
+        f32x4 ba[NT / 2 + 1], bg[NT / 2 + 1], sa[NT / 2 + 1], sg[NT / 2 + 1];
 #pragma unroll
         for (int j = 0; j < NT / 2; ++j) {
           const int n = n0 + wn * WN + j * 16 + fq * 4;
-          ba[j] = bg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          ba[j] = bg[j] = sa[j] = sg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (ln) {
+            if constexpr (LN_STAGED) {
+              const float* ts = sLnS + (tile & 3) * BN + wn * WN + j * 16 + fq * 4;
+              sa[j] = *reinterpret_cast<const f32x4*>(ts);
+              sg[j] = *reinterpret_cast<const f32x4*>(ts + WN / 2);
+            } else {
+              const float* ln_s = ln_args()->ln_s;
+              sa[j] = *reinterpret_cast<const f32x4*>(ln_s + n);
+              sg[j] = *reinterpret_cast<const f32x4*>(ln_s + n + WN / 2);
+            }
+          }
           if (p.bias) {
             ba[j] = *reinterpret_cast<const f32x4*>(tile_bias + wn * WN + j * 16 + fq * 4);
             bg[j] = *reinterpret_cast<const f32x4*>(tile_bias + wn * WN + j * 16 + fq * 4 + WN / 2);
+          }
+        }
+        if (ln) {
+          if constexpr (LN_STAGED) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+              const f32x2 v = *reinterpret_cast<const f32x2*>(sLnStat + (tile & 3) * (2 * BM) + (wm * WM + i * 16 + fr) * 2);
+              ln_mean[i] = v[0];
+              ln_rstd[i] = v[1];
+            }
+          } else {
+            ln_rows(mw, ln_mean, ln_rstd);
           }
         }
 #pragma unroll
@@ -349,7 +493,13 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
           u32x2 po[NT / 2 + 1];
 #pragma unroll
           for (int j = 0; j < NT / 2; ++j) {
-            const f32x4 a = acc[i][j] + ba[j], g = acc[i][j + NT / 2] + bg[j];
+            f32x4 a = acc[i][j], g = acc[i][j + NT / 2];
+            if (ln) {
+              a = (a - ln_mean[i] * sa[j]) * ln_rstd[i];
+              g = (g - ln_mean[i] * sg[j]) * ln_rstd[i];
+            }
+            a += ba[j];
+            g += bg[j];
             acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc[i][j + NT / 2] = (f32x4){0.f, 0.f, 0.f, 0.f};
             T o[4];
@@ -367,8 +517,13 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         }
       }
       const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N) && !(p.debug & 16);   // every lane of every wave stored
-      return full ? (p.geglu ? 2 : 1) : 0;   // (full implies wide)
+      return full ? (p.geglu ? 2 : ln_emit ? 3 : 1) : 0;   // (full implies wide)
     }
+    // general path (ragged tiles, conv_out, fp32 outputs, split-K partials): LayerNorm consumers supported, statistics are never emitted here
+    // (the ring kernels take a LayerNorm consumer only when every tile runs the fast path above: launch_igemm)
+    const bool ln_slow = ln_use && STAGES == 2 && ksplit == 1;
+    float lns_mean[MT], lns_rstd[MT];
+    if (ln_slow) ln_rows(m0 + wm * WM, lns_mean, lns_rstd);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int m = m0 + wm * WM + i * 16 + fr;
@@ -381,6 +536,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
           f32x4 v = acc[i][j];
           acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (!m_ok || n >= p.N) continue;
+          if (ln_slow) v = (v - lns_mean[i] * *reinterpret_cast<const f32x4*>(ln_args()->ln_s + n)) * lns_rstd[i];
           if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
           if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)batch * p.rowvec_stride + n);
           if (res) {
@@ -418,6 +574,11 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
           acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           acc[i][j + NT / 2] = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (!m_ok) continue;
+          if (ln_slow) {
+            const float* ln_s = ln_args()->ln_s;
+            a = (a - lns_mean[i] * *reinterpret_cast<const f32x4*>(ln_s + n)) * lns_rstd[i];
+            g = (g - lns_mean[i] * *reinterpret_cast<const f32x4*>(ln_s + n + WN / 2)) * lns_rstd[i];
+          }
           if (p.bias) {
             a += *reinterpret_cast<const f32x4*>(p.bias + n);
             g += *reinterpret_cast<const f32x4*>(p.bias + n + WN / 2);
@@ -503,7 +664,9 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       // vmcnt counts loads, stores and LDS-DMA together in issue order: the epilogue's stores are younger than the DMA of
       // step s+1, so they may stay in flight across this wait (their L2 acks are not on the critical path)
       constexpr int S1 = MT * ((NT + 1) / 2), S2 = MT * ((NT / 2 + 1) / 2);   // 16-byte stores per wave and tile
+      constexpr int S3 = S1 + MT;   // + the row-statistics stores of a LayerNorm producer
       if (cls == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (S1 & 15) | ((S1 >> 4) << 14));
+      else if (cls == 3) __builtin_amdgcn_s_waitcnt(0x0F70 | (S3 & 15) | ((S3 >> 4) << 14));
       else if (cls == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (S2 & 15) | ((S2 >> 4) << 14));
       else __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();
@@ -592,7 +755,17 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
           const int n = it_n0 + c < p.N ? it_n0 + c : p.N - 1;
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + n),
                                            (__attribute__((address_space(3))) void*)(sBias + it_bias_buf * BN + wrow0 * 8), 4, 0, 0);
+          if constexpr (LN_STAGED)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.ln_s + n),
+                                             (__attribute__((address_space(3))) void*)(sLnS + it_bias_buf * BN + wrow0 * 8), 4, 0, 0);
         }
+      }
+      if constexpr (LN_STAGED) {   // (mean, rstd) of the tile's BM rows: 2 * BM floats = one dword per lane of the block
+        static_assert(2 * BM == NTHR, "one DMA piece per wave");
+        int f = it_m0 * 2 + tid;
+        f = f < p.M * 2 ? f : p.M * 2 - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.ln_stat + f),
+                                         (__attribute__((address_space(3))) void*)(sLnStat + it_bias_buf * (2 * BM) + wrow0 * 8), 4, 0, 0);
       }
     };
     auto advance_ring = [&]() __attribute__((always_inline)) {
@@ -621,6 +794,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     auto wait_one_slot_in_flight = [&](int young = 0) {
       constexpr int S1 = MT * ((NT + 1) / 2), S2 = MT * ((NT / 2 + 1) / 2);
       if (young == 1) ETAINV_VMCNT(N1 + S1);
+      else if (young == 3) ETAINV_VMCNT(N1 + S1 + MT);   // + the row-statistics stores of a LayerNorm producer
       else if (young == 2) ETAINV_VMCNT(N1 + S2);
       else ETAINV_VMCNT(N1);
     };
@@ -771,14 +945,31 @@ static double igemm_algo_bytes(const IGemmParams& p) {
                 (p.residual ? out_el : 0.0));
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int STAGES = 2, bool UPS = false>
-static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
+template <typename T, int BM, int BN, int WAVES_M, int STAGES = 2, bool UPS = false, int LN = 0>
+static int launch_igemm_t(const IGemmParams& p_in, hipStream_t s, int* stat_P = nullptr) {
+  IGemmParams p = p_in;
+  // LayerNorm producer: the fast epilogue (whole wave tiles inside one image and inside N) writes one (mean, M2) partial per row and wave
+  // tile column; anything else reports 0 partials and the caller computes the statistics with launch_row_stats
+  constexpr int WM_ = BM / WAVES_M, WN_ = BN / 2;
+  if (p.stat_out && !(STAGES == 3 && UPS) && !p.geglu && !p.out_nchw && !p.out_f32 && p.ksplit <= 1 && p.rows_per_batch % WM_ == 0 && p.N % WN_ == 0 && p.N % 16 == 0) {
+    p.stat_P = p.N / WN_;
+  } else {
+    p.stat_out = nullptr;
+    p.stat_P = 0;
+  }
+  if (stat_P) *stat_P = p.stat_P;
+  if constexpr (!UPS && LN == 0) {   // one instantiation per LayerNorm role (the 256 x 128 ring only runs GEGLU: never a producer)
+    if constexpr (!(STAGES == 3 && BN == 128))
+      if (p.stat_out) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 1>(p, s, nullptr);
+    if (p.ln_stat) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 2>(p, s, nullptr);
+  }
   const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN) * (STAGES == 2 && p.ksplit > 1 ? p.ksplit : 1);   // virtual tiles with split-K
-  const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(T) + 4 * BN * sizeof(float) + (STAGES == 3 ? 1024 : 0);
+  const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(T) + 4 * BN * sizeof(float) + (STAGES == 3 ? 1024 : 0) +
+                     (LN == 2 && STAGES == 3 && BN == 128 ? (size_t)4 * (BN + 2 * BM) * sizeof(float) : 0);   // staged s vectors and (mean, rstd) rows
   static bool attr_set[kMaxDevices] = {};   // per device: function attributes and the allocations below belong to the current device
   const int dev = current_device();
   if (!attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set[dev] = true;
   }
   // persistent grid: as many blocks as are resident at once (LDS-limited: 160 KiB / lds per CU, 256 CUs), a multiple of 8
@@ -792,7 +983,7 @@ static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
     (void)hipMemsetAsync(d_stamps, 0, 2048 * 8 * 8 * sizeof(uint64_t), s);
     ps.stamps = d_stamps;
   }
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS>), dim3(grid), dim3(WAVES_M * 128), lds, s, ps);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS, LN>), dim3(grid), dim3(WAVES_M * 128), lds, s, ps);
   if (ps.stamps) {
     (void)hipStreamSynchronize(s);
     std::vector<uint64_t> h((size_t)grid * 8 * 8);
@@ -813,7 +1004,7 @@ static int launch_igemm_t(const IGemmParams& p, hipStream_t s) {
   return 0;
 #endif
   ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s, igemm_algo_bytes(p));
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS>), dim3(grid), dim3(WAVES_M * 128), lds, s, p);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS, LN>), dim3(grid), dim3(WAVES_M * 128), lds, s, p);
   ETAINV_LAUNCH_CHECK();
   return 0;
 }
@@ -827,6 +1018,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p) {
     const int m = (int)(idx / n4), n = (int)(idx - (int64_t)m * n4) * 4;
     f32x4 v = *reinterpret_cast<const f32x4*>(p.ws + (int64_t)m * p.N + n);
     for (int k = 1; k < p.ksplit; ++k) v += *reinterpret_cast<const f32x4*>(p.ws + ((int64_t)k * p.M + m) * p.N + n);
+    if (p.ln_stat) {   // folded LayerNorm (see IGemmParams::ln_stat)
+      v = (v - p.ln_stat[(int64_t)m * 2] * *reinterpret_cast<const f32x4*>(p.ln_s + n)) * p.ln_stat[(int64_t)m * 2 + 1];
+    }
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
     if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)(m / p.rows_per_batch) * p.rowvec_stride + n);
     if (p.residual) {
@@ -838,7 +1032,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p) {
   }
 }
 
-int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
+int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P) {
+  if (stat_P) *stat_P = 0;
   static void* zero_pages[kMaxDevices] = {};   // 256 zero bytes read by the halo lanes of the 3x3 taps (one-time allocation per device)
   const int dev = current_device();
   if (!zero_pages[dev]) {
@@ -857,22 +1052,26 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
   ETAINV_CHECK(!p.geglu || (p.N % 128) == 0, "GEGLU needs N % 128 == 0");
   ETAINV_CHECK(p.rows_per_batch > 0, "rows_per_batch");
   ETAINV_CHECK(!p.rowvec || p.rowvec_stride >= p.N, "rowvec_stride");
+  ETAINV_CHECK(!p.ln_stat || (p.ln_s && p.bias && p.taps == 1 && !p.a2), "folded LayerNorm: s / c vectors, plain GEMM");
+  ETAINV_CHECK(!p.ln_stat || (!p.residual && !p.rowvec && !p.stat_out), "folded LayerNorm: no residual / row vector / statistics output on the consumer");
   // tile choice: big tiles when they still fill the 256 CUs, else 64x64 (GEGLU pairing is per wave tile,
   // so the packing of a GEGLU weight fixes its tile: always 128 wide)
   const int64_t big_tiles = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128);
   const bool big = p.geglu || (big_tiles >= 192 && p.N > 64);
   ETAINV_CHECK(!p.out_nchw || p.N == 4, "out_nchw needs N == 4");
   const int64_t huge_tiles = (int64_t)cdiv(p.M, 256) * cdiv(p.N, 160);
+  // a LayerNorm consumer on a ring kernel: fast epilogue only (64-row wave tiles inside one image)
+  const bool ln_ring_ok = !p.ln_stat || p.rows_per_batch % 64 == 0;
   if (!p.geglu && p.ups && p.N % 160 == 0 && huge_tiles >= 256 && !getenv("ETAINV_NO_RING")) {
     // the ring's issue is branch-free, so the fused-upsample addressing is its own instantiation
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, true>(p, s)));
-  } else if (!p.geglu && p.N % 160 == 0 && huge_tiles >= 256 && !getenv("ETAINV_NO_RING")) {
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, true, 0>(p, s, stat_P)));
+  } else if (!p.geglu && p.N % 160 == 0 && huge_tiles >= 256 && ln_ring_ok && !getenv("ETAINV_NO_RING")) {
     // experimental (opt-in): 256 x 160 x 64 tile, 8 waves, one resident block per CU (26 % fewer L2 -> LDS bytes per
     // FLOP).  Measured equal to 128 x 160 with two resident blocks (1026 vs 1033 TFLOP/s on conv 1280->1280 @16x16)
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3>(p, s)));
-  } else if (p.geglu && p.c1 >= (getenv("ETAINV_GEGLU_RING_MINK") ? atoi(getenv("ETAINV_GEGLU_RING_MINK")) : 320) && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 128) >= 256 && !getenv("ETAINV_NO_RING")) {
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, false, 0>(p, s, stat_P)));
+  } else if (p.geglu && ln_ring_ok && p.c1 >= (getenv("ETAINV_GEGLU_RING_MINK") ? atoi(getenv("ETAINV_GEGLU_RING_MINK")) : 320) && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 128) >= 256 && !getenv("ETAINV_NO_RING")) {
     // (since the interleaved windows the ring also wins at K = 320: 1.42 vs 1.55 ms for ff1 320 -> 2560 at 64 x 64 x 128 rows)
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 128, 4, 3>(p, s)));
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 128, 4, 3, false, 0>(p, s, stat_P)));
   } else {
     // two-slot kernels: 128 x 160 (every channel count of SD1.x is a multiple of 320: no padded columns, 20 MFMAs per 9 fragment
     // reads), 128 x 128 (GEGLU / other widths), 64 x 64 for small M*N.  A two-slot block is bound by one memory latency per K tile
@@ -901,12 +1100,15 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s) {
       pk.bias = nullptr;
       pk.rowvec = nullptr;
       pk.residual = nullptr;
+      pk.ln_stat = nullptr;    // applied by the reduction
+      pk.stat_out = nullptr;   // (a split-K producer emits no statistics)
     }
     ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s, igemm_algo_bytes(p));
     prof_pause(true);
     int rc = 0;
-    ETAINV_DISPATCH_HALF(dtype, T, rc = cfg == 0 ? launch_igemm_t<T, 128, 160, 2>(pk, s) : cfg == 1 ? launch_igemm_t<T, 128, 128, 2>(pk, s)
-                                                                                                   : launch_igemm_t<T, 64, 64, 2>(pk, s));
+    ETAINV_DISPATCH_HALF(dtype, T, rc = cfg == 0   ? launch_igemm_t<T, 128, 160, 2, 2, false, 0>(pk, s, stat_P)
+                                        : cfg == 1 ? launch_igemm_t<T, 128, 128, 2, 2, false, 0>(pk, s, stat_P)
+                                                   : launch_igemm_t<T, 64, 64, 2, 2, false, 0>(pk, s, stat_P));
     prof_pause(false);
     if (rc) return rc;
     if (ks > 1) {

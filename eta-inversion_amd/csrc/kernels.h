@@ -33,8 +33,19 @@ struct IGemmParams {
   int ksplit = 1;             // split-K parts (filled in by launch_igemm for small M*N with deep K)
   float* ws = nullptr;        // [ksplit][M][N] fp32 partials
   int rows_per_batch = 1;     // Ho*Wo for convs; M/batch for linears
+  // ---- LayerNorm folded into the GEMM pair around it (the transformer blocks' norm1/2/3: no LayerNorm pass over HBM).
+  // Producer side (the GEMM that writes the LayerNorm's input x): per row and per column chunk of the STORED (rounded) output, the pair
+  // (mean, M2 = sum of squared deviations from that mean) -> stat_out[m][stat_P][2]; stat_P is chosen by launch_igemm (columns of one wave
+  // tile per chunk) and reported through its stat_P argument; 0 = this launch could not emit them (the caller runs launch_row_stats).
+  float* stat_out = nullptr;
+  int stat_P = 0;
+  // Consumer side (K = LayerNorm width, weights pre-multiplied by gamma: launch_ln_fold): out = rstd[m] * (acc - mean[m] * ln_s[n]) + bias[n],
+  // bias = the folded c vector; ln_stat = (mean, rstd) per row, [M][2] (launch_ln_finalize of the producer's partials, or launch_row_stats).
+  const float* ln_stat = nullptr;
+  const float* ln_s = nullptr;      // [N] physical column order, like bias
 };
-int launch_igemm(const IGemmParams& p, int dtype, hipStream_t s);
+// stat_P (optional): receives the number of partials per row written to p.stat_out (0: none written)
+int launch_igemm(const IGemmParams& p, int dtype, hipStream_t s, int* stat_P = nullptr);
 
 // ---- norm.hip
 // GroupNorm(32 groups) over NHWC with optional second (concatenated) source and fused SiLU.
@@ -44,6 +55,10 @@ int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float
                      int b, int hw, int groups, float eps, int silu, float* scratch, int dtype, hipStream_t s);
 int launch_layernorm(const void* x, const float* gamma, const float* beta, void* out, int rows, int c, float eps, int dtype,
                      hipStream_t s);
+// stat[row] = (mean, rstd) of x[row][0..c): IGemmParams::ln_stat computed by a pass over x (when the producing GEMM could not emit partials)
+int launch_row_stats(const void* x, float* stat, int rows, int c, float eps, int dtype, hipStream_t s);
+// partials[row][P] (mean, M2) pairs over cw columns each (IGemmParams::stat_out) -> stat[row] = (mean, rstd); Chan's update in index order
+int launch_ln_finalize(const float* partials, int P, int cw, float eps, float* stat, int rows, hipStream_t s);
 
 // ---- attention.hip
 // self-attention modes: 0 plain; 1 ptp self-replace (cond target rows use Q,K of their source row);
@@ -85,7 +100,12 @@ int launch_time_embedding(const int64_t* t_host, int rows, int dim, void* out, i
 // y = silu(x) elementwise on T
 int launch_silu(const void* x, void* out, int64_t n, int dtype, hipStream_t s);
 // cast fp32 -> T with optional row permutation (weights)
-int launch_pack_weight(const float* src, void* dst, int64_t rows, int64_t cols, int mode, int taps, int dtype, hipStream_t s, float scale = 1.0f);
+int launch_pack_weight(const float* src, void* dst, int64_t rows, int64_t cols, int mode, int taps, int dtype, hipStream_t s, float scale = 1.0f,
+                       const float* colscale = nullptr);
+// LayerNorm(gamma, beta) folded into the Linear (w_src [rows][cols] fp32, pack mode 0 / 2) that consumes it: packed operand W' = gamma . W, the
+// row sums s of the rounded W' and c = beta W^T + bias (bias_packed may be null) -- see IGemmParams::ln_stat
+int launch_ln_fold(const float* w_src, const float* gamma, const float* beta, const float* bias_packed, int64_t rows, int64_t cols, int mode, float scale,
+                   void* w_dst, float* s_dst, float* c_dst, int dtype, hipStream_t s);
 int launch_cast_f32(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, hipStream_t s);
 
 // ---- maps.hip

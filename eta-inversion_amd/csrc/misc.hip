@@ -137,7 +137,8 @@ __global__ void silu_kernel(const T* x, T* out, int64_t n) {
 //   mode 4: conv_out [4][I][3][3] -> [tap][I][4]                         (rows = 4, cols = I*9)
 //   mode 5: conv_in as a K = 64 GEMM: [O][4][3][3] -> [O][64], k = tap*4 + ci, k >= 36 zero   (rows = O, cols = 36)
 template <typename TD>
-__global__ void pack_weight_kernel(const float* __restrict__ src, TD* __restrict__ dst, int64_t rows, int64_t cols, int mode, int taps, float scale) {
+__global__ void pack_weight_kernel(const float* __restrict__ src, TD* __restrict__ dst, int64_t rows, int64_t cols, int mode, int taps, float scale,
+                                   const float* __restrict__ colscale) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (mode == 5) {
     if (i >= rows * 64) return;
@@ -165,7 +166,43 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, TD* __restrict
     const int64_t tap = i / (cin * 4), r = i - tap * cin * 4, ci = r / 4, o = r - ci * 4;
     s = o * cols + ci * 9 + tap;
   }
-  dst[i] = from_f32<TD>(src[s] * scale);   // scale: 1, or a constant folded into the weights in fp32 BEFORE the rounding (softmax scale of to_q)
+  // scale: 1, or a constant folded into the weights in fp32 BEFORE the rounding (softmax scale of to_q); colscale (modes 0 / 2): a per-input-
+  // column factor (the gamma of a LayerNorm folded into this Linear)
+  float v = src[s] * scale;
+  if (colscale) v *= colscale[s % cols];
+  dst[i] = from_f32<TD>(v);
+}
+
+// LayerNorm folded into the Linear that consumes it (reference: BasicTransformerBlock norm1 -> attn1.to_q/k/v, norm2 -> attn2.to_q,
+// norm3 -> ff.net.0.proj):   LN(x) W^T + b  =  rstd * (x W'^T - mean * s) + c   with  W'[n][k] = gamma[k] W[n][k]  (packed by
+// pack_weight_kernel with colscale = gamma),  s[n] = sum_k W'[n][k] over the ROUNDED operand the MFMAs multiply,  c[n] = sum_k beta[k] W[n][k] + b[n].
+// One wave per packed row; `mode` 0 / 2 as in pack_weight_kernel (2: GEGLU row interleave), bias already in packed order.
+template <typename TD>
+__global__ void __launch_bounds__(256) ln_fold_vectors_kernel(const float* __restrict__ src, const TD* __restrict__ packed, const float* __restrict__ beta,
+                                                              const float* __restrict__ bias_packed, int64_t rows, int64_t cols, int mode, float scale,
+                                                              float* __restrict__ s_out, float* __restrict__ c_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= rows) return;
+  int64_t logical = p;
+  if (mode == 2) {
+    const int64_t blk = p / 64, within = p % 64;
+    logical = within < 32 ? blk * 32 + within : rows / 2 + blk * 32 + within - 32;
+  }
+  float s = 0.f, c = 0.f;
+  for (int64_t k = lane; k < cols; k += 64) {
+    s += to_f32(packed[p * cols + k]);
+    c += beta[k] * (src[logical * cols + k] * scale);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    c += __shfl_xor(c, o);
+  }
+  if (lane == 0) {
+    s_out[p] = s;
+    c_out[p] = c + (bias_packed ? bias_packed[p] : 0.f);
+  }
 }
 
 template <typename TS, typename TD>
@@ -231,10 +268,24 @@ int launch_silu(const void* x, void* out, int64_t n, int dtype, hipStream_t s) {
   return 0;
 }
 
-int launch_pack_weight(const float* src, void* dst, int64_t rows, int64_t cols, int mode, int taps, int dtype, hipStream_t s, float scale) {
+int launch_pack_weight(const float* src, void* dst, int64_t rows, int64_t cols, int mode, int taps, int dtype, hipStream_t s, float scale,
+                       const float* colscale) {
   ETAINV_CHECK(src && dst && rows > 0 && cols > 0, "bad arguments");
+  ETAINV_CHECK(!colscale || mode == 0 || mode == 2, "column scale: plain / GEGLU packing only");
   const int64_t n = mode == 5 ? rows * 64 : rows * cols;
-  ETAINV_DISPATCH_DTYPE(dtype, TD, hipLaunchKernelGGL(pack_weight_kernel<TD>, dim3(cdiv(n, 256)), dim3(256), 0, s, src, (TD*)dst, rows, cols, mode, taps, scale));
+  ETAINV_DISPATCH_DTYPE(dtype, TD, hipLaunchKernelGGL(pack_weight_kernel<TD>, dim3(cdiv(n, 256)), dim3(256), 0, s, src, (TD*)dst, rows, cols, mode, taps, scale,
+                                                      colscale));
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ln_fold(const float* w_src, const float* gamma, const float* beta, const float* bias_packed, int64_t rows, int64_t cols, int mode, float scale,
+                   void* w_dst, float* s_dst, float* c_dst, int dtype, hipStream_t s) {
+  ETAINV_CHECK(w_src && gamma && beta && w_dst && s_dst && c_dst && rows > 0 && cols > 0, "bad arguments");
+  ETAINV_CHECK(mode == 0 || mode == 2, "plain / GEGLU packing only");
+  if (launch_pack_weight(w_src, w_dst, rows, cols, mode, 1, dtype, s, scale, gamma)) return 1;
+  ETAINV_DISPATCH_HALF(dtype, TD, hipLaunchKernelGGL(ln_fold_vectors_kernel<TD>, dim3(cdiv(rows, 4)), dim3(256), 0, s, w_src, (const TD*)w_dst, beta, bias_packed,
+                                                     rows, cols, mode, scale, s_dst, c_dst));
   ETAINV_LAUNCH_CHECK();
   return 0;
 }

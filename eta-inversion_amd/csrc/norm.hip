@@ -215,6 +215,59 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x,
   }
 }
 
+// Row statistics alone, (mean, rstd) as the LayerNorm-folded GEMMs read them (igemm.hip, IGemmParams::ln_stat): the fallback when the GEMM that
+// wrote x could not emit partials from its epilogue (split-K, ragged wave tiles).
+template <typename T>
+__global__ void __launch_bounds__(256) row_stats_kernel(const T* __restrict__ x, float* __restrict__ stat, int rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nvec = C >> 3;
+  float t[3][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int v = lane + 64 * i;
+    if (v < nvec) {
+      load8(x + (int64_t)row * C + v * 8, t[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += t[i][j];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int v = lane + 64 * i;
+    if (v < nvec) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float d = t[i][j] - mean; sq += d * d; }
+    }
+  }
+  sq = wave_sum(sq);
+  if (lane == 0) {
+    stat[(int64_t)row * 2] = mean;
+    stat[(int64_t)row * 2 + 1] = rsqrtf(sq / (float)C + eps);
+  }
+}
+
+// (mean, M2) partials of equal column counts, written per wave tile by the epilogue of the producing GEMM -> (mean, rstd) per row.  Chan's
+// pairwise update in index order: no E[x^2] - E[x]^2 cancellation, the same result whatever order the producer's blocks ran in.
+__global__ void __launch_bounds__(256) ln_finalize_kernel(const float* __restrict__ part, int P, float cw, float eps, float* __restrict__ stat, int rows) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const float2* pr = reinterpret_cast<const float2*>(part) + (int64_t)row * P;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int q = 0; q < P; ++q) {
+    const float2 v = pr[q];
+    const float nt = n + cw, d = v.x - mean, f = cw / nt;
+    mean += d * f;
+    m2 += v.y + d * d * n * f;
+    n = nt;
+  }
+  reinterpret_cast<float2*>(stat)[row] = make_float2(mean, rsqrtf(m2 / n + eps));
+}
+
 int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float* gamma, const float* beta, void* out, int b,
                      int hw, int groups, float eps, int silu, float* scratch, int dtype, hipStream_t s) {
   const int C = c1 + c2;
@@ -261,6 +314,23 @@ int launch_layernorm(const void* x, const float* gamma, const float* beta, void*
   ETAINV_DISPATCH_HALF(dtype, T,
                        hipLaunchKernelGGL(layernorm_kernel<T>, dim3(cdiv(rows, 4)), dim3(256), 0, s, (const T*)x, gamma, beta,
                                           (T*)out, rows, c, eps));
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_row_stats(const void* x, float* stat, int rows, int c, float eps, int dtype, hipStream_t s) {
+  ETAINV_CHECK(x && stat, "null pointer");
+  ETAINV_CHECK(c % 8 == 0 && (c >> 3) <= 192, "row width must be a multiple of 8 and <= 1536");
+  ProfScope prof(PROF_LAYERNORM, 2.0 * (double)rows * c, s);
+  ETAINV_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL(row_stats_kernel<T>, dim3(cdiv(rows, 4)), dim3(256), 0, s, (const T*)x, stat, rows, c, eps));
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ln_finalize(const float* partials, int P, int cw, float eps, float* stat, int rows, hipStream_t s) {
+  ETAINV_CHECK(partials && stat && P > 0 && cw > 0 && rows > 0, "bad arguments");
+  ProfScope prof(PROF_LAYERNORM, (double)rows * P * 8.0, s);
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, partials, P, (float)cw, eps, stat, rows);
   ETAINV_LAUNCH_CHECK();
   return 0;
 }

@@ -194,6 +194,20 @@ int etainv_prof_split(int cls, double ridge, double* out6, int64_t* launches2);
  * Activations NHWC in the compute dtype; weights in the engine layouts described in DESIGN.md. */
 int etainv_op_gemm(const void* a, const void* w, const void* bias, const void* residual, void* out,
                    int m, int n, int k, int geglu, int dtype, void* stream);
+/* LayerNorm folded into the two GEMMs around it (reference: BasicTransformerBlock norm1/2/3 of [3P] diffusers 0.21.1 attention.py, called from
+ * Transformer2DModel inside `self.unet(...)`, modules/inversion/eta_inversion.py:321).  The GEMM that writes the LayerNorm's input leaves per-row
+ * (mean, M2) partials [m][P][2] in stat_out (*stat_p_out = P, each over n / P columns; 0 = this launch shape emits none: use etainv_op_row_stats);
+ * etainv_op_ln_finalize turns them into stat[m] = (mean, rstd); the GEMM that consumes the LayerNorm runs on the RAW rows with the weights of
+ * etainv_op_ln_fold: out = rstd (a W'^T - mean s) + c.  stat == NULL: a plain GEMM with bias c_vec. */
+int etainv_op_gemm_ln(const void* a, const void* w_folded, const float* c_vec, const float* s_vec, const float* stat,
+                      const void* residual, void* out, float* stat_out, int* stat_p_out, int m, int n, int k, int geglu,
+                      int dtype, void* stream);
+/* W' = gamma . W (packed, compute dtype; geglu: the value / gate row interleave of the GEGLU projection), s = row sums of the rounded W',
+ * c = beta W^T + bias (bias in logical row order, may be NULL) */
+int etainv_op_ln_fold(const float* w, const float* gamma, const float* beta, const float* bias, int n, int k, int geglu, float scale,
+                      void* w_out, float* s_out, float* c_out, int dtype, void* stream);
+int etainv_op_row_stats(const void* x, float* stat, int rows, int c, float eps, int dtype, void* stream);
+int etainv_op_ln_finalize(const float* partials, int p, int cw, float eps, float* stat, int rows, void* stream);
 int etainv_op_conv3x3(const void* x_nhwc, const void* x2_nhwc, int c1, int c2, const void* w_okkc, const void* bias,
                       const float* rowvec, const void* residual, void* out, int b, int h, int wd, int cout,
                       int stride, int upsample, int taps, int dtype, void* stream);

@@ -239,6 +239,84 @@ def test_gemm_geglu_persistent_ring(capi, dtype, m, c):
     assert float(err.max()) < 2 * TOL[dtype]
 
 
+def _ln_pair(capi, dtype, m, c, n_out, geglu, k_prod=None, ragged=0):
+    """producer GEMM (+bias +residual) that leaves the row statistics of its stored output, then the consumer GEMM of LayerNorm(x) on the raw rows
+    with gamma folded into the weights -- against x = stored rows, LayerNorm in fp32, a plain fp32 Linear"""
+    lib = capi.load()
+    dt = capi.dtype_code(dtype)
+    k_prod = k_prod or c
+    m = m + ragged
+    a0, w0 = rnd(m, k_prod, seed=1, dtype=dtype), rnd(c, k_prod, seed=2, scale=k_prod ** -0.5, dtype=dtype)
+    b0 = rnd(c, seed=3) + 0.7                      # a row mean well away from zero
+    r0 = rnd(m, c, seed=4, scale=2.0, dtype=dtype)
+    x = torch.empty(m, c, dtype=dtype, device="cuda")
+    part = torch.full((m * (c // 32) * 2,), float("nan"), dtype=torch.float32, device="cuda")
+    stat = torch.full((m, 2), float("nan"), dtype=torch.float32, device="cuda")
+    sp = C.c_int(-1)
+    capi.check(lib.etainv_op_gemm_ln(capi.ptr(a0), capi.ptr(w0), capi.ptr(b0), None, None, capi.ptr(r0), capi.ptr(x), capi.ptr(part), C.byref(sp),
+                                     m, c, k_prod, 0, dt, capi.stream_ptr()))
+    P = sp.value
+    xr = a0.float() @ w0.float().t() + b0 + r0.float()
+    assert relerr(x, xr) < TOL[dtype]
+    xf = x.float()                                 # statistics are those of the STORED (rounded) rows
+    if P == 0:                                     # this launch shape cannot emit partials: the pass the engine falls back to
+        capi.check(lib.etainv_op_row_stats(capi.ptr(x), capi.ptr(stat), m, c, 1e-5, dt, capi.stream_ptr()))
+    else:
+        st = part[: m * P * 2].view(m, P, 2)
+        assert torch.isfinite(st).all()
+        xs = xf.view(m, P, c // P)
+        torch.testing.assert_close(st[..., 0], xs.mean(-1), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(st[..., 1], ((xs - xs.mean(-1, keepdim=True)) ** 2).sum(-1), rtol=2e-4, atol=1e-3)
+        capi.check(lib.etainv_op_ln_finalize(capi.ptr(part), P, c // P, 1e-5, capi.ptr(stat), m, capi.stream_ptr()))
+    torch.testing.assert_close(stat[:, 0], xf.mean(-1), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(stat[:, 1], (xf.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4, atol=1e-6)
+    # consumer
+    w = rnd(n_out, c, seed=5, scale=c ** -0.5)
+    gamma, beta, bias = 1.0 + 0.3 * rnd(c, seed=6), 0.2 * rnd(c, seed=7), rnd(n_out, seed=8)
+    wp = torch.empty(n_out, c, dtype=dtype, device="cuda")
+    s_vec, c_vec = torch.empty(n_out, device="cuda"), torch.empty(n_out, device="cuda")
+    capi.check(lib.etainv_op_ln_fold(capi.ptr(w), capi.ptr(gamma), capi.ptr(beta), capi.ptr(bias), n_out, c, geglu, 1.0, capi.ptr(wp), capi.ptr(s_vec),
+                                     capi.ptr(c_vec), dt, capi.stream_ptr()))
+    n_store = n_out // 2 if geglu else n_out
+    out = torch.empty(m, n_store, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_gemm_ln(capi.ptr(x), capi.ptr(wp), capi.ptr(c_vec), capi.ptr(s_vec), capi.ptr(stat), None, capi.ptr(out), None, None,
+                                     m, n_out, c, geglu, dt, capi.stream_ptr()))
+    h = F.layer_norm(xf, (c,), gamma, beta, 1e-5) @ w.t() + bias
+    ref = h[:, :n_out // 2] * F.gelu(h[:, n_out // 2:]) if geglu else h
+    assert relerr(out, ref) < TOL[dtype]
+    rows = m // 64 * 64
+    if rows:
+        err = (out.float() - ref)[:rows].reshape(-1, 64, n_store).norm(dim=(1, 2)) / ref[:rows].reshape(-1, 64, n_store).norm(dim=(1, 2))
+        assert float(err.max()) < 2 * TOL[dtype]   # a wrong row group hides in a global norm
+    return sp.value
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,c,n_out,geglu,expect_p", [
+    (32768, 320, 960, 0, 4),        # 256 x 160 ring on both sides (fused QKV of the 64 x 64 level): 4 partials of 80 columns
+    (16384, 640, 640, 0, 8),        # attn2.to_q
+    (32768, 320, 2560, 1, 4),       # GEGLU projection on the 256 x 128 ring
+    (4096, 320, 960, 0, None),      # mid-size tiles (the producer runs 64 x 64 tiles here: 10 partials)
+    (8192, 1280, 1280, 0, 16),      # 16 partials per row
+    (1024, 320, 2560, 1, None),     # GEGLU on 128 x 128 tiles
+    (256, 320, 320, 0, None),       # 64 x 64 tiles
+    (64, 1280, 3840, 0, None),      # producer AND consumer split along K: statistics by the fallback pass, LayerNorm in the reduction kernel
+])
+def test_gemm_layernorm_fold(capi, dtype, m, c, n_out, geglu, expect_p):
+    p = _ln_pair(capi, dtype, m, c, n_out, geglu)
+    if expect_p is not None:
+        assert p == expect_p
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_layernorm_fold_ragged(capi, dtype):
+    """row counts that are not a multiple of the wave tile: general epilogue on the consumer, fallback statistics pass on the producer"""
+    assert _ln_pair(capi, dtype, 4096, 320, 960, 0, ragged=24) == 0
+    assert _ln_pair(capi, dtype, 32768, 320, 960, 0, ragged=40) == 0
+    _ln_pair(capi, dtype, 100, 640, 5120, 1, ragged=0)
+    _ln_pair(capi, dtype, 12, 1280, 1280, 0, ragged=0)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv3x3_persistent_ring(capi, dtype):
     """4 x 64 x 64 x 320 -> 320 (M = 16384, K = 2880, 128 tiles of 256 x 160) and 8 x 32 x 32 x 1280+640 -> 640"""
