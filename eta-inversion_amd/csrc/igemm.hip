@@ -45,6 +45,7 @@ static inline int current_device() {
 }
 constexpr int64_t SPLITK_WS_BYTES = 64ll << 20;
 
+
 // ---- LayerNorm statistics carried between two GEMMs (IGemmParams::stat_out / ln_stat): partial (mean, M2) pairs of equal counts combined by
 // Chan's pairwise update -- no E[x^2] - E[x]^2 cancellation, fixed combination order
 // both sides hold `n` values each
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   // SPLIT-K (two-slot kernels only, small M*N with a deep K: the 8x8 / 16x16 levels at batch 1): every output tile becomes
   // `ksplit` virtual tiles that each walk nk/ksplit K tiles and store an fp32 partial; a second kernel adds the partials in
   // a fixed order and applies the epilogue (deterministic, no float atomics).
-  const int ksplit = (STAGES == 2 && p.ksplit > 1) ? p.ksplit : 1;
+  const int ksplit = (STAGES != 3 && p.ksplit > 1) ? p.ksplit : 1;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int total_tiles = ((p.M + BM - 1) / BM) * tiles_n * ksplit;
   const int G = gridDim.x;
@@ -521,7 +522,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     }
     // general path (ragged tiles, conv_out, fp32 outputs, split-K partials): LayerNorm consumers supported, statistics are never emitted here
     // (the ring kernels take a LayerNorm consumer only when every tile runs the fast path above: launch_igemm)
-    const bool ln_slow = ln_use && STAGES == 2 && ksplit == 1;
+    const bool ln_slow = ln_use && STAGES != 3 && ksplit == 1;
     float lns_mean[MT], lns_rstd[MT];
     if (ln_slow) ln_rows(m0 + wm * WM, lns_mean, lns_rstd);
 #pragma unroll
@@ -637,7 +638,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = Mfma<T>::run(fb[j], fa[i], acc[i][j]);
     }
-    int cls = 0;
+    int cls = -1;   // -1: no epilogue in this step (no stores issued)
     if (++ct_kt == nk) {
       int m0, n0;
       ep_part = tile_origin(ct_tile, m0, n0);
@@ -649,28 +650,66 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   };
 
   setup_issue(0);
-  if constexpr (STAGES == 2) {
-    // DMA of step s+1 in flight during the MFMAs of step s; vmcnt(0) + barrier per K tile
-    issue_tile(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int sidx = 0; sidx < total_steps; ++sidx) {
-      const int cur = sidx & 1;
-      if (sidx + 1 < total_steps) {
-        advance_issue();
-        issue_tile(it_kt, cur ^ 1);
+  if constexpr (STAGES != 3) {
+    // Simple S-slot loop (S = STAGES = 2 or 4).  S = 2: the DMA of step s+1 is in flight during the MFMAs of step s, vmcnt(0) + barrier per K tile --
+    // every K step costs one memory latency (0.62 us), covered only by the other resident blocks.  S = 4 (the 64 x 64 tiles of small launches,
+    // where few blocks are resident: batch 1): three K tiles in flight, COUNTED vmcnt (the wait at the end of step s needs tile s+1 only and
+    // leaves tiles s+2, s+3 -- and the epilogue's stores, youngest in the queue -- in flight), raw s_barrier (__syncthreads drains vmcnt).
+    constexpr int S = STAGES;
+    constexpr int NP = A_LOADS + B_LOADS;   // DMA pieces per wave and K tile (a bias piece at a tile switch only makes a wait cover more)
+    static_assert(S == 2 || BN % RP == 0, "counted waits need the same piece count in every wave");
+    constexpr int S1 = MT * ((NT + 1) / 2), S2 = MT * ((NT / 2 + 1) / 2), S3 = S1 + MT;   // 16-byte stores per wave and tile, per store class
+#define ETAINV_VMCNT_IMM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+    // wait until all but `tiles` K tiles (and the stores of an epilogue of class cls) have landed
+    auto wait_landed = [&](int tiles, int cls) __attribute__((always_inline)) {
+      if (cls == 0) { ETAINV_VMCNT_IMM(0); return; }   // epilogue with an unknown store count
+      const int st = cls == 1 ? S1 : cls == 2 ? S2 : cls == 3 ? S3 : 0;
+      if constexpr (S == 2) {
+        if (st == S1) ETAINV_VMCNT_IMM(S1); else if (st == S2) ETAINV_VMCNT_IMM(S2); else if (st == S3) ETAINV_VMCNT_IMM(S3); else ETAINV_VMCNT_IMM(0);
+      } else {
+        static_assert(S == 2 || (S - 2) * NP + S3 < 64, "vmcnt field");
+#define ETAINV_WAIT_T(T_)                                                                                         \
+        if (st == S1) ETAINV_VMCNT_IMM((T_) * NP + S1); else if (st == S2) ETAINV_VMCNT_IMM((T_) * NP + S2);      \
+        else if (st == S3) ETAINV_VMCNT_IMM((T_) * NP + S3); else ETAINV_VMCNT_IMM((T_) * NP);
+        if (tiles >= 2) { ETAINV_WAIT_T(2) } else if (tiles == 1) { ETAINV_WAIT_T(1) } else { ETAINV_WAIT_T(0) }
+#undef ETAINV_WAIT_T
       }
-      const int cls = compute_stage(cur);
-      // vmcnt counts loads, stores and LDS-DMA together in issue order: the epilogue's stores are younger than the DMA of
-      // step s+1, so they may stay in flight across this wait (their L2 acks are not on the critical path)
-      constexpr int S1 = MT * ((NT + 1) / 2), S2 = MT * ((NT / 2 + 1) / 2);   // 16-byte stores per wave and tile
-      constexpr int S3 = S1 + MT;   // + the row-statistics stores of a LayerNorm producer
-      if (cls == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (S1 & 15) | ((S1 >> 4) << 14));
-      else if (cls == 3) __builtin_amdgcn_s_waitcnt(0x0F70 | (S3 & 15) | ((S3 >> 4) << 14));
-      else if (cls == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (S2 & 15) | ((S2 >> 4) << 14));
-      else __builtin_amdgcn_s_waitcnt(0x0F70);
-      __syncthreads();
+    };
+    auto block_sync = [&]() __attribute__((always_inline)) {
+      if constexpr (S == 2) {
+        __syncthreads();
+      } else {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS reads of the finished slot are done
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    static_assert(S == 2 || S == 4, "slot counts");
+    issue_tile(0, 0);
+    if constexpr (S > 2) {
+#pragma unroll
+      for (int q = 1; q < S - 1; ++q)
+        if (q < total_steps) { advance_issue(); issue_tile(it_kt, q); }
     }
+    wait_landed(total_steps - 1 < S - 2 ? total_steps - 1 : S - 2, -1);
+    block_sync();
+    int slot = 0;
+    for (int sidx = 0; sidx < total_steps; ++sidx) {
+      if (sidx + S - 1 < total_steps) {
+        advance_issue();
+        issue_tile(it_kt, slot == 0 ? S - 1 : slot - 1);   // the slot read in step sidx - 1 (every wave is past that step's barrier)
+      }
+      const int cls = compute_stage(slot);
+      // vmcnt counts loads, stores and LDS-DMA together in issue order: the epilogue's stores are younger than every DMA piece issued so far,
+      // so they may stay in flight across this wait (their L2 acks are not on the critical path)
+      int ahead = total_steps - 2 - sidx;   // K tiles issued beyond tile sidx + 1
+      ahead = ahead < 0 ? 0 : ahead > S - 2 ? S - 2 : ahead;
+      wait_landed(ahead, cls);
+      block_sync();
+      slot = slot + 1 == S ? 0 : slot + 1;
+    }
+#undef ETAINV_VMCNT_IMM
   } else {
     // 3-slot LDS ring, software-pipelined fragments, COUNTED vmcnt, raw s_barrier.  Step s (K tile s of the flattened tile
     // stream, slot s % 3) is two straight-line windows, each one basic block so that the scheduler can place the non-matrix
@@ -963,7 +1002,7 @@ static int launch_igemm_t(const IGemmParams& p_in, hipStream_t s, int* stat_P = 
       if (p.stat_out) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 1>(p, s, nullptr);
     if (p.ln_stat) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 2>(p, s, nullptr);
   }
-  const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN) * (STAGES == 2 && p.ksplit > 1 ? p.ksplit : 1);   // virtual tiles with split-K
+  const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN) * (STAGES != 3 && p.ksplit > 1 ? p.ksplit : 1);   // virtual tiles with split-K
   const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(T) + 4 * BN * sizeof(float) + (STAGES == 3 ? 1024 : 0) +
                      (LN == 2 && STAGES == 3 && BN == 128 ? (size_t)4 * (BN + 2 * BM) * sizeof(float) : 0);   // staged s vectors and (mean, rstd) rows
   static bool attr_set[kMaxDevices] = {};   // per device: function attributes and the allocations below belong to the current device
@@ -1080,7 +1119,8 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
     // fixed-order reduction that applies the epilogue.
     const int cfg = (big && !p.geglu && p.N % 160 == 0) ? 0 : big ? 1 : 2;
     const int bm = cfg == 2 ? 64 : 128, bn = cfg == 0 ? 160 : cfg == 1 ? 128 : 64;
-    const int slots = cfg == 2 ? 1024 : 512;                       // resident blocks: 4 (64 x 64) or 2 per CU
+    // resident blocks with two LDS slots: 64 x 64 tiles 4 per CU, the others 2 per CU
+    const int slots = cfg == 2 ? 1024 : 512;
     const int64_t tiles = (int64_t)cdiv(p.M, bm) * cdiv(p.N, bn);
     const int nk = p.taps * (p.c1 + p.c2) / BK;
     int ks = 1;
@@ -1106,6 +1146,9 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
     ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s, igemm_algo_bytes(p));
     prof_pause(true);
     int rc = 0;
+    // (four LDS slots with three K tiles in flight -- the S = 4 form of the simple loop -- were measured for these kernels at batch 1: -37 % with
+    // four slots everywhere (half the resident blocks), -1.5 % when only launches whose blocks are all resident anyway took it: a K step of a
+    // lone block is bound by its own LDS-read -> MFMA chain, not by the memory latency)
     ETAINV_DISPATCH_HALF(dtype, T, rc = cfg == 0   ? launch_igemm_t<T, 128, 160, 2, 2, false, 0>(pk, s, stat_P)
                                         : cfg == 1 ? launch_igemm_t<T, 128, 128, 2, 2, false, 0>(pk, s, stat_P)
                                                    : launch_igemm_t<T, 64, 64, 2, 2, false, 0>(pk, s, stat_P));

@@ -81,7 +81,30 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x1,
     }
   }
   __syncthreads();
-  if (threadIdx.x < groups) {
+  if (groups <= 32) {
+    // eight threads per group, each a strided eighth of the group's 4 x cpg values, then a fixed-order butterfly over the eight (consecutive)
+    // lanes.  One thread per group walked 4 x cpg dependent LDS reads: 13 us at 1280 channels, 29 us at 2560 -- invisible when thousands of
+    // blocks overlap, the whole kernel at batch 1.
+    const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    float a = 0.f, c = 0.f;
+    if (g < groups) {
+      for (int w = 0; w < 4; ++w)
+        for (int ch = g * cpg + sub; ch < (g + 1) * cpg; ch += 8) {
+          a += sm[(w * C + ch) * 2 + 0];
+          c += sm[(w * C + ch) * 2 + 1];
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      a += __shfl_xor(a, o);
+      c += __shfl_xor(c, o);
+    }
+    if (g < groups && sub == 0) {
+      float* p = partial + (((int64_t)b * chunks + blockIdx.x) * groups + g) * 2;
+      p[0] = a;
+      p[1] = c;
+    }
+  } else if (threadIdx.x < groups) {
     const int g = threadIdx.x;
     float a = 0.f, c = 0.f;
     for (int w = 0; w < 4; ++w)
@@ -110,23 +133,37 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x1,
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   // (mean, rstd) of this image's groups from the per-chunk partial sums, in a fixed order (no separate finalize launch: at
   // batch 1 that 64-thread kernel was a 12 us chain of dependent loads, 8.5 % of the run)
-  __shared__ double s_red[4][64][2];
+  __shared__ double s_red[8][64][2];
   __shared__ float st[64 * 2];
   {
+    // thread = (group, one of NS strided slices of the chunks): the loads of a slice are independent and issued together (one thread per group
+    // and wave walked chunks / 4 dependent global loads: 4-7 us in front of every apply block at batch 1)
+    const int NS = groups <= 32 ? 8 : 4;
+    const int g = groups <= 32 ? (threadIdx.x & 31) : lane, slice = groups <= 32 ? (threadIdx.x >> 5) : wid;
     double a = 0.0, c = 0.0;
-    if (lane < groups)
-      for (int k = wid; k < chunks_st; k += 4) {
-        const float* p = partial + (((int64_t)b * chunks_st + k) * groups + lane) * 2;
+    if (g < groups) {
+      f32x2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = slice + u * NS;
+        v[u] = (f32x2){0.f, 0.f};
+        if (k < chunks_st) v[u] = *reinterpret_cast<const f32x2*>(partial + (((int64_t)b * chunks_st + k) * groups + g) * 2);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a += v[u][0]; c += v[u][1]; }
+      for (int k = slice + 8 * NS; k < chunks_st; k += NS) {   // (GN_MAX_CHUNKS = 64: never with 8 slices)
+        const float* p = partial + (((int64_t)b * chunks_st + k) * groups + g) * 2;
         a += p[0];
         c += p[1];
       }
-    s_red[wid][lane][0] = a;
-    s_red[wid][lane][1] = c;
+      s_red[slice][g][0] = a;
+      s_red[slice][g][1] = c;
+    }
     __syncthreads();
     if (threadIdx.x < groups) {
       const int g = threadIdx.x;
-      const double sa = ((s_red[0][g][0] + s_red[1][g][0]) + s_red[2][g][0]) + s_red[3][g][0];
-      const double sq = ((s_red[0][g][1] + s_red[1][g][1]) + s_red[2][g][1]) + s_red[3][g][1];
+      double sa = 0.0, sq = 0.0;
+      for (int w = 0; w < NS; ++w) { sa += s_red[w][g][0]; sq += s_red[w][g][1]; }
       const double mean = sa / count;
       double var = sq / count - mean * mean;
       if (var < 0.0) var = 0.0;
