@@ -211,8 +211,9 @@ def main():
     # fabric-side bytes per igemm launch: a PMC figure (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/unet_call.py
     # --rows 128, FETCH_SIZE x2 per MI355X_MICROARCH.md, aggregated by tools/pmc_traffic.py), NOT measured by this run: the file is named
     # in the JSON and belongs to the kernels of the round it was taken in
+    # (taken at 128 UNet rows = the default workload; null for the other configurations, whose launches have other sizes)
     traffic, traffic_src = None, None
-    for cand in sorted((ROOT / "profiles").glob("r*_pmc_traffic_rows128.json"), reverse=True):
+    for cand in (sorted((ROOT / "profiles").glob("r*_pmc_traffic_rows128.json"), reverse=True) if 4 * B == 128 else []):
         traffic, traffic_src = json.load(open(cand))["igemm"]["hbm_bytes_per_launch"], f"profiles/{cand.name} (one 128-row UNet call)"
         break
     images = B * world * a.steps

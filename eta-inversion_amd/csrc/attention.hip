@@ -365,7 +365,14 @@ template <int D> struct A32 {
   static constexpr int KV = 64;                              // keys per tile
   static constexpr int KS = (D + 8 + 15) / 16;               // K = 16 steps of S^T = K Q^T, pad chunk included (40 -> 3, 80 -> 6)
   static constexpr int KROW = (2 * KS + 1) * 8;              // K row in elements: an ODD number of 16-byte chunks (7 / 13): conflict-free ds_read_b128
-  static constexpr int VROW = (D + 8 + 15) / 16 * 16;        // V row: D dims + pad chunk, rounded to 16 (48 / 96)
+  // V row in elements: D dims + pad chunk, rounded up to a stride of 64 bytes times an odd number -- the transposed reads of a 32-lane half
+  // touch 64 bytes (two 16-dim groups) of 4 consecutive rows, and only such strides put those four segments on different banks (48 elements =
+  // 96 bytes wrapped the fourth row onto the first: PMC 37 % of the kernel's LDS cycles were bank conflicts); 96 / 96
+#ifndef ETAINV_A40_VROW_PLAIN
+  static constexpr int VROW = ((D + 8 + 31) / 32 | 1) * 32;
+#else
+  static constexpr int VROW = (D + 8 + 15) / 16 * 16;
+#endif
   static constexpr int DT = (D + 1 + 31) / 32;               // 32-row tiles of O^T incl. the denominator row D (2 / 3)
   static constexpr bool ZBUF = DT * 32 > VROW;               // V^T rows past VROW are read from an all-zero image (D = 40: rows 48 .. 63)
   static constexpr int KBUF = KV * KROW, VBUF = KV * VROW;

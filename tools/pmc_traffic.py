@@ -12,7 +12,7 @@ for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
         cls = "igemm" if "igemm_kernel" in k else "self_attn" if "self_attn" in k else "cross_attn" if "cross_attn" in k else \
-              "groupnorm" if "gn_" in k else "layernorm" if "layernorm" in k else "other"
+              "groupnorm" if "gn_" in k else "layernorm" if ("layernorm" in k or "ln_finalize" in k or "row_stats" in k) else "other"
         agg[cls][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[cls][r["Counter_Name"]] += 1
 out = {}
