@@ -121,6 +121,12 @@ struct etainv_engine {
   size_t maps_bytes = 0;
   // norm1/2/3 of the transformer blocks folded into the GEMMs around them (no LayerNorm pass over HBM); ETAINV_LN_UNFUSED=1 keeps the
   // standalone LayerNorm kernel (A/B switch, read at engine creation)
+  // GroupNorm statistics from the epilogue of the GEMM / conv that wrote the tensor (per-channel partials per wave-tile row block, one buffer per
+  // activation buffer a GroupNorm can read: skip[0..11], tmp[0..2], h1) instead of a statistics pass over it; ETAINV_GN_UNFUSED=1 keeps the pass
+  void* gn_bufs[16] = {};
+  float* gn_part[16] = {};
+  float* gn_final = nullptr;
+  bool gn_fused = true;
   bool ln_fused = true;
   bool ln_folded = false;   // the gamma-scaled consumer weights are packed (redone after any set_weight)
   hipStream_t upload_stream = nullptr;   // stream of the last set_weight (the fold waits for it when the forward runs on another one)
@@ -376,12 +382,20 @@ int build_workspace(etainv_engine* e) {
   // LayerNorm partials [M][P][2]: P = C / (wave tile columns) <= C / 32, M * C <= B * hmax on every level
   want(reinterpret_cast<void**>(&e->lnstat), B * hmax / 32 * 2 * 4);
   want(reinterpret_cast<void**>(&e->lnfinal), B * hw[0] * 2 * 4);   // (mean, rstd) per token row
+  // GroupNorm partials: [rows / wm][2][C] floats with wm >= 32 rows per block -> elements / 16 floats per tensor
+  for (int i = 0; i < 12; ++i) want(reinterpret_cast<void**>(&e->gn_part[i]), B * skip_el[i] / 16 * 4);
+  for (int i = 0; i < 3; ++i) want(reinterpret_cast<void**>(&e->gn_part[12 + i]), B * hw[0] * 640 / 16 * 4);
+  want(reinterpret_cast<void**>(&e->gn_part[15]), B * hmax / 16 * 4);
+  want(reinterpret_cast<void**>(&e->gn_final), B * etainv_engine::kGroups * 2 * 4);
   const size_t res = L / 4;
   e->maps_bytes = (size_t)5 * e->max_img * 2 * etainv_engine::kHeads * res * res * 77 * 4;
   want(reinterpret_cast<void**>(&e->maps_acc), e->maps_bytes);
   e->wsbytes = plan.off;
   ETAINV_HIP(hipMalloc(reinterpret_cast<void**>(&e->wsarena), e->wsbytes));
   for (auto& f : fix) f(e->wsarena);
+  for (int i = 0; i < 12; ++i) e->gn_bufs[i] = e->skip[i];
+  for (int i = 0; i < 3; ++i) e->gn_bufs[12 + i] = e->tmp[i];
+  e->gn_bufs[15] = e->h1;
   ETAINV_HIP(hipMemset(e->maps_acc, 0, e->maps_bytes));
   return 0;
 }
@@ -394,11 +408,41 @@ struct Fwd {
   const etainv_attn_ctrl* ctrl;
   int tblock_idx = 0;
 
+  // rows per GroupNorm partial block of the tensor now in each tracked buffer (0: no partials -- the GroupNorm runs its statistics pass)
+  int part_wm[16] = {};
+  int part_of(const void* buf) const {
+    for (int i = 0; i < 16; ++i)
+      if (e->gn_bufs[i] == buf) return i;
+    return -1;
+  }
+  // launch + bookkeeping: gn_out asks the epilogue for the GroupNorm partials of p.out (when the launch shape can: launch_igemm reports the rows
+  // per block, 0 otherwise)
+  int run(IGemmParams& p, bool gn_out) {
+    const int idx = part_of(p.out);
+    int wm = 0;
+    if (gn_out && e->gn_fused && idx >= 0) {
+      p.stat_out = e->gn_part[idx];
+      p.stat_kind = 1;
+      if (launch_igemm(p, e->dt, s, &wm)) return 1;
+    } else if (launch_igemm(p, e->dt, s)) {
+      return 1;
+    }
+    if (idx >= 0) part_wm[idx] = wm;
+    return 0;
+  }
+  int groupnorm(const void* x1, const void* x2, int c1, int c2, const Norm& nm, int hw, float eps, int silu) {
+    const int i1 = part_of(x1), i2 = x2 ? part_of(x2) : -1;
+    const int w1 = i1 >= 0 ? part_wm[i1] : 0, w2 = i2 >= 0 ? part_wm[i2] : 0;
+    if (w1 > 0 && hw % w1 == 0 && (!x2 || (w2 > 0 && hw % w2 == 0)))
+      return launch_groupnorm_pre(x1, x2, c1, c2, e->gn_part[i1], w1, x2 ? e->gn_part[i2] : nullptr, w2, nm.g, nm.b, e->gnbuf, rows, hw,
+                                  etainv_engine::kGroups, eps, silu, e->gn_final, e->dt, s);
+    return launch_groupnorm(x1, x2, c1, c2, nm.g, nm.b, e->gnbuf, rows, hw, etainv_engine::kGroups, eps, silu, e->gn_scratch, e->dt, s);
+  }
   struct LnIn { const float* s; const float* c; };   // folded LayerNorm of the input rows ((mean, rstd) per row in e->lnfinal)
   // ln_out: this GEMM writes the input of a LayerNorm -- leave (mean, rstd) of its output rows in e->lnfinal (partials from the epilogue when
   // the launch can, combined by a small pass; else a pass over the output)
   int gemm(const void* a, const Lin& l, void* out, int M, const void* residual = nullptr, int geglu = 0, const void* a2 = nullptr,
-           int c1 = 0, int c2 = 0, bool ln_out = false, const LnIn* ln = nullptr) {
+           int c1 = 0, int c2 = 0, bool ln_out = false, const LnIn* ln = nullptr, bool gn_out = false) {
     IGemmParams p;
     p.a1 = a;
     p.a2 = a2;
@@ -422,14 +466,14 @@ struct Fwd {
       p.ln_stat = e->lnfinal;
       p.ln_s = ln->s;
     }
-    if (!ln_out) return launch_igemm(p, e->dt, s);
+    if (!ln_out) return run(p, gn_out);
     p.stat_out = e->lnstat;
     int P = 0;
     if (launch_igemm(p, e->dt, s, &P)) return 1;
     if (P == 0) return launch_row_stats(out, e->lnfinal, M, l.n, 1e-5f, e->dt, s);
     return launch_ln_finalize(e->lnstat, P, l.n / P, 1e-5f, e->lnfinal, M, s);
   }
-  int conv(const void* a, const Lin& l, void* out, int H, int W, int stride, int ups, const float* rowvec, const void* residual) {
+  int conv(const void* a, const Lin& l, void* out, int H, int W, int stride, int ups, const float* rowvec, const void* residual, bool gn_out = true) {
     IGemmParams p;
     p.a1 = a;
     p.w = l.w;
@@ -449,14 +493,14 @@ struct Fwd {
     p.M = rows * p.Ho * p.Wo;
     p.N = l.n;
     p.rows_per_batch = p.Ho * p.Wo;
-    return launch_igemm(p, e->dt, s);
+    return run(p, gn_out);
   }
   // x = cat[x1 (c1), x2 (c2)] -> out
   int resblock(const ResBlock& r, const void* x1, const void* x2, int c1, int c2, int side, void* out) {
     const int hw = side * side;
-    if (launch_groupnorm(x1, x2, c1, c2, r.n1.g, r.n1.b, e->gnbuf, rows, hw, etainv_engine::kGroups, 1e-5f, 1, e->gn_scratch, e->dt, s)) return 1;
+    if (groupnorm(x1, x2, c1, c2, r.n1, hw, 1e-5f, 1)) return 1;
     if (conv(e->gnbuf, r.conv1, e->h1, side, side, 1, 0, e->tprojbuf + r.tproj_off, nullptr)) return 1;
-    if (launch_groupnorm(e->h1, nullptr, r.cout, 0, r.n2.g, r.n2.b, e->gnbuf, rows, hw, etainv_engine::kGroups, 1e-5f, 1, e->gn_scratch, e->dt, s)) return 1;
+    if (groupnorm(e->h1, nullptr, r.cout, 0, r.n2, hw, 1e-5f, 1)) return 1;
     const void* residual = x1;
     if (r.shortcut.w) {
       if (gemm(x1, r.shortcut, e->scbuf, rows * hw, nullptr, 0, x2, c1, c2)) return 1;
@@ -467,7 +511,7 @@ struct Fwd {
   int transformer(const TBlock& t, const void* x, int side, void* out) {
     const int hw = side * side, M = rows * hw, c = t.c, d = c / etainv_engine::kHeads;
     const int blk = tblock_idx++;
-    if (launch_groupnorm(x, nullptr, c, 0, t.gn.g, t.gn.b, e->gnbuf, rows, hw, etainv_engine::kGroups, 1e-6f, 0, e->gn_scratch, e->dt, s)) return 1;
+    if (groupnorm(x, nullptr, c, 0, t.gn, hw, 1e-6f, 0)) return 1;
     const bool fold = e->ln_fused;
     if (gemm(e->gnbuf, t.proj_in, e->hsA, M, nullptr, 0, nullptr, 0, 0, fold)) return 1;
     // self-attention
@@ -532,7 +576,7 @@ struct Fwd {
       if (gemm(e->lnbuf, t.ff1, e->ffbuf, M, nullptr, 1)) return 1;
     }
     if (gemm(e->ffbuf, t.ff2, e->hsB, M, e->hsA)) return 1;
-    return gemm(e->hsB, t.proj_out, out, M, x);
+    return gemm(e->hsB, t.proj_out, out, M, x, 0, nullptr, 0, 0, false, nullptr, /*gn_out=*/true);
   }
 };
 
@@ -563,6 +607,7 @@ extern "C" int etainv_engine_create(const etainv_engine_config* cfg, etainv_engi
   e->maxB = cfg->max_unet_batch;
   e->max_img = cfg->max_img;
   e->ln_fused = !getenv("ETAINV_LN_UNFUSED");
+  e->gn_fused = !getenv("ETAINV_GN_UNFUSED");
   if (build_model(e) || build_workspace(e)) {
     etainv_engine_destroy(e);
     return 1;
@@ -686,7 +731,7 @@ extern "C" int etainv_unet_forward(etainv_engine_t* e, const void* latent, int n
     cin_l.b = e->conv_in_b;
     cin_l.n = etainv_engine::kCh0;
     cin_l.k = 64;
-    if (f.gemm(e->gnbuf, cin_l, e->skip[0], n_rows * L * L)) return 1;
+    if (f.gemm(e->gnbuf, cin_l, e->skip[0], n_rows * L * L, nullptr, 0, nullptr, 0, 0, false, nullptr, /*gn_out=*/true)) return 1;
   }
   const int ch[4] = {320, 640, 1280, 1280};
   int ri = 0, ti = 0, si = 1, side = L;
@@ -749,9 +794,7 @@ extern "C" int etainv_unet_forward(etainv_engine_t* e, const void* latent, int n
     }
   }
   // ---- out
-  if (launch_groupnorm(h, nullptr, 320, 0, e->norm_out.g, e->norm_out.b, e->gnbuf, n_rows, L * L, etainv_engine::kGroups, 1e-5f, 1,
-                       e->gn_scratch, e->dt, s))
-    return 1;
+  if (f.groupnorm(h, nullptr, 320, 0, e->norm_out, L * L, 1e-5f, 1)) return 1;
   {
     IGemmParams p;
     p.a1 = e->gnbuf;
@@ -904,6 +947,32 @@ extern "C" int etainv_op_gemm_ln(const void* a, const void* w_folded, const floa
   }
   p.stat_out = stat_out;
   return launch_igemm(p, dtype, (hipStream_t)stream, stat_p_out);
+}
+
+extern "C" int etainv_op_gemm_gnstat(const void* a, const void* w, const float* bias, const void* residual, void* out, float* part, int* wm_out, int m,
+                                     int n, int k, int rows_per_image, int dtype, void* stream) {
+  IGemmParams p;
+  p.a1 = a;
+  p.w = w;
+  p.bias = bias;
+  p.residual = residual;
+  p.out = out;
+  p.M = m;
+  p.N = n;
+  p.c1 = k;
+  p.W = m;
+  p.Wo = m;
+  p.rows_per_batch = rows_per_image;
+  p.stat_out = part;
+  p.stat_kind = 1;
+  return launch_igemm(p, dtype, (hipStream_t)stream, wm_out);
+}
+
+extern "C" int etainv_op_groupnorm_pre(const void* x1, const void* x2, int c1, int c2, const float* part1, int wm1, const float* part2, int wm2,
+                                       const float* gamma, const float* beta, void* out, int b, int hw, int groups, float eps, int silu,
+                                       float* final_stats, int dtype, void* stream) {
+  return launch_groupnorm_pre(x1, x2, c1, c2, part1, wm1, part2, wm2, gamma, beta, out, b, hw, groups, eps, silu, final_stats, dtype,
+                              (hipStream_t)stream);
 }
 
 extern "C" int etainv_op_ln_fold(const float* w, const float* gamma, const float* beta, const float* bias, int n, int k, int geglu, float scale,

@@ -74,13 +74,24 @@ __device__ __forceinline__ void chan_merge_fq_equal(float n, float& mean, float&
   chan_merge_equal(2.f * n, mean, m2, mb, qb);
 }
 
+// sum over the 16 lanes of a DPP row (lane & 15): butterflies xor 1, xor 2 (quad_perm), i <-> 7 - i (row_half_mirror), i <-> 15 - i (row_mirror);
+// every lane ends with the total
+__device__ __forceinline__ float row_sum16(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true));
+  return x;
+}
+
 // LN: the folded-LayerNorm role of the launch as a compile-time constant -- the ring kernels sit exactly at 256 VGPRs, and a role read at
 // run time makes the register allocator keep all three epilogues' values apart (0 = none, 1 = producer: row statistics from the epilogue,
-// 2 = consumer: rstd (acc - mean s) + c)
+// 2 = consumer: rstd (acc - mean s) + c, 3 = GroupNorm producer: per-channel (sum, sum of squares) of the stored values over the rows of each wave tile)
 template <typename T, int BM, int BN, int WAVES_M, int STAGES, bool UPS = false, int LN = 0>
 __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) {
   constexpr bool ln_emit = LN == 1;
   constexpr bool ln_use = LN == 2;
+  constexpr bool gn_emit = LN == 3;
   constexpr int NTHR = WAVES_M * 128;      // WAVES_M x 2 waves
   constexpr int RP = NTHR / 8;             // LDS rows staged per pass (8 lanes x 16 B per 128-B row)
   constexpr int WM = BM / WAVES_M, WN = BN / 2;  // wave tile
@@ -452,6 +463,45 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
 #pragma unroll
           for (int i = 0; i < MT; ++i) emit_row_stat(po[i], mw + i * 16 + fr, n0 / WN + wn);
         }
+        if (gn_emit) {
+          // GroupNorm producer: the GroupNorm that reads this output needs sum and sum of squares per (image, group).  Per wave tile (WM rows of one
+          // image x WN channels) and channel: this lane's MT rows, then the 16 pixel lanes of the DPP row -> stat_out[row tile][0 / 1][channel]
+          // (fixed order: deterministic); norm.hip gn_finalize_kernel adds row tiles and channels of a group.  Replaces the statistics pass over x.
+          float* gs = ln_args()->stat_out;
+          const int64_t rt = mw / WM;
+          if (m0 + BM > p.M) {   // (wave-uniform) ragged last M tile: rows past M count as zero
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+              if (mw + i * 16 + fr >= p.M)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) po[i][j] = (u32x2){0u, 0u};
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            f32x4 sm = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+              T o[4];
+              *reinterpret_cast<u32x2*>(o) = po[i][j];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float v = to_f32(o[q]);
+                sm[q] += v;
+                sq[q] += v * v;
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              sm[q] = row_sum16(sm[q]);
+              sq[q] = row_sum16(sq[q]);
+            }
+            const int n = n0 + wn * WN + j * 16 + fq * 4;
+            if (fr == 0 && n < p.N) {
+              *reinterpret_cast<f32x4*>(gs + (rt * 2 + 0) * p.N + n) = sm;
+              *reinterpret_cast<f32x4*>(gs + (rt * 2 + 1) * p.N + n) = sq;
+            }
+          }
+        }
         }
       } else {
         const int No = p.N >> 1;
@@ -518,7 +568,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         }
       }
       const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N) && !(p.debug & 16);   // every lane of every wave stored
-      return full ? (p.geglu ? 2 : ln_emit ? 3 : 1) : 0;   // (full implies wide)
+      return full ? (p.geglu ? 2 : ln_emit ? 3 : gn_emit ? 4 : 1) : 0;   // (full implies wide)
     }
     // general path (ragged tiles, conv_out, fp32 outputs, split-K partials): LayerNorm consumers supported, statistics are never emitted here
     // (the ring kernels take a LayerNorm consumer only when every tile runs the fast path above: launch_igemm)
@@ -658,19 +708,20 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     constexpr int S = STAGES;
     constexpr int NP = A_LOADS + B_LOADS;   // DMA pieces per wave and K tile (a bias piece at a tile switch only makes a wait cover more)
     static_assert(S == 2 || BN % RP == 0, "counted waits need the same piece count in every wave");
-    constexpr int S1 = MT * ((NT + 1) / 2), S2 = MT * ((NT / 2 + 1) / 2), S3 = S1 + MT;   // 16-byte stores per wave and tile, per store class
+    constexpr int S1 = MT * ((NT + 1) / 2), S2 = MT * ((NT / 2 + 1) / 2), S3 = S1 + MT, S4 = S1 + 2 * NT;   // stores per wave and tile, per store class
 #define ETAINV_VMCNT_IMM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
     // wait until all but `tiles` K tiles (and the stores of an epilogue of class cls) have landed
     auto wait_landed = [&](int tiles, int cls) __attribute__((always_inline)) {
       if (cls == 0) { ETAINV_VMCNT_IMM(0); return; }   // epilogue with an unknown store count
-      const int st = cls == 1 ? S1 : cls == 2 ? S2 : cls == 3 ? S3 : 0;
+      const int st = cls == 1 ? S1 : cls == 2 ? S2 : cls == 3 ? S3 : cls == 4 ? S4 : 0;
       if constexpr (S == 2) {
-        if (st == S1) ETAINV_VMCNT_IMM(S1); else if (st == S2) ETAINV_VMCNT_IMM(S2); else if (st == S3) ETAINV_VMCNT_IMM(S3); else ETAINV_VMCNT_IMM(0);
+        if (st == S1) ETAINV_VMCNT_IMM(S1); else if (st == S2) ETAINV_VMCNT_IMM(S2); else if (st == S3) ETAINV_VMCNT_IMM(S3);
+        else if (st == S4) ETAINV_VMCNT_IMM(S4); else ETAINV_VMCNT_IMM(0);
       } else {
-        static_assert(S == 2 || (S - 2) * NP + S3 < 64, "vmcnt field");
+        static_assert(S == 2 || (S - 2) * NP + S4 < 64, "vmcnt field");
 #define ETAINV_WAIT_T(T_)                                                                                         \
         if (st == S1) ETAINV_VMCNT_IMM((T_) * NP + S1); else if (st == S2) ETAINV_VMCNT_IMM((T_) * NP + S2);      \
-        else if (st == S3) ETAINV_VMCNT_IMM((T_) * NP + S3); else ETAINV_VMCNT_IMM((T_) * NP);
+        else if (st == S3) ETAINV_VMCNT_IMM((T_) * NP + S3); else if (st == S4) ETAINV_VMCNT_IMM((T_) * NP + S4); else ETAINV_VMCNT_IMM((T_) * NP);
         if (tiles >= 2) { ETAINV_WAIT_T(2) } else if (tiles == 1) { ETAINV_WAIT_T(1) } else { ETAINV_WAIT_T(0) }
 #undef ETAINV_WAIT_T
       }
@@ -834,6 +885,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       constexpr int S1 = MT * ((NT + 1) / 2), S2 = MT * ((NT / 2 + 1) / 2);
       if (young == 1) ETAINV_VMCNT(N1 + S1);
       else if (young == 3) ETAINV_VMCNT(N1 + S1 + MT);   // + the row-statistics stores of a LayerNorm producer
+      else if (young == 4) ETAINV_VMCNT(N1 + S1 + 2 * NT);   // + the channel-statistics stores of a GroupNorm producer
       else if (young == 2) ETAINV_VMCNT(N1 + S2);
       else ETAINV_VMCNT(N1);
     };
@@ -987,20 +1039,26 @@ static double igemm_algo_bytes(const IGemmParams& p) {
 template <typename T, int BM, int BN, int WAVES_M, int STAGES = 2, bool UPS = false, int LN = 0>
 static int launch_igemm_t(const IGemmParams& p_in, hipStream_t s, int* stat_P = nullptr) {
   IGemmParams p = p_in;
-  // LayerNorm producer: the fast epilogue (whole wave tiles inside one image and inside N) writes one (mean, M2) partial per row and wave
-  // tile column; anything else reports 0 partials and the caller computes the statistics with launch_row_stats
+  // Statistics producers: the fast epilogue (whole wave tiles inside one image and inside N) writes, for a LayerNorm (stat_kind 0), one (mean, M2)
+  // partial per row and wave-tile column, for a GroupNorm (stat_kind 1) per-channel sums per wave-tile row block; anything else reports 0 and the
+  // caller runs the statistics pass over the output.  *stat_P: partials per row (kind 0) / rows per partial (kind 1).
   constexpr int WM_ = BM / WAVES_M, WN_ = BN / 2;
-  if (p.stat_out && !(STAGES == 3 && UPS) && !p.geglu && !p.out_nchw && !p.out_f32 && p.ksplit <= 1 && p.rows_per_batch % WM_ == 0 && p.N % WN_ == 0 && p.N % 16 == 0) {
-    p.stat_P = p.N / WN_;
+  if (p.stat_out && !(STAGES == 3 && UPS && p.stat_kind == 0) && !p.geglu && !p.out_nchw && !p.out_f32 && p.ksplit <= 1 && p.rows_per_batch % WM_ == 0 &&
+      p.N % WN_ == 0 && p.N % 16 == 0) {
+    p.stat_P = p.stat_kind == 0 ? p.N / WN_ : WM_;
   } else {
     p.stat_out = nullptr;
     p.stat_P = 0;
   }
   if (stat_P) *stat_P = p.stat_P;
-  if constexpr (!UPS && LN == 0) {   // one instantiation per LayerNorm role (the 256 x 128 ring only runs GEGLU: never a producer)
-    if constexpr (!(STAGES == 3 && BN == 128))
-      if (p.stat_out) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 1>(p, s, nullptr);
-    if (p.ln_stat) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 2>(p, s, nullptr);
+  if constexpr (LN == 0) {   // one instantiation per role (the 256 x 128 ring only runs GEGLU: never a producer; fused upsample: GroupNorm producer only)
+    if constexpr (!(STAGES == 3 && BN == 128)) {
+      if constexpr (!UPS)
+        if (p.stat_out && p.stat_kind == 0) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 1>(p, s, nullptr);
+      if (p.stat_out && p.stat_kind == 1) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 3>(p, s, nullptr);
+    }
+    if constexpr (!UPS)
+      if (p.ln_stat) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 2>(p, s, nullptr);
   }
   const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN) * (STAGES != 3 && p.ksplit > 1 ? p.ksplit : 1);   // virtual tiles with split-K
   const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(T) + 4 * BN * sizeof(float) + (STAGES == 3 ? 1024 : 0) +

@@ -39,6 +39,9 @@ struct IGemmParams {
   // tile per chunk) and reported through its stat_P argument; 0 = this launch could not emit them (the caller runs launch_row_stats).
   float* stat_out = nullptr;
   int stat_P = 0;
+  // stat_kind 1: GroupNorm producer instead -- stat_out[row block][2][N]: per channel, the sum and the sum of squares of the stored output over the
+  // rows of each wave tile (stat_P = rows per block, reported by launch_igemm); launch_groupnorm_pre consumes them
+  int stat_kind = 0;
   // Consumer side (K = LayerNorm width, weights pre-multiplied by gamma: launch_ln_fold): out = rstd[m] * (acc - mean[m] * ln_s[n]) + bias[n],
   // bias = the folded c vector; ln_stat = (mean, rstd) per row, [M][2] (launch_ln_finalize of the producer's partials, or launch_row_stats).
   const float* ln_stat = nullptr;
@@ -53,6 +56,10 @@ int launch_igemm(const IGemmParams& p, int dtype, hipStream_t s, int* stat_P = n
 constexpr int GN_MAX_CHUNKS = 64;
 int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float* gamma, const float* beta, void* out,
                      int b, int hw, int groups, float eps, int silu, float* scratch, int dtype, hipStream_t s);
+// GroupNorm whose statistics arrive as per-channel partials from the epilogues of the GEMMs that wrote x1 / x2 (IGemmParams::stat_kind 1; part =
+// [b * hw / wm][2][c] floats): a finalize launch (sums in double, fixed order) -> final[b][groups] (mean, rstd), then the apply pass of launch_groupnorm
+int launch_groupnorm_pre(const void* x1, const void* x2, int c1, int c2, const float* part1, int wm1, const float* part2, int wm2, const float* gamma,
+                         const float* beta, void* out, int b, int hw, int groups, float eps, int silu, float* final_stats, int dtype, hipStream_t s);
 int launch_layernorm(const void* x, const float* gamma, const float* beta, void* out, int rows, int c, float eps, int dtype,
                      hipStream_t s);
 // stat[row] = (mean, rstd) of x[row][0..c): IGemmParams::ln_stat computed by a pass over x (when the producing GEMM could not emit partials)

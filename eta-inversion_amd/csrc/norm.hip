@@ -135,7 +135,13 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x1,
   // batch 1 that 64-thread kernel was a 12 us chain of dependent loads, 8.5 % of the run)
   __shared__ double s_red[8][64][2];
   __shared__ float st[64 * 2];
-  {
+  if (chunks_st == 0) {   // `partial` already holds (mean, rstd) per (image, group): gn_finalize_kernel
+    if (threadIdx.x < groups) {
+      st[threadIdx.x * 2 + 0] = partial[((int64_t)b * groups + threadIdx.x) * 2 + 0];
+      st[threadIdx.x * 2 + 1] = partial[((int64_t)b * groups + threadIdx.x) * 2 + 1];
+    }
+    __syncthreads();
+  } else {
     // thread = (group, one of NS strided slices of the chunks): the loads of a slice are independent and issued together (one thread per group
     // and wave walked chunks / 4 dependent global loads: 4-7 us in front of every apply block at batch 1)
     const int NS = groups <= 32 ? 8 : 4;
@@ -305,6 +311,49 @@ __global__ void __launch_bounds__(256) ln_finalize_kernel(const float* __restric
   reinterpret_cast<float2*>(stat)[row] = make_float2(mean, rsqrtf(m2 / n + eps));
 }
 
+// Per-channel (sum, sum of squares) partials written by the epilogues of the GEMMs that produced x1 (c1 channels) and, for the decoder's concat,
+// x2 (c2 channels) -- part[row block][2][c], row blocks of wm pixels, hw / wm of them per image -> final[b][group] = (mean, rstd).
+// One wave per (image, group): the 64 lanes take strided (row block, channel) pairs, sums in double, fixed order (a block per image walked
+// 320 dependent loads per thread at batch 1: slower than the statistics pass it replaces).
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ part1, int wm1, int c1, const float* __restrict__ part2, int wm2, int c2,
+                                                          int hw, int groups, float eps, float* __restrict__ final_stats) {
+  const int b = blockIdx.y, C = c1 + c2, cpg = C / groups;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (g >= groups) return;
+  double a = 0.0, q = 0.0;
+  // channels of the group that lie in source 1 / source 2 (a group may straddle the concat boundary)
+  const int lo = g * cpg, hi = lo + cpg;
+  const int n1 = max(0, min(hi, c1) - lo), nb1 = hw / wm1;
+  for (int idx = lane; idx < n1 * nb1; idx += 64) {
+    const int r = idx / n1, ch = lo + idx - r * n1;
+    const float* base = part1 + ((int64_t)(b * nb1 + r) * 2) * c1 + ch;
+    a += base[0];
+    q += base[c1];
+  }
+  if (c2 > 0) {
+    const int lo2 = max(lo, c1) - c1, n2 = hi - max(lo, c1), nb2 = hw / wm2;
+    for (int idx = lane; idx < n2 * nb2; idx += 64) {
+      const int r = idx / n2, ch = lo2 + idx - r * n2;
+      const float* base = part2 + ((int64_t)(b * nb2 + r) * 2) * c2 + ch;
+      a += base[0];
+      q += base[c2];
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    a += __shfl_xor(a, o);
+    q += __shfl_xor(q, o);
+  }
+  if (lane == 0) {
+    const double count = (double)hw * (double)cpg;
+    const double mean = a / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    final_stats[((int64_t)b * groups + g) * 2 + 0] = (float)mean;
+    final_stats[((int64_t)b * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
 int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float* gamma, const float* beta, void* out, int b,
                      int hw, int groups, float eps, int silu, float* scratch, int dtype, hipStream_t s) {
   const int C = c1 + c2;
@@ -339,6 +388,33 @@ int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float
     default: ETAINV_GN_LAUNCH(5) break;
   });
 #undef ETAINV_GN_LAUNCH
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_groupnorm_pre(const void* x1, const void* x2, int c1, int c2, const float* part1, int wm1, const float* part2, int wm2, const float* gamma,
+                         const float* beta, void* out, int b, int hw, int groups, float eps, int silu, float* final_stats, int dtype, hipStream_t s) {
+  const int C = c1 + c2;
+  ETAINV_CHECK(x1 && gamma && beta && out && part1 && final_stats, "null pointer");
+  ETAINV_CHECK(c1 % 8 == 0 && c2 % 8 == 0 && C % groups == 0 && groups <= 32, "channel layout");
+  ETAINV_CHECK((C >> 3) <= 64 * GN_MAX_VEC_PER_LANE, "C too large");
+  ETAINV_CHECK(c2 == 0 || (x2 && part2), "second source missing");
+  ETAINV_CHECK(wm1 > 0 && hw % wm1 == 0 && (c2 == 0 || (wm2 > 0 && hw % wm2 == 0)), "row blocks must tile an image");
+  ProfScope prof(PROF_GROUPNORM, 2.0 * 2.0 * (double)b * hw * C, s);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((groups + 3) / 4, b), dim3(256), 0, s, part1, wm1, c1, part2, wm2, c2, hw, groups, eps, final_stats);
+  const int chunks_apply = std::max(1, std::min(hw / 4, std::max(std::min(GN_MAX_CHUNKS, std::max(1, std::min(hw / 8, 1024 / std::max(1, b)))), 4096 / std::max(1, b))));
+  const int vpl = ((C >> 3) + 63) / 64;
+#define ETAINV_GN_APPLY(VPL_)                                                                                                              \
+  hipLaunchKernelGGL((gn_apply_kernel<T, VPL_>), dim3(chunks_apply, b), dim3(256), 0, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups,     \
+                     (const float*)final_stats, 0, (float)hw * (float)(C / groups), eps, gamma, beta, silu, (T*)out);
+  ETAINV_DISPATCH_HALF(dtype, T, switch (vpl) {
+    case 1: ETAINV_GN_APPLY(1) break;
+    case 2: ETAINV_GN_APPLY(2) break;
+    case 3: ETAINV_GN_APPLY(3) break;
+    case 4: ETAINV_GN_APPLY(4) break;
+    default: ETAINV_GN_APPLY(5) break;
+  });
+#undef ETAINV_GN_APPLY
   ETAINV_LAUNCH_CHECK();
   return 0;
 }

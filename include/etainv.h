@@ -208,6 +208,15 @@ int etainv_op_ln_fold(const float* w, const float* gamma, const float* beta, con
                       void* w_out, float* s_out, float* c_out, int dtype, void* stream);
 int etainv_op_row_stats(const void* x, float* stat, int rows, int c, float eps, int dtype, void* stream);
 int etainv_op_ln_finalize(const float* partials, int p, int cw, float eps, float* stat, int rows, void* stream);
+/* GroupNorm statistics from the producing GEMM's epilogue (reference: the GroupNorms of [3P] diffusers ResnetBlock2D / Transformer2DModel inside the
+ * UNet call, eta_inversion.py:321): etainv_op_gemm_gnstat = etainv_op_gemm that also leaves per-channel (sum, sum of squares) partials of its stored
+ * output, part[m / wm][2][n] (*wm_out rows per block; 0 = this launch shape emits none); etainv_op_groupnorm_pre = GroupNorm(+SiLU) of cat[x1, x2]
+ * from such partials (no statistics pass over x). */
+int etainv_op_gemm_gnstat(const void* a, const void* w, const float* bias, const void* residual, void* out, float* part, int* wm_out, int m,
+                          int n, int k, int rows_per_image, int dtype, void* stream);
+int etainv_op_groupnorm_pre(const void* x1, const void* x2, int c1, int c2, const float* part1, int wm1, const float* part2, int wm2,
+                            const float* gamma, const float* beta, void* out, int b, int hw, int groups, float eps, int silu,
+                            float* final_stats, int dtype, void* stream);
 int etainv_op_conv3x3(const void* x_nhwc, const void* x2_nhwc, int c1, int c2, const void* w_okkc, const void* bias,
                       const float* rowvec, const void* residual, void* out, int b, int h, int wd, int cout,
                       int stride, int upsample, int taps, int dtype, void* stream);

@@ -438,6 +438,66 @@ def test_groupnorm(capi, dtype, b, hw, c1, c2, silu):
     assert relerr(out, ref.permute(0, 2, 1)) < TOL[dtype]
 
 
+def _gemm_gnstat(capi, dtype, b, hw, c, k, seed, residual):
+    """x = a W^T + bias (+ residual) through the GEMM whose epilogue leaves the per-channel GroupNorm partials of the stored x"""
+    lib = capi.load()
+    m = b * hw
+    a, w = rnd(m, k, seed=seed, dtype=dtype), rnd(c, k, seed=seed + 1, scale=k ** -0.5, dtype=dtype)
+    bias = rnd(c, seed=seed + 2) + 0.4
+    res = rnd(m, c, seed=seed + 3, dtype=dtype) if residual else None
+    x = torch.empty(m, c, dtype=dtype, device="cuda")
+    part = torch.full((m // 32 * 2 * c + 64,), float("nan"), dtype=torch.float32, device="cuda")
+    wm = C.c_int(-1)
+    capi.check(lib.etainv_op_gemm_gnstat(capi.ptr(a), capi.ptr(w), capi.ptr(bias), capi.ptr(res), capi.ptr(x), capi.ptr(part), C.byref(wm), m, c, k, hw,
+                                         capi.dtype_code(dtype), capi.stream_ptr()))
+    ref = a.float() @ w.float().t() + bias + (res.float() if residual else 0)
+    assert relerr(x, ref) < TOL[dtype]
+    if wm.value > 0:       # partials against the sums of the STORED values
+        pv = part[: m // wm.value * 2 * c].view(m // wm.value, 2, c)
+        xs = x.float().view(m // wm.value, wm.value, c)
+        torch.testing.assert_close(pv[:, 0], xs.sum(1), rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(pv[:, 1], (xs * xs).sum(1), rtol=1e-4, atol=1e-3)
+    return x, part, wm.value
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,hw,c1,c2,silu,expect", [
+    (8, 4096, 320, 0, 1, (64, 0)),          # 256 x 160 ring producer, 64-row blocks
+    (4, 1024, 640, 320, 1, None),           # the decoder's concat: two producers (with different tile shapes)
+    (16, 1024, 640, 0, 0, (64, 0)),
+    (2, 256, 1280, 0, 1, None),             # small tiles
+    (1, 64, 1280, 1280, 1, None),
+])
+def test_groupnorm_from_producer_partials(capi, dtype, b, hw, c1, c2, silu, expect):
+    lib = capi.load()
+    x1, p1, w1 = _gemm_gnstat(capi, dtype, b, hw, c1, 320, 10, True)
+    x2, p2, w2 = _gemm_gnstat(capi, dtype, b, hw, c2, 640, 20, False) if c2 else (None, None, 0)
+    if expect is not None:
+        assert (w1, w2) == expect
+    assert w1 > 0 and (not c2 or w2 > 0)
+    C_ = c1 + c2
+    gamma, beta = rnd(C_, seed=2) * 0.1 + 1, rnd(C_, seed=3) * 0.1
+    out = torch.empty(b, hw, C_, dtype=dtype, device="cuda")
+    final = torch.empty(b * 32 * 2, dtype=torch.float32, device="cuda")
+    eps = 1e-5 if silu else 1e-6
+    capi.check(lib.etainv_op_groupnorm_pre(capi.ptr(x1), capi.ptr(x2), c1, c2, capi.ptr(p1), w1, capi.ptr(p2), w2, capi.ptr(gamma), capi.ptr(beta),
+                                           capi.ptr(out), b, hw, 32, eps, silu, capi.ptr(final), capi.dtype_code(dtype), capi.stream_ptr()))
+    x = torch.cat([x1.view(b, hw, c1)] + ([x2.view(b, hw, c2)] if c2 else []), dim=-1).float()
+    ref = F.group_norm(x.permute(0, 2, 1), 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    assert relerr(out, ref.permute(0, 2, 1)) < TOL[dtype]
+    g = x.view(b, hw, 32, C_ // 32).permute(0, 2, 1, 3).reshape(b, 32, -1)
+    torch.testing.assert_close(final.view(b, 32, 2)[..., 0], g.mean(-1), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(final.view(b, 32, 2)[..., 1], (g.var(-1, unbiased=False) + eps).rsqrt(), rtol=1e-4, atol=1e-6)
+
+
+def test_gemm_gnstat_ragged_image_reports_none(capi):
+    """an image whose pixel count is not a multiple of the wave tile: no partials (the engine runs the statistics pass)"""
+    _, _, wm = _gemm_gnstat(capi, torch.float16, 3, 36, 320, 320, 30, True)
+    assert wm == 0
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows,c", [(4096, 320), (1023, 640), (130, 1280)])
 def test_layernorm(capi, dtype, rows, c):
