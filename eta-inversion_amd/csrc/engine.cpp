@@ -58,6 +58,7 @@ struct WeightSlot {
   int dst_dtype = ETAINV_F32;  // F32 or the compute dtype (-1 placeholder replaced at build)
   float scale = 1.0f;          // constant folded into the values in fp32 before the rounding to the compute dtype
   float* stage = nullptr;      // fp32 copy kept instead of packing at once: the consumer of a folded LayerNorm is packed when gamma / beta are known
+  bool stage_and_pack = false; // fp32 copy kept AND packed (proj_in: the per-image GroupNorm fold needs the fp32 values on every call)
   bool set = false;
   int64_t numel() const {
     int64_t n = 1;
@@ -81,7 +82,7 @@ struct TBlock {
   Lin proj_in, qkv, out1, q, kv, out2, ff1, ff2, proj_out;
   // LayerNorm folded into its consumer (norm1 -> fused QKV, norm2 -> attn2.to_q, norm3 -> GEGLU projection): fp32 staging copies of the
   // consumer weights, the row sums s of the packed gamma-scaled operand and c = beta W^T + bias (kernels.h, launch_ln_fold)
-  float *st_qkv = nullptr, *st_q = nullptr, *st_ff1 = nullptr;
+  float *st_qkv = nullptr, *st_q = nullptr, *st_ff1 = nullptr, *st_pin = nullptr;   // st_pin: proj_in, for the per-image GroupNorm fold
   float *s_qkv = nullptr, *c_qkv = nullptr, *s_q = nullptr, *c_q = nullptr, *s_ff1 = nullptr, *c_ff1 = nullptr;
   float q_scale = 1.0f;
 };
@@ -126,7 +127,10 @@ struct etainv_engine {
   void* gn_bufs[16] = {};
   float* gn_part[16] = {};
   float* gn_final = nullptr;
+  void* gn_wb = nullptr;
+  float* gn_cb = nullptr;
   bool gn_fused = true;
+  bool gn_fold = true;   // ... and the transformer's GroupNorm (no activation) folded into proj_in through per-image weights; ETAINV_GN_NOFOLD=1: off
   bool ln_fused = true;
   bool ln_folded = false;   // the gamma-scaled consumer weights are packed (redone after any set_weight)
   hipStream_t upload_stream = nullptr;   // stream of the last set_weight (the fold waits for it when the forward runs on another one)
@@ -172,8 +176,9 @@ struct Builder {
     });
   }
   // the slot keeps an fp32 copy at *holder + off (elements) instead of being packed by set_weight
-  void stage_slot(const std::string& name, float** holder, size_t off) {
+  void stage_slot(const std::string& name, float** holder, size_t off, bool and_pack = false) {
     const int idx = e->slot_by_name.at(name);
+    e->slots[idx].stage_and_pack = and_pack;
     etainv_engine* eng = e;
     fixups.push_back([eng, idx, holder, off](char*) { eng->slots[idx].stage = *holder + off; });
   }
@@ -266,6 +271,10 @@ struct Builder {
     linear(tp + ".ff.net.0.proj", t.ff1, 8 * c, c, true, PK_GEGLU);
     linear(tp + ".ff.net.2", t.ff2, c, 4 * c, true);
     conv1x1(prefix + ".proj_out", t.proj_out, c, c);
+    if (e->gn_fused && c <= 640) {
+      want(&t.st_pin, (size_t)c * c * 4);
+      stage_slot(prefix + ".proj_in.weight", &t.st_pin, 0, /*and_pack=*/true);
+    }
     if (e->ln_fused) {
       const size_t cc = (size_t)c * c;
       want(&t.st_qkv, 3 * cc * 4);
@@ -387,6 +396,8 @@ int build_workspace(etainv_engine* e) {
   for (int i = 0; i < 3; ++i) want(reinterpret_cast<void**>(&e->gn_part[12 + i]), B * hw[0] * 640 / 16 * 4);
   want(reinterpret_cast<void**>(&e->gn_part[15]), B * hmax / 16 * 4);
   want(reinterpret_cast<void**>(&e->gn_final), B * etainv_engine::kGroups * 2 * 4);
+  want(&e->gn_wb, B * 640 * 640 * 2);                                   // per-image proj_in weights of a folded GroupNorm (C <= 640)
+  want(reinterpret_cast<void**>(&e->gn_cb), B * 640 * 4);
   const size_t res = L / 4;
   e->maps_bytes = (size_t)5 * e->max_img * 2 * etainv_engine::kHeads * res * res * 77 * 4;
   want(reinterpret_cast<void**>(&e->maps_acc), e->maps_bytes);
@@ -442,7 +453,7 @@ struct Fwd {
   // ln_out: this GEMM writes the input of a LayerNorm -- leave (mean, rstd) of its output rows in e->lnfinal (partials from the epilogue when
   // the launch can, combined by a small pass; else a pass over the output)
   int gemm(const void* a, const Lin& l, void* out, int M, const void* residual = nullptr, int geglu = 0, const void* a2 = nullptr,
-           int c1 = 0, int c2 = 0, bool ln_out = false, const LnIn* ln = nullptr, bool gn_out = false) {
+           int c1 = 0, int c2 = 0, bool ln_out = false, const LnIn* ln = nullptr, bool gn_out = false, int rows_per_image = 0) {
     IGemmParams p;
     p.a1 = a;
     p.a2 = a2;
@@ -461,6 +472,11 @@ struct Fwd {
     p.taps = 1;
     p.geglu = geglu;
     p.rows_per_batch = M;
+    if (rows_per_image) {   // per-image weights [image][n][k] and bias [image][n]
+      p.rows_per_batch = rows_per_image;
+      p.w_batch_stride = (int64_t)l.n * l.k;
+      p.bias_batch_stride = l.n;
+    }
     if (ln) {
       p.bias = ln->c;
       p.ln_stat = e->lnfinal;
@@ -511,9 +527,24 @@ struct Fwd {
   int transformer(const TBlock& t, const void* x, int side, void* out) {
     const int hw = side * side, M = rows * hw, c = t.c, d = c / etainv_engine::kHeads;
     const int blk = tblock_idx++;
-    if (groupnorm(x, nullptr, c, 0, t.gn, hw, 1e-6f, 0)) return 1;
     const bool fold = e->ln_fused;
-    if (gemm(e->gnbuf, t.proj_in, e->hsA, M, nullptr, 0, nullptr, 0, 0, fold)) return 1;
+    // The GroupNorm in front of proj_in has no activation: with its statistics known from the producer's epilogue it becomes a per-image scaling
+    // of proj_in's input channels + a per-image bias -- folded into per-image copies of the (small) weight matrix instead of a pass over x.
+    // Levels with C <= 640 (C = 1280: the 128 weight copies would cost more than the pass) and images that are whole M tiles.
+    const int ix = part_of(x), wx = ix >= 0 ? part_wm[ix] : 0;
+    if (e->gn_fold && t.st_pin && wx > 0 && hw % wx == 0 && hw % 256 == 0) {
+      if (launch_gn_finalize(c, 0, e->gn_part[ix], wx, nullptr, 0, rows, hw, etainv_engine::kGroups, 1e-6f, e->gn_final, s)) return 1;
+      if (launch_gn_fold(t.st_pin, t.gn.g, t.gn.b, t.proj_in.b, e->gn_final, etainv_engine::kGroups, rows, c, c, e->gn_wb, e->gn_cb, e->dt, s)) return 1;
+      Lin pin;
+      pin.w = e->gn_wb;
+      pin.b = e->gn_cb;
+      pin.n = c;
+      pin.k = c;
+      if (gemm(x, pin, e->hsA, M, nullptr, 0, nullptr, 0, 0, fold, nullptr, false, hw)) return 1;
+    } else {
+      if (groupnorm(x, nullptr, c, 0, t.gn, hw, 1e-6f, 0)) return 1;
+      if (gemm(e->gnbuf, t.proj_in, e->hsA, M, nullptr, 0, nullptr, 0, 0, fold)) return 1;
+    }
     // self-attention
     if (fold) {
       const LnIn ln1{t.s_qkv, t.c_qkv};
@@ -608,6 +639,7 @@ extern "C" int etainv_engine_create(const etainv_engine_config* cfg, etainv_engi
   e->max_img = cfg->max_img;
   e->ln_fused = !getenv("ETAINV_LN_UNFUSED");
   e->gn_fused = !getenv("ETAINV_GN_UNFUSED");
+  e->gn_fold = e->gn_fused && !getenv("ETAINV_GN_NOFOLD");
   if (build_model(e) || build_workspace(e)) {
     etainv_engine_destroy(e);
     return 1;
@@ -644,11 +676,8 @@ extern "C" int etainv_engine_set_weight(etainv_engine_t* e, const char* name, co
   ETAINV_CHECK(numel == s.numel(), std::string("size mismatch for ") + name);
   int64_t rows = s.shape[0], cols = s.numel() / s.shape[0];
   if (s.ndim == 1) { rows = s.shape[0]; cols = 1; }
-  if (s.stage) {
-    ETAINV_HIP(hipMemcpyAsync(s.stage, data, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-  } else if (launch_pack_weight(data, s.dst, rows, cols, s.pack, s.taps, s.dst_dtype, (hipStream_t)stream, s.scale)) {
-    return 1;
-  }
+  if (s.stage) ETAINV_HIP(hipMemcpyAsync(s.stage, data, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if ((!s.stage || s.stage_and_pack) && launch_pack_weight(data, s.dst, rows, cols, s.pack, s.taps, s.dst_dtype, (hipStream_t)stream, s.scale)) return 1;
   s.set = true;
   e->ln_folded = false;
   e->upload_stream = (hipStream_t)stream;

@@ -156,7 +156,15 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   // fast path (no upsample): element offset of tap (0,0) in source 1 / source 2 (lane chunk included) and 9-bit tap validity
   int a_e1[A_LOADS], a_e2[A_LOADS], a_mask[A_LOADS];
   const T* w_row[B_LOADS];
-  int it_n0 = 0, it_m0 = 0, it_bias_buf = 0;
+  int it_n0 = 0, it_m0 = 0, it_bias_buf = 0, it_boff = 0;
+  // Rarely used fields are read through the kernel-argument segment at their point of use (scalar loads) instead of living in SGPRs across the main
+  // loop: the ring kernels are out of scalar registers too, and every SGPR spilled to a VGPR lane costs a vector register.
+  auto ln_args = [&]() __attribute__((always_inline)) {
+    typedef const __attribute__((address_space(4))) IGemmParams* KArgs;   // constant address space: scalar loads
+    KArgs kp = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+  };
   // position of the K tile being issued, advanced incrementally (no integer division in the loop); it_k0 = first K tile of the part
   int it_tap = 0, it_c0 = 0, it_ky = 0, it_kx = 0, it_k0 = 0;
   auto setup_issue = [&](int i) __attribute__((always_inline)) {   // geometry of the tile whose K tiles are being prefetched
@@ -206,11 +214,23 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         a_mask[q] = mask;   // (with pad0 the a_y / a_x origin is the output pixel itself)
       }
     }
+    // per-image weights / bias (a GroupNorm folded into the 1x1 conv behind it: engine.cpp, transformer()): the tile lies inside one image
+    int64_t woff = 0;
+    it_boff = 0;
+    {
+      const auto kp = ln_args();
+      const int64_t wbs = kp->w_batch_stride;
+      if (wbs) {
+        const int img = m0 / p.rows_per_batch;
+        woff = img * wbs;
+        it_boff = img * kp->bias_batch_stride;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < B_LOADS; ++q) {
       int n = n0 + (tid >> 3) + RP * q;
       n = n < p.N ? n : p.N - 1;
-      w_row[q] = reinterpret_cast<const T*>(p.w) + (int64_t)n * (p.taps * cin) + lchunk * 8;
+      w_row[q] = reinterpret_cast<const T*>(p.w) + woff + (int64_t)n * (p.taps * cin) + lchunk * 8;
     }
   };
   const T* zero_page = reinterpret_cast<const T*>(p.zeros);
@@ -256,7 +276,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       const int c = wrow0 * 8 + lane;
       if (c < BN) {
         const int n = it_n0 + c < p.N ? it_n0 + c : p.N - 1;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + n),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + it_boff + n),
                                          (__attribute__((address_space(3))) void*)(sBias + it_bias_buf * BN + wrow0 * 8), 4, 0, 0);
       }
     }
@@ -299,14 +319,6 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   // 1 = exactly MT*ceil(NT/2) per wave, 2 = exactly MT*ceil(NT/4) per wave (GEGLU) -- see the counted vmcnt waits of the ring
   // LayerNorm consumer: mean / rstd of this lane's MT pixel rows from the producer's partials.  The four lanes that share a row (fq) each
   // combine every fourth partial, then merge among themselves.
-  // The LayerNorm fields are read through the kernel-argument segment at their point of use (scalar loads in the epilogue) instead of living in
-  // SGPRs across the main loop: the ring kernels are out of scalar registers too, and every SGPR spilled to a VGPR lane costs a vector register.
-  auto ln_args = [&]() __attribute__((always_inline)) {
-    typedef const __attribute__((address_space(4))) IGemmParams* KArgs;   // constant address space: scalar loads
-    KArgs kp = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
-    return kp;
-  };
   auto ln_rows = [&](int mw, float (&mean)[MT], float (&rstd)[MT]) __attribute__((always_inline)) {
     const float* ln_stat = ln_args()->ln_stat;   // finalized (mean, rstd) per row: norm.hip, ln_finalize_kernel / row_stats_kernel
 #pragma unroll
@@ -588,7 +600,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
           acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (!m_ok || n >= p.N) continue;
           if (ln_slow) v = (v - lns_mean[i] * *reinterpret_cast<const f32x4*>(ln_args()->ln_s + n)) * lns_rstd[i];
-          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + (int64_t)batch * ln_args()->bias_batch_stride + n);
           if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)batch * p.rowvec_stride + n);
           if (res) {
             const T* r = res + (int64_t)m * p.N + n;
@@ -843,7 +855,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         const int c = wrow0 * 8 + lane;
         if (c < BN) {
           const int n = it_n0 + c < p.N ? it_n0 + c : p.N - 1;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + n),
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + it_boff + n),
                                            (__attribute__((address_space(3))) void*)(sBias + it_bias_buf * BN + wrow0 * 8), 4, 0, 0);
           if constexpr (LN_STAGED)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.ln_s + n),
@@ -1051,6 +1063,7 @@ static int launch_igemm_t(const IGemmParams& p_in, hipStream_t s, int* stat_P = 
     p.stat_P = 0;
   }
   if (stat_P) *stat_P = p.stat_P;
+  ETAINV_CHECK(!p.w_batch_stride || (p.rows_per_batch % BM == 0 && !p.geglu && p.taps == 1), "per-image weights: every M tile inside one image, plain 1x1");
   if constexpr (LN == 0) {   // one instantiation per role (the 256 x 128 ring only runs GEGLU: never a producer; fused upsample: GroupNorm producer only)
     if constexpr (!(STAGES == 3 && BN == 128)) {
       if constexpr (!UPS)
@@ -1118,7 +1131,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p) {
     if (p.ln_stat) {   // folded LayerNorm (see IGemmParams::ln_stat)
       v = (v - p.ln_stat[(int64_t)m * 2] * *reinterpret_cast<const f32x4*>(p.ln_s + n)) * p.ln_stat[(int64_t)m * 2 + 1];
     }
-    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + (int64_t)(m / p.rows_per_batch) * p.bias_batch_stride + n);
     if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (int64_t)(m / p.rows_per_batch) * p.rowvec_stride + n);
     if (p.residual) {
       const T* r = reinterpret_cast<const T*>(p.residual) + (int64_t)m * p.N + n;

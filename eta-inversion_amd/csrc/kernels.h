@@ -33,6 +33,10 @@ struct IGemmParams {
   int ksplit = 1;             // split-K parts (filled in by launch_igemm for small M*N with deep K)
   float* ws = nullptr;        // [ksplit][M][N] fp32 partials
   int rows_per_batch = 1;     // Ho*Wo for convs; M/batch for linears
+  // per-image operands (a GroupNorm folded into the 1x1 conv that follows it): rows of image b use w + b * w_batch_stride (elements) and
+  // bias + b * bias_batch_stride; 0 = one weight matrix.  Needs rows_per_batch % (M tile) == 0.
+  int64_t w_batch_stride = 0;
+  int bias_batch_stride = 0;
   // ---- LayerNorm folded into the GEMM pair around it (the transformer blocks' norm1/2/3: no LayerNorm pass over HBM).
   // Producer side (the GEMM that writes the LayerNorm's input x): per row and per column chunk of the STORED (rounded) output, the pair
   // (mean, M2 = sum of squared deviations from that mean) -> stat_out[m][stat_P][2]; stat_P is chosen by launch_igemm (columns of one wave
@@ -60,6 +64,13 @@ int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float
 // [b * hw / wm][2][c] floats): a finalize launch (sums in double, fixed order) -> final[b][groups] (mean, rstd), then the apply pass of launch_groupnorm
 int launch_groupnorm_pre(const void* x1, const void* x2, int c1, int c2, const float* part1, int wm1, const float* part2, int wm2, const float* gamma,
                          const float* beta, void* out, int b, int hw, int groups, float eps, int silu, float* final_stats, int dtype, hipStream_t s);
+// the finalize half of launch_groupnorm_pre alone: final_stats[b][groups] = (mean, rstd)
+int launch_gn_finalize(int c1, int c2, const float* part1, int wm1, const float* part2, int wm2, int b, int hw, int groups, float eps, float* final_stats,
+                       hipStream_t s);
+// GroupNorm (no activation) folded into the 1x1 conv / Linear W [n][k] that follows it: per image b, W_b[n][k] = W[n][k] * rstd[b][g(k)] * gamma[k]
+// (rounded to the compute dtype) and c_b[n] = sum_k (beta[k] - mean[b][g(k)] * rstd * gamma[k]) * W[n][k] + bias[n]
+int launch_gn_fold(const float* w, const float* gamma, const float* beta, const float* bias, const float* final_stats, int groups, int b, int n, int k,
+                   void* wb_out, float* cb_out, int dtype, hipStream_t s);
 int launch_layernorm(const void* x, const float* gamma, const float* beta, void* out, int rows, int c, float eps, int dtype,
                      hipStream_t s);
 // stat[row] = (mean, rstd) of x[row][0..c): IGemmParams::ln_stat computed by a pass over x (when the producing GEMM could not emit partials)

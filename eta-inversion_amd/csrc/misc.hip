@@ -279,6 +279,41 @@ int launch_pack_weight(const float* src, void* dst, int64_t rows, int64_t cols, 
   return 0;
 }
 
+// GroupNorm (no activation) folded into the 1x1 conv behind it (Transformer2DModel.norm -> proj_in): per image b the conv sees
+// x * a_b + sh_b with a_b[k] = rstd[b][g(k)] * gamma[k], sh_b[k] = beta[k] - mean[b][g(k)] * a_b[k], so W_b = W . diag(a_b) and c_b = W sh_b + bias.
+// One wave per (image, output row n).
+template <typename TD>
+__global__ void __launch_bounds__(256) gn_fold_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ bias, const float* __restrict__ stats, int groups, int n_out, int k_in,
+                                                      TD* __restrict__ wb, float* __restrict__ cb) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+  if (n >= n_out) return;
+  const int cpg = k_in / groups;
+  const float* st = stats + (int64_t)b * groups * 2;
+  float c = 0.f;
+  for (int k = lane; k < k_in; k += 64) {
+    const int g = k / cpg;
+    const float a = st[g * 2 + 1] * gamma[k];
+    const float wv = w[(int64_t)n * k_in + k];
+    wb[((int64_t)b * n_out + n) * k_in + k] = from_f32<TD>(wv * a);
+    c += (beta[k] - st[g * 2] * a) * wv;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if (lane == 0) cb[(int64_t)b * n_out + n] = c + (bias ? bias[n] : 0.f);
+}
+
+int launch_gn_fold(const float* w, const float* gamma, const float* beta, const float* bias, const float* final_stats, int groups, int b, int n, int k,
+                   void* wb_out, float* cb_out, int dtype, hipStream_t s) {
+  ETAINV_CHECK(w && gamma && beta && final_stats && wb_out && cb_out && b > 0 && n > 0 && k > 0 && k % groups == 0, "bad arguments");
+  ProfScope prof(PROF_GROUPNORM, 0.0, s);
+  ETAINV_DISPATCH_HALF(dtype, TD, hipLaunchKernelGGL(gn_fold_kernel<TD>, dim3(cdiv(n, 4), b), dim3(256), 0, s, w, gamma, beta, bias, final_stats, groups, n, k,
+                                                     (TD*)wb_out, cb_out));
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_ln_fold(const float* w_src, const float* gamma, const float* beta, const float* bias_packed, int64_t rows, int64_t cols, int mode, float scale,
                    void* w_dst, float* s_dst, float* c_dst, int dtype, hipStream_t s) {
   ETAINV_CHECK(w_src && gamma && beta && w_dst && s_dst && c_dst && rows > 0 && cols > 0, "bad arguments");

@@ -392,6 +392,16 @@ int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float
   return 0;
 }
 
+int launch_gn_finalize(int c1, int c2, const float* part1, int wm1, const float* part2, int wm2, int b, int hw, int groups, float eps, float* final_stats,
+                       hipStream_t s) {
+  ETAINV_CHECK(part1 && final_stats && (c1 + c2) % groups == 0 && groups <= 32, "bad arguments");
+  ETAINV_CHECK(wm1 > 0 && hw % wm1 == 0 && (c2 == 0 || (part2 && wm2 > 0 && hw % wm2 == 0)), "row blocks must tile an image");
+  ProfScope prof(PROF_GROUPNORM, 0.0, s);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((groups + 3) / 4, b), dim3(256), 0, s, part1, wm1, c1, part2, wm2, c2, hw, groups, eps, final_stats);
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_groupnorm_pre(const void* x1, const void* x2, int c1, int c2, const float* part1, int wm1, const float* part2, int wm2, const float* gamma,
                          const float* beta, void* out, int b, int hw, int groups, float eps, int silu, float* final_stats, int dtype, hipStream_t s) {
   const int C = c1 + c2;
@@ -401,7 +411,10 @@ int launch_groupnorm_pre(const void* x1, const void* x2, int c1, int c2, const f
   ETAINV_CHECK(c2 == 0 || (x2 && part2), "second source missing");
   ETAINV_CHECK(wm1 > 0 && hw % wm1 == 0 && (c2 == 0 || (wm2 > 0 && hw % wm2 == 0)), "row blocks must tile an image");
   ProfScope prof(PROF_GROUPNORM, 2.0 * 2.0 * (double)b * hw * C, s);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((groups + 3) / 4, b), dim3(256), 0, s, part1, wm1, c1, part2, wm2, c2, hw, groups, eps, final_stats);
+  prof_pause(true);
+  const int rc = launch_gn_finalize(c1, c2, part1, wm1, part2, wm2, b, hw, groups, eps, final_stats, s);
+  prof_pause(false);
+  if (rc) return 1;
   const int chunks_apply = std::max(1, std::min(hw / 4, std::max(std::min(GN_MAX_CHUNKS, std::max(1, std::min(hw / 8, 1024 / std::max(1, b)))), 4096 / std::max(1, b))));
   const int vpl = ((C >> 3) + 63) / 64;
 #define ETAINV_GN_APPLY(VPL_)                                                                                                              \
