@@ -232,6 +232,9 @@ def main():
             "end_to_end_mfma_frac": value / world * FWD_PER_IMAGE * F_UNET_TFLOP / MFMA_PEAK_TFLOPS,
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv3x3 / conv1x1 / linear)", "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "note": "achieved = GEMM FLOPs only over the kernel's whole duration; its epilogues also carry bias / time row / residual / GEGLU and, "
+                                 "since round 2, the LayerNorm and GroupNorm statistics that were separate passes (ETAINV_LN_UNFUSED / ETAINV_GN_UNFUSED move them "
+                                 "back out: higher igemm TFLOP/s, lower images/s)",
                          "launches": ig_n, "avg_launch_ms": ig_ms / max(ig_n, 1), "share_of_wall": ig_ms * 1e-3 / dt_prof,
                          "measured_on": "one extra step after the timed region, HIP events on the launch stream"},
             # the same igemm launches split by which roofline bounds them (algorithmic intensity of the launch vs the 312.5 FLOP/B ridge): the

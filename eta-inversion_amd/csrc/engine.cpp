@@ -130,7 +130,10 @@ struct etainv_engine {
   void* gn_wb = nullptr;
   float* gn_cb = nullptr;
   bool gn_fused = true;
-  bool gn_fold = true;   // ... and the transformer's GroupNorm (no activation) folded into proj_in through per-image weights; ETAINV_GN_NOFOLD=1: off
+  // ... and, opt-in (ETAINV_GN_FOLD=1), the transformer's GroupNorm (no activation) folded into proj_in through per-image weights: -1.3 % of a
+  // 128-row UNet call, nothing measurable on the whole benchmark step, and the rounding of W . diag(rstd gamma) makes the result depend on the
+  // ratio of a group's mean to its deviation -- off by default
+  bool gn_fold = false;
   bool ln_fused = true;
   bool ln_folded = false;   // the gamma-scaled consumer weights are packed (redone after any set_weight)
   hipStream_t upload_stream = nullptr;   // stream of the last set_weight (the fold waits for it when the forward runs on another one)
@@ -271,7 +274,7 @@ struct Builder {
     linear(tp + ".ff.net.0.proj", t.ff1, 8 * c, c, true, PK_GEGLU);
     linear(tp + ".ff.net.2", t.ff2, c, 4 * c, true);
     conv1x1(prefix + ".proj_out", t.proj_out, c, c);
-    if (e->gn_fused && c <= 640) {
+    if (e->gn_fold && c <= 640) {
       want(&t.st_pin, (size_t)c * c * 4);
       stage_slot(prefix + ".proj_in.weight", &t.st_pin, 0, /*and_pack=*/true);
     }
@@ -639,7 +642,7 @@ extern "C" int etainv_engine_create(const etainv_engine_config* cfg, etainv_engi
   e->max_img = cfg->max_img;
   e->ln_fused = !getenv("ETAINV_LN_UNFUSED");
   e->gn_fused = !getenv("ETAINV_GN_UNFUSED");
-  e->gn_fold = e->gn_fused && !getenv("ETAINV_GN_NOFOLD");
+  e->gn_fold = e->gn_fused && getenv("ETAINV_GN_FOLD") != nullptr;
   if (build_model(e) || build_workspace(e)) {
     etainv_engine_destroy(e);
     return 1;

@@ -82,3 +82,26 @@ def test_unet_bench_shape_class_vs_oracle(oracle_unet):
         assert all(torch.equal(out[0], out[i]) for i in range(rows))
         assert relerr(out[0].cpu(), ref) < 3e-3, rows
     e.close()
+
+
+@pytest.mark.parametrize("switch", ["ETAINV_LN_UNFUSED", "ETAINV_GN_UNFUSED", "ETAINV_GN_FOLD"])
+def test_unet_norm_fusion_switches_agree(monkeypatch, switch):
+    """the A/B switches of the norm fusions (LayerNorm folded into the GEMMs around it, GroupNorm statistics from the producer's epilogue, GroupNorm
+    folded into proj_in through per-image weights) change where the arithmetic happens, not the result: same weights and inputs, L = 32 (both
+    fused paths and their fallbacks at the 4 x 4 level), against the default engine"""
+    from etainv.engine import Engine
+    g = torch.Generator().manual_seed(5)
+    # 16 UNet rows: enough tiles that the level-0 convs run unsplit (a split-K producer emits no statistics, and then nothing is fused behind it)
+    x, ctx = torch.randn(8, 4, 32, 32, generator=g).cuda(), torch.randn(16, 77, 768, generator=g).cuda()
+    outs = []
+    for on in (False, True):
+        if on:
+            monkeypatch.setenv(switch, "1")
+        e = Engine(dtype=torch.float16, max_unet_batch=16, latent_size=32, max_img=4)
+        e.load_synthetic(0)
+        outs.append(e.unet(x, 500, ctx).float().cpu())
+        torch.cuda.synchronize()
+        e.close()
+    err = relerr(outs[1], outs[0])
+    print(f"{switch}: rel L2 {err:.2e}")
+    assert 0 < err < 2e-3
