@@ -682,6 +682,9 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
   T* sKs = sK + KC * KSTR;                       // [KC][KSTR]  keys of the source row (EDIT only)
   T* sVt = EDIT ? sKs + KC * KSTR : sKs;         // [DT*16][VSTR]
   float* sP = reinterpret_cast<float*>(sVt + DT * 16 * VSTR);  // [4 waves][QT][16][PSTR] source probabilities (EDIT only)
+  // (EDIT only) this image's per-token tables -- mapper (as int bits), refine alpha, equalizer, cross-replace alpha of the step -- read once per
+  // block instead of four global loads per key and lane in every query tile
+  float* sTab = sP + 4 * QT * 16 * PSTR;                       // [4][80]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, q4 = lane >> 4;
@@ -720,6 +723,14 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
     const T* e = reinterpret_cast<const T*>(&c);
 #pragma unroll
     for (int j = 0; j < 8; ++j) sVt[(ch * 8 + j) * VSTR + key] = e[j];
+  }
+  if (EDIT && do_edit && tid < p.n_ctx) {
+    int mp = p.mapper ? p.mapper[img * 77 + tid] : 0;
+    if (mp < 0) mp += p.n_ctx;                      // python negative index: -1 -> last token
+    sTab[0 * 80 + tid] = __builtin_bit_cast(float, mp);
+    sTab[1 * 80 + tid] = p.alphas ? p.alphas[img * 77 + tid] : 0.f;
+    sTab[2 * 80 + tid] = p.equalizer ? p.equalizer[img * 77 + tid] : 1.f;
+    sTab[3 * 80 + tid] = p.cross_alpha[img * 77 + tid];
   }
   __syncthreads();
 
@@ -804,13 +815,12 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
               rep = 0.f;
               for (int w = 0; w < p.n_ctx; ++w) rep += sPw[w] * mrow[w * 77];
             } else {                                          // AttentionRefine
-              int mp = p.mapper[img * 77 + key];
-              if (mp < 0) mp += p.n_ctx;                      // python negative index: -1 -> last token
-              const float a = p.alphas[img * 77 + key];
+              const int mp = __builtin_bit_cast(int, sTab[0 * 80 + key]);
+              const float a = sTab[1 * 80 + key];
               rep = sPw[mp] * a + tg * (1.f - a);
             }
-            if (p.equalizer) rep *= p.equalizer[img * 77 + key];
-            const float ca = p.cross_alpha[img * 77 + key];
+            rep *= sTab[2 * 80 + key];
+            const float ca = sTab[3 * 80 + key];
             pr[kt][r] = rep * ca + (1.f - ca) * tg;
           }
         }
@@ -936,7 +946,7 @@ template <typename T, int D>
 static int launch_cross_t(const void* q, const void* kv, void* out, int b, const CrossParams& p, hipStream_t s) {
   constexpr int QT = 2;
   constexpr int DP = (D + 31) / 32 * 32, DT = (D + 15) / 16;
-  const size_t lds_edit = (size_t)(2 * 96 * (DP + 8) + DT * 16 * (96 + 8)) * sizeof(T) + (size_t)4 * QT * 16 * 81 * sizeof(float);
+  const size_t lds_edit = (size_t)(2 * 96 * (DP + 8) + DT * 16 * (96 + 8)) * sizeof(T) + (size_t)(4 * QT * 16 * 81 + 4 * 80) * sizeof(float);
   const size_t lds_plain = (size_t)(96 * (DP + 8) + DT * 16 * (96 + 8)) * sizeof(T);
   static bool attr = false;
   if (!attr) {
