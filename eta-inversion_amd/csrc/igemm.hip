@@ -1167,7 +1167,13 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   // tile choice: big tiles when they still fill the 256 CUs, else 64x64 (GEGLU pairing is per wave tile,
   // so the packing of a GEGLU weight fixes its tile: always 128 wide)
   const int64_t big_tiles = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128);
-  const bool big = p.geglu || (big_tiles >= 192 && p.N > 64);
+  // ... and for a deep K (3x3 convs of the 8x8 / 16x16 levels at a few dozen rows: 180-360 K tiles) big tiles with split-K even when they
+  // alone would leave most CUs empty: 640 resident 64 x 64 blocks each walked all K tiles at one memory latency per tile (182 us per launch,
+  // 1.8 % of the benchmark step)
+  static const int deepk_min_tiles = getenv("ETAINV_DEEPK_MIN_TILES") ? atoi(getenv("ETAINV_DEEPK_MIN_TILES")) : 64;
+  const bool deep_k = !p.geglu && p.N % 160 == 0 && p.taps * (p.c1 + p.c2) / BK >= 64 && !p.out_nchw && !p.out_f32 &&
+                      (int64_t)cdiv(p.M, 128) * cdiv(p.N, 160) >= deepk_min_tiles;
+  const bool big = p.geglu || (big_tiles >= 192 && p.N > 64) || deep_k;
   ETAINV_CHECK(!p.out_nchw || p.N == 4, "out_nchw needs N == 4");
   const int64_t huge_tiles = (int64_t)cdiv(p.M, 256) * cdiv(p.N, 160);
   // a LayerNorm consumer on a ring kernel: fast epilogue only (64-row wave tiles inside one image)
