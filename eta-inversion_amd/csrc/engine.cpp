@@ -124,6 +124,13 @@ struct etainv_engine {
   // standalone LayerNorm kernel (A/B switch, read at engine creation)
   // GroupNorm statistics from the epilogue of the GEMM / conv that wrote the tensor (per-channel partials per wave-tile row block, one buffer per
   // activation buffer a GroupNorm can read: skip[0..11], tmp[0..2], h1) instead of a statistics pass over it; ETAINV_GN_UNFUSED=1 keeps the pass
+  // cross-attention K / V of the text context per transformer block.  The context does not change over the 50 steps of a loop: with
+  // etainv_engine_cache_context(e, 1) a call whose (context pointer, rows, dtype) equal the previous call's reuses them (16 small GEMMs and the
+  // context cast per UNet call, 0.6 % of the benchmark step); the caller switches it off when the loop ends.
+  void* kvcache[16] = {};
+  bool ctx_cache_on = false;
+  const void* ctx_cached = nullptr;
+  int ctx_rows = 0, ctx_io = -1;
   void* gn_bufs[16] = {};
   float* gn_part[16] = {};
   float* gn_final = nullptr;
@@ -384,6 +391,7 @@ int build_workspace(etainv_engine* e) {
   want(&e->attnbuf, B * hmax * 2);
   want(&e->qbuf, B * hmax * 2);
   want(&e->kvbuf, B * 77 * 2 * 1280 * 2);
+  for (size_t i = 0; i < e->tb.size() && i < 16; ++i) want(&e->kvcache[i], B * 77 * 2 * (size_t)e->tb[i].c * 2);
   want(&e->ffbuf, B * hmax * 4 * 2);
   want(&e->ctxT, B * 77 * 768 * 2);
   want(&e->tembuf, B * 320 * 2);
@@ -421,6 +429,7 @@ struct Fwd {
   int rows;
   const etainv_attn_ctrl* ctrl;
   int tblock_idx = 0;
+  bool kv_reuse = false;   // the K / V projections of this context are already in e->kvcache (etainv_engine_cache_context)
 
   // rows per GroupNorm partial block of the tensor now in each tracked buffer (0: no partials -- the GroupNorm runs its statistics pass)
   int part_wm[16] = {};
@@ -572,7 +581,8 @@ struct Fwd {
       if (launch_layernorm(e->hsB, t.ln2.g, t.ln2.b, e->lnbuf, M, c, 1e-5f, e->dt, s)) return 1;
       if (gemm(e->lnbuf, t.q, e->qbuf, M)) return 1;
     }
-    if (gemm(e->ctxT, t.kv, e->kvbuf, rows * etainv_engine::kCtx)) return 1;
+    void* kvb = e->kvcache[blk];
+    if (!kv_reuse && gemm(e->ctxT, t.kv, kvb, rows * etainv_engine::kCtx)) return 1;
     CrossParams cp;
     cp.N = hw;
     cp.heads = etainv_engine::kHeads;
@@ -599,7 +609,7 @@ struct Fwd {
         cp.map_layer = layer_of_block[blk];
       }
     }
-    if (launch_cross_attention_p(e->qbuf, e->kvbuf, e->attnbuf, rows, d, cp, e->dt, s)) return 1;
+    if (launch_cross_attention_p(e->qbuf, kvb, e->attnbuf, rows, d, cp, e->dt, s)) return 1;
     if (gemm(e->attnbuf, t.out2, e->hsA, M, e->hsB, 0, nullptr, 0, 0, fold)) return 1;
     // feed-forward (GEGLU)
     if (fold) {
@@ -711,6 +721,13 @@ extern "C" int etainv_engine_weights_ready(etainv_engine_t* e) {
   return 1;
 }
 
+extern "C" int etainv_engine_cache_context(etainv_engine_t* e, int enable) {
+  ETAINV_CHECK(e, "null engine");
+  e->ctx_cache_on = enable != 0;
+  e->ctx_cached = nullptr;   // (the first call after switching it on computes the projections)
+  return 0;
+}
+
 extern "C" int64_t etainv_engine_workspace_bytes(etainv_engine_t* e) { return e ? (int64_t)e->wsbytes : 0; }
 extern "C" int64_t etainv_engine_weight_bytes(etainv_engine_t* e) { return e ? (int64_t)e->wbytes : 0; }
 
@@ -753,7 +770,11 @@ extern "C" int etainv_unet_forward(etainv_engine_t* e, const void* latent, int n
     p.rows_per_batch = n_rows;
     if (launch_igemm(p, e->dt, s)) return 1;
   }
-  if (launch_cast_f32(ctx, io_dtype, e->ctxT, e->dt, (int64_t)n_rows * etainv_engine::kCtx * etainv_engine::kCtxDim, s)) return 1;
+  f.kv_reuse = e->ctx_cache_on && e->ctx_cached == ctx && e->ctx_rows == n_rows && e->ctx_io == io_dtype;
+  if (!f.kv_reuse && launch_cast_f32(ctx, io_dtype, e->ctxT, e->dt, (int64_t)n_rows * etainv_engine::kCtx * etainv_engine::kCtxDim, s)) return 1;
+  e->ctx_cached = e->ctx_cache_on ? ctx : nullptr;
+  e->ctx_rows = n_rows;
+  e->ctx_io = io_dtype;
 
   // ---- down path
   if (launch_im2col_in(latent, io_dtype, n_lat, n_rows, L, e->gnbuf, e->dt, s)) return 1;

@@ -123,6 +123,10 @@ class Engine:
                                                         0, 1.0, _capi.stream_ptr()))
         return out
 
+    def cache_context(self, enable):
+        """loops that pass one unchanged context tensor to every UNet call: reuse its cross-attention K / V projections (off when the loop ends)"""
+        _capi.check(self.lib.etainv_engine_cache_context(self.h, int(bool(enable))))
+
     def local_blend(self, x, n_img, blend_alpha, thres=0.3):
         assert x.dtype == torch.float32
         _capi.check(self.lib.etainv_local_blend(self.h, _capi.ptr(x), n_img, _capi.ptr(blend_alpha), float(thres), _capi.stream_ptr()))

@@ -99,6 +99,7 @@ class EtaLoop:
             e.maps_reset()
         n = B * 4 * L * L
         st = _capi.stream_ptr()
+        e.cache_context(True)                                   # one context tensor for all S calls
         for j, t in enumerate(self.t_fwd):
             x_in = lat[j] if teacher is None else teacher[j].contiguous()
             e.unet(x_in, int(t), ctx, ctrl, out=eps_all)
@@ -112,6 +113,7 @@ class EtaLoop:
                 e.word_maps(B, tokens, j + 1, maps_mean, accumulate=True, scale=1.0 / S)
                 if maps_steps is not None:
                     e.word_maps(B, tokens, j + 1, maps_steps[j], accumulate=False, scale=1.0)
+        e.cache_context(False)
         return {"latents": lat, "maps_mean": maps_mean, "maps_steps": maps_steps}
 
     # ---------------------------------------------------------------- backward / eta sampling
@@ -172,6 +174,7 @@ class EtaLoop:
         if ptp is not None:
             e.maps_reset()
         st = _capi.stream_ptr()
+        e.cache_context(True)                                   # one context tensor for all S calls
         for i, t in enumerate(self.t_bwd):
             t = int(t)
             ctrl = None
@@ -202,6 +205,7 @@ class EtaLoop:
                 e.local_blend(x, B, ptp.blend_alpha, 0.3)                       # LocalBlend, reference ptp.py:31-47
             if trace is not None:
                 trace.append({"t": t, "latent": x.clone(), "best": best.clone(), "eps_all": eps_all.clone()})
+        e.cache_context(False)
         return x
 
 

@@ -171,6 +171,11 @@ int etainv_maps_word_maps_role(etainv_engine_t* e, int n_img, const int32_t* tok
 int etainv_local_blend(etainv_engine_t* e, float* x, int n_img, const float* blend_alpha, float thres, void* stream);
 
 /* Workspace statistics for DESIGN.md / bench (bytes). */
+/* The loops of DiffusionInversion.diffusion_forward / sample (reference modules/inversion/diffusion_inversion.py:388-418, 493-528) pass the SAME context
+ * tensor to every UNet call.  enable = 1: etainv_unet_forward reuses the cross-attention K / V projections of the context when the context
+ * pointer, row count and dtype equal the previous call's -- the caller promises not to change the buffer's contents in between and switches the
+ * cache off (enable = 0) when the loop ends.  Off by default: every call projects the context it is given. */
+int etainv_engine_cache_context(etainv_engine_t* e, int enable);
 int64_t etainv_engine_workspace_bytes(etainv_engine_t* e);
 int64_t etainv_engine_weight_bytes(etainv_engine_t* e);
 

@@ -105,3 +105,26 @@ def test_unet_norm_fusion_switches_agree(monkeypatch, switch):
     err = relerr(outs[1], outs[0])
     print(f"{switch}: rel L2 {err:.2e}")
     assert 0 < err < 2e-3
+
+
+def test_context_cache_reuses_projections_and_tracks_changes(engines):
+    """etainv_engine_cache_context: a second call with the same context tensor reuses the cross-attention K / V projections (same output bit
+    for bit); a different tensor, a different row count, or switching the cache off and on recomputes them"""
+    e = engines(torch.float16, 16)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 4, 16, 16, generator=g).cuda()
+    c1, c2 = torch.randn(4, 77, 768, generator=g).cuda(), torch.randn(4, 77, 768, generator=g).cuda()
+    ref1, ref2 = e.unet(x, 300, c1).clone(), e.unet(x, 300, c2).clone()
+    assert not torch.equal(ref1, ref2)
+    e.cache_context(True)
+    try:
+        assert torch.equal(e.unet(x, 300, c1), ref1)
+        assert torch.equal(e.unet(x, 300, c1), ref1)          # projections reused
+        assert torch.equal(e.unet(x, 300, c2), ref2)          # another tensor: recomputed
+        assert torch.equal(e.unet(x[:1], 300, c2[:2]), e.unet(x[:1], 300, c2[:2].clone()))   # fewer rows, same base pointer: recomputed
+        c2.copy_(c1)                                          # contents changed behind the engine's back: the caller's promise is broken,
+        e.cache_context(True)                                 # re-arming the cache is what a loop start does
+        assert torch.equal(e.unet(x, 300, c2), ref1)
+    finally:
+        e.cache_context(False)
+    assert torch.equal(e.unet(x, 300, c1), ref1)
