@@ -941,11 +941,22 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       read_frags(slot, 1, fa1, fb1);
       if constexpr (HAS_PB) issue_b(pslot);
       mfma_range(fa0, fb0, std::integral_constant<int, 0>{}, std::integral_constant<int, NA>{});
+#ifndef ETAINV_W1_READS1
+      // the F1 reads go two per MFMA at the head of the window: the LDS latency of the last one then lies under the rest of the cluster instead of
+      // in front of the rendezvous (one per MFMA over the first nine: convs -3.0 ... -3.8 %, short-K GEMMs 0 ... -4 %)
+#pragma unroll
+      for (int q = 0; q < (MT + NT + 1) / 2; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, (MT + NT) - (MT + NT + 1) / 2, 0);
+#else
 #pragma unroll
       for (int q = 0; q < MT + NT; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 ds_read
       }
+#endif
       if constexpr (HAS_PB) {
 #pragma unroll
         for (int q = 0; q < B_PASSES; ++q) {
