@@ -936,8 +936,11 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
 #ifndef ETAINV_RING_EARLY_SYNC
 #define ETAINV_RING_EARLY_SYNC 1
 #endif
+#ifndef ETAINV_RING_NA_BASE
+#define ETAINV_RING_NA_BASE (MT + NT)
+#endif
       constexpr int NA = (!HAS_NEXT || !ETAINV_RING_EARLY_SYNC) ? MT * NT
-                         : ((MT + NT) + (HAS_PB ? B_PASSES : 0) + 2 < MT * NT ? (MT + NT) + (HAS_PB ? B_PASSES : 0) + 2 : MT * NT);
+                         : (ETAINV_RING_NA_BASE + (HAS_PB ? B_PASSES : 0) + 2 < MT * NT ? ETAINV_RING_NA_BASE + (HAS_PB ? B_PASSES : 0) + 2 : MT * NT);
       read_frags(slot, 1, fa1, fb1);
       if constexpr (HAS_PB) issue_b(pslot);
       mfma_range(fa0, fb0, std::integral_constant<int, 0>{}, std::integral_constant<int, NA>{});
@@ -949,8 +952,9 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, (MT + NT) - (MT + NT + 1) / 2, 0);
+      constexpr int RSLOTS = (MT + NT + 1) / 2;   // MFMAs that carry the reads
 #else
+      constexpr int RSLOTS = MT + NT;
 #pragma unroll
       for (int q = 0; q < MT + NT; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
@@ -964,8 +968,9 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
           __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // 1 DMA piece
         }
       }
-      if constexpr (NA - (MT + NT) - (HAS_PB ? B_PASSES : 0) > 0)
-        __builtin_amdgcn_sched_group_barrier(0x008, NA - (MT + NT) - (HAS_PB ? B_PASSES : 0), 0);
+      static_assert(NA >= RSLOTS + (HAS_PB ? B_PASSES : 0), "window 1a must hold its read and DMA slots");
+      if constexpr (NA - RSLOTS - (HAS_PB ? B_PASSES : 0) > 0)
+        __builtin_amdgcn_sched_group_barrier(0x008, NA - RSLOTS - (HAS_PB ? B_PASSES : 0), 0);
       __builtin_amdgcn_sched_barrier(0);
 #ifdef ETAINV_IGEMM_STAMPS
       const uint64_t t1 = __builtin_amdgcn_s_memtime();
