@@ -178,9 +178,60 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x1,
     }
     __syncthreads();
   }
-  float sc[VPL][8], sh[VPL][8];
+  if constexpr (VPL == 0) {
+    // FLAT mode (nvec = 40 / 80 / 160 / 320, i.e. C = 320 / 640 / 1280 / 2560): a wave takes G = 320 / nvec pixels per iteration as 320 flat
+    // (pixel, channel vector) items = 5 rounds of 64 lanes, every lane busy.  One pixel per round left 24 of 64 lanes idle at C = 320 (40
+    // vectors) and the second round three quarters empty at C = 640 -- the two widths that carry most of the GroupNorm time.
+    constexpr int R = 5;
+    const int G = 320 / nvec;
+    float sc[R][8], sh[R][8];
+    int poff[R], voff[R];
+    bool second[R];
 #pragma unroll
-  for (int i = 0; i < VPL; ++i) {
+    for (int r = 0; r < R; ++r) {
+      const int idx = lane + 64 * r;
+      const int px = idx / nvec, v = idx - px * nvec;
+      poff[r] = px;
+      second[r] = v >= nv1;
+      voff[r] = (second[r] ? v - nv1 : v) * 8;
+      int g = (v * 8) / cpg, rem = v * 8 - g * cpg;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ch = v * 8 + j;
+        const float a = st[g * 2 + 1] * gamma[ch];
+        sc[r][j] = a;
+        sh[r][j] = beta[ch] - st[g * 2] * a;
+        if (++rem == cpg) { rem = 0; ++g; }
+      }
+    }
+    for (int pix0 = beg + wid * G; pix0 < end; pix0 += 4 * G) {
+      float t[R][8];
+      bool ok[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int pix = pix0 + poff[r];
+        ok[r] = pix < end;
+        const int64_t row = (int64_t)b * hw + (ok[r] ? pix : beg);
+        if (second[r]) load8(x2 + row * c2 + voff[r], t[r]);
+        else load8(x1 + row * c1 + voff[r], t[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float y = t[r][j] * sc[r][j] + sh[r][j];
+          t[r][j] = silu ? silu_f(y) : y;
+        }
+        const int pix = pix0 + poff[r];
+        if (ok[r]) store8(out + ((int64_t)b * hw + pix) * C + (second[r] ? nv1 * 8 : 0) + voff[r], t[r]);
+      }
+    }
+    return;
+  }
+  constexpr int VP = VPL > 0 ? VPL : 1;
+  float sc[VP][8], sh[VP][8];
+#pragma unroll
+  for (int i = 0; i < VP; ++i) {
     const int v = lane + 64 * i;
     if (v < nvec) {
       int g = (v * 8) / cpg, rem = v * 8 - g * cpg;
@@ -194,11 +245,11 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x1,
       }
     }
   }
-#pragma unroll(VPL <= 2 ? GN_UNROLL : 1)
+#pragma unroll(VP <= 2 ? GN_UNROLL : 1)
   for (int pix = beg + wid; pix < end; pix += 4) {
     const int64_t row = (int64_t)b * hw + pix;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
+    for (int i = 0; i < VP; ++i) {
       const int v = lane + 64 * i;
       if (v < nvec) {
         float t[8];
@@ -354,6 +405,15 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
   }
 }
 
+// apply-pass instantiation: 0 = flat mode (C = 320 / 640: 320 vector items per wave iteration; -18 ... -25 % there, the wider tensors -- whose
+// rounds were already full -- lose a few percent to the extra index arithmetic), else vectors per lane
+static inline int gn_apply_mode(int C) {
+  static const bool no_flat = getenv("ETAINV_GN_NOFLAT") != nullptr;
+  const int nvec = C >> 3;
+  if (!no_flat && (nvec == 40 || nvec == 80)) return 0;
+  return (nvec + 63) / 64;
+}
+
 int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float* gamma, const float* beta, void* out, int b,
                      int hw, int groups, float eps, int silu, float* scratch, int dtype, hipStream_t s) {
   const int C = c1 + c2;
@@ -377,16 +437,25 @@ int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float
       attr_ = true;                                                                                                                        \
     }                                                                                                                                      \
     hipLaunchKernelGGL((gn_stats_kernel<T, VPL_>), dim3(chunks, b), dim3(256), lds, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups, partial); \
-    hipLaunchKernelGGL((gn_apply_kernel<T, VPL_>), dim3(chunks_apply, b), dim3(256), 0, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups,     \
-                       partial, chunks, (float)hw * (float)(C / groups), eps, gamma, beta, silu, (T*)out);                                  \
   }
+#define ETAINV_GN_APPLY(VPL_)                                                                                                              \
+  hipLaunchKernelGGL((gn_apply_kernel<T, VPL_>), dim3(chunks_apply, b), dim3(256), 0, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups,     \
+                     (const float*)partial, chunks, (float)hw * (float)(C / groups), eps, gamma, beta, silu, (T*)out);
   ETAINV_DISPATCH_HALF(dtype, T, switch (vpl) {
     case 1: ETAINV_GN_LAUNCH(1) break;
     case 2: ETAINV_GN_LAUNCH(2) break;
     case 3: ETAINV_GN_LAUNCH(3) break;
     case 4: ETAINV_GN_LAUNCH(4) break;
     default: ETAINV_GN_LAUNCH(5) break;
+  } switch (gn_apply_mode(C)) {
+    case 0: ETAINV_GN_APPLY(0) break;
+    case 1: ETAINV_GN_APPLY(1) break;
+    case 2: ETAINV_GN_APPLY(2) break;
+    case 3: ETAINV_GN_APPLY(3) break;
+    case 4: ETAINV_GN_APPLY(4) break;
+    default: ETAINV_GN_APPLY(5) break;
   });
+#undef ETAINV_GN_APPLY
 #undef ETAINV_GN_LAUNCH
   ETAINV_LAUNCH_CHECK();
   return 0;
@@ -416,11 +485,11 @@ int launch_groupnorm_pre(const void* x1, const void* x2, int c1, int c2, const f
   prof_pause(false);
   if (rc) return 1;
   const int chunks_apply = std::max(1, std::min(hw / 4, std::max(std::min(GN_MAX_CHUNKS, std::max(1, std::min(hw / 8, 1024 / std::max(1, b)))), 4096 / std::max(1, b))));
-  const int vpl = ((C >> 3) + 63) / 64;
 #define ETAINV_GN_APPLY(VPL_)                                                                                                              \
   hipLaunchKernelGGL((gn_apply_kernel<T, VPL_>), dim3(chunks_apply, b), dim3(256), 0, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups,     \
                      (const float*)final_stats, 0, (float)hw * (float)(C / groups), eps, gamma, beta, silu, (T*)out);
-  ETAINV_DISPATCH_HALF(dtype, T, switch (vpl) {
+  ETAINV_DISPATCH_HALF(dtype, T, switch (gn_apply_mode(C)) {
+    case 0: ETAINV_GN_APPLY(0) break;
     case 1: ETAINV_GN_APPLY(1) break;
     case 2: ETAINV_GN_APPLY(2) break;
     case 3: ETAINV_GN_APPLY(3) break;
