@@ -405,6 +405,13 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
   }
 }
 
+// blocks of the apply pass over the whole batch (each block computes its per-lane scale / shift vectors before it streams: fewer, longer
+// blocks amortise that better)
+static inline int gn_apply_blocks() {
+  static const int n = getenv("ETAINV_GN_APPLY_BLOCKS") ? atoi(getenv("ETAINV_GN_APPLY_BLOCKS")) : 2048;
+  return n;
+}
+
 // apply-pass instantiation: 0 = flat mode (C = 320 / 640: 320 vector items per wave iteration; -18 ... -25 % there, the wider tensors -- whose
 // rounds were already full -- lose a few percent to the extra index arithmetic), else vectors per lane
 static inline int gn_apply_mode(int C) {
@@ -425,7 +432,7 @@ int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float
   float* partial = scratch;
   const size_t lds = (size_t)4 * C * 2 * sizeof(float);
   // the apply pass has no cross-block reduction: use more, smaller chunks to fill the chip
-  const int chunks_apply = std::max(1, std::min(hw / 4, std::max(chunks, 4096 / std::max(1, b))));
+  const int chunks_apply = std::max(1, std::min(hw / 4, std::max(chunks, gn_apply_blocks() / std::max(1, b))));
   ProfScope prof(PROF_GROUPNORM, 2.0 * 2.0 * (double)b * hw * C, s);  // algorithmic bytes: read + write once, 2-byte elements
   const int vpl = ((C >> 3) + 63) / 64;
 #define ETAINV_GN_LAUNCH(VPL_)                                                                                                             \
@@ -484,7 +491,7 @@ int launch_groupnorm_pre(const void* x1, const void* x2, int c1, int c2, const f
   const int rc = launch_gn_finalize(c1, c2, part1, wm1, part2, wm2, b, hw, groups, eps, final_stats, s);
   prof_pause(false);
   if (rc) return 1;
-  const int chunks_apply = std::max(1, std::min(hw / 4, std::max(std::min(GN_MAX_CHUNKS, std::max(1, std::min(hw / 8, 1024 / std::max(1, b)))), 4096 / std::max(1, b))));
+  const int chunks_apply = std::max(1, std::min(hw / 4, std::max(std::min(GN_MAX_CHUNKS, std::max(1, std::min(hw / 8, 1024 / std::max(1, b)))), gn_apply_blocks() / std::max(1, b))));
 #define ETAINV_GN_APPLY(VPL_)                                                                                                              \
   hipLaunchKernelGGL((gn_apply_kernel<T, VPL_>), dim3(chunks_apply, b), dim3(256), 0, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups,     \
                      (const float*)final_stats, 0, (float)hw * (float)(C / groups), eps, gamma, beta, silu, (T*)out);
