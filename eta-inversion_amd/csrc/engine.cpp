@@ -138,8 +138,7 @@ struct etainv_engine {
   float* gn_cb = nullptr;
   bool gn_fused = true;
   // ... and, opt-in (ETAINV_GN_FOLD=1), the transformer's GroupNorm (no activation) folded into proj_in through per-image weights: -1.3 % of a
-  // 128-row UNet call, nothing measurable on the whole benchmark step, and the rounding of W . diag(rstd gamma) makes the result depend on the
-  // ratio of a group's mean to its deviation -- off by default
+  // 128-row UNet call, nothing measurable on the whole benchmark step -- off by default
   bool gn_fold = false;
   bool ln_fused = true;
   bool ln_folded = false;   // the gamma-scaled consumer weights are packed (redone after any set_weight)

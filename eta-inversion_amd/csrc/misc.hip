@@ -296,8 +296,10 @@ __global__ void __launch_bounds__(256) gn_fold_kernel(const float* __restrict__ 
     const int g = k / cpg;
     const float a = st[g * 2 + 1] * gamma[k];
     const float wv = w[(int64_t)n * k_in + k];
-    wb[((int64_t)b * n_out + n) * k_in + k] = from_f32<TD>(wv * a);
-    c += (beta[k] - st[g * 2] * a) * wv;
+    const TD wr = from_f32<TD>(wv * a);
+    wb[((int64_t)b * n_out + n) * k_in + k] = wr;
+    // the mean term against the ROUNDED operand the MFMAs multiply: a group's mean then cancels exactly, whatever its size
+    c += beta[k] * wv - st[g * 2] * to_f32(wr);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
