@@ -1187,7 +1187,8 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   // alone would leave most CUs empty: 640 resident 64 x 64 blocks each walked all K tiles at one memory latency per tile (182 us per launch,
   // 1.8 % of the benchmark step)
   static const int deepk_min_tiles = getenv("ETAINV_DEEPK_MIN_TILES") ? atoi(getenv("ETAINV_DEEPK_MIN_TILES")) : 64;
-  const bool deep_k = !p.geglu && p.N % 160 == 0 && p.taps * (p.c1 + p.c2) / BK >= 64 && !p.out_nchw && !p.out_f32 &&
+  static const int deepk_min_nk = getenv("ETAINV_DEEPK_MIN_NK") ? atoi(getenv("ETAINV_DEEPK_MIN_NK")) : 64;
+  const bool deep_k = !p.geglu && p.N % 160 == 0 && p.taps * (p.c1 + p.c2) / BK >= deepk_min_nk && !p.out_nchw && !p.out_f32 &&
                       (int64_t)cdiv(p.M, 128) * cdiv(p.N, 160) >= deepk_min_tiles;
   const bool big = p.geglu || (big_tiles >= 192 && p.N > 64) || deep_k;
   ETAINV_CHECK(!p.out_nchw || p.N == 4, "out_nchw needs N == 4");
