@@ -405,7 +405,7 @@ int build_workspace(etainv_engine* e) {
   for (int i = 0; i < 12; ++i) want(reinterpret_cast<void**>(&e->gn_part[i]), B * skip_el[i] / 16 * 4);
   for (int i = 0; i < 3; ++i) want(reinterpret_cast<void**>(&e->gn_part[12 + i]), B * hw[0] * 640 / 16 * 4);
   want(reinterpret_cast<void**>(&e->gn_part[15]), B * hmax / 16 * 4);
-  want(reinterpret_cast<void**>(&e->gn_final), B * etainv_engine::kGroups * 2 * 4);
+  want(reinterpret_cast<void**>(&e->gn_final), B * (etainv_engine::kGroups * 2 + 2 * 2560) * 4);   // (mean, rstd) + scale / shift planes
   want(&e->gn_wb, B * 640 * 640 * 2);                                   // per-image proj_in weights of a folded GroupNorm (C <= 640)
   want(reinterpret_cast<void**>(&e->gn_cb), B * 640 * 4);
   const size_t res = L / 4;

@@ -61,12 +61,13 @@ constexpr int GN_MAX_CHUNKS = 64;
 int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float* gamma, const float* beta, void* out,
                      int b, int hw, int groups, float eps, int silu, float* scratch, int dtype, hipStream_t s);
 // GroupNorm whose statistics arrive as per-channel partials from the epilogues of the GEMMs that wrote x1 / x2 (IGemmParams::stat_kind 1; part =
-// [b * hw / wm][2][c] floats): a finalize launch (sums in double, fixed order) -> final[b][groups] (mean, rstd), then the apply pass of launch_groupnorm
+// [b * hw / wm][2][c] floats): a finalize launch (sums in double, fixed order) -> final_stats = [b][groups][2] (mean, rstd) followed by the apply
+// pass's per-channel scale / shift planes [b][2][c1 + c2] (the buffer holds b * (2 * groups + 2 * C) floats), then the apply pass of launch_groupnorm
 int launch_groupnorm_pre(const void* x1, const void* x2, int c1, int c2, const float* part1, int wm1, const float* part2, int wm2, const float* gamma,
                          const float* beta, void* out, int b, int hw, int groups, float eps, int silu, float* final_stats, int dtype, hipStream_t s);
 // the finalize half of launch_groupnorm_pre alone: final_stats[b][groups] = (mean, rstd)
 int launch_gn_finalize(int c1, int c2, const float* part1, int wm1, const float* part2, int wm2, int b, int hw, int groups, float eps, float* final_stats,
-                       hipStream_t s);
+                       hipStream_t s, const float* gamma = nullptr, const float* beta = nullptr, float* scsh = nullptr);
 // GroupNorm (no activation) folded into the 1x1 conv / Linear W [n][k] that follows it: per image b, W_b[n][k] = W[n][k] * rstd[b][g(k)] * gamma[k]
 // (rounded to the compute dtype) and c_b[n] = sum_k (beta[k] - mean[b][g(k)] * rstd * gamma[k]) * W[n][k] + bias[n]
 int launch_gn_fold(const float* w, const float* gamma, const float* beta, const float* bias, const float* final_stats, int groups, int b, int n, int k,

@@ -135,7 +135,9 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x1,
   // batch 1 that 64-thread kernel was a 12 us chain of dependent loads, 8.5 % of the run)
   __shared__ double s_red[8][64][2];
   __shared__ float st[64 * 2];
-  if (chunks_st == 0) {   // `partial` already holds (mean, rstd) per (image, group): gn_finalize_kernel
+  const bool pre_scsh = chunks_st == 0 && gamma == nullptr;   // `partial` = per-channel scale / shift planes [b][2][C] (gn_finalize_kernel)
+  if (pre_scsh) {
+  } else if (chunks_st == 0) {   // `partial` already holds (mean, rstd) per (image, group): gn_finalize_kernel
     if (threadIdx.x < groups) {
       st[threadIdx.x * 2 + 0] = partial[((int64_t)b * groups + threadIdx.x) * 2 + 0];
       st[threadIdx.x * 2 + 1] = partial[((int64_t)b * groups + threadIdx.x) * 2 + 1];
@@ -194,6 +196,14 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x1,
       poff[r] = px;
       second[r] = v >= nv1;
       voff[r] = (second[r] ? v - nv1 : v) * 8;
+      if (pre_scsh) {
+        const float* ps = partial + ((int64_t)b * 2) * C + v * 8;
+        *reinterpret_cast<f32x4*>(&sc[r][0]) = *reinterpret_cast<const f32x4*>(ps);
+        *reinterpret_cast<f32x4*>(&sc[r][4]) = *reinterpret_cast<const f32x4*>(ps + 4);
+        *reinterpret_cast<f32x4*>(&sh[r][0]) = *reinterpret_cast<const f32x4*>(ps + C);
+        *reinterpret_cast<f32x4*>(&sh[r][4]) = *reinterpret_cast<const f32x4*>(ps + C + 4);
+        continue;
+      }
       int g = (v * 8) / cpg, rem = v * 8 - g * cpg;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -234,6 +244,14 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x1,
   for (int i = 0; i < VP; ++i) {
     const int v = lane + 64 * i;
     if (v < nvec) {
+      if (pre_scsh) {
+        const float* ps = partial + ((int64_t)b * 2) * C + v * 8;
+        *reinterpret_cast<f32x4*>(&sc[i][0]) = *reinterpret_cast<const f32x4*>(ps);
+        *reinterpret_cast<f32x4*>(&sc[i][4]) = *reinterpret_cast<const f32x4*>(ps + 4);
+        *reinterpret_cast<f32x4*>(&sh[i][0]) = *reinterpret_cast<const f32x4*>(ps + C);
+        *reinterpret_cast<f32x4*>(&sh[i][4]) = *reinterpret_cast<const f32x4*>(ps + C + 4);
+        continue;
+      }
       int g = (v * 8) / cpg, rem = v * 8 - g * cpg;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -367,7 +385,8 @@ __global__ void __launch_bounds__(256) ln_finalize_kernel(const float* __restric
 // One wave per (image, group): the 64 lanes take strided (row block, channel) pairs, sums in double, fixed order (a block per image walked
 // 320 dependent loads per thread at batch 1: slower than the statistics pass it replaces).
 __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ part1, int wm1, int c1, const float* __restrict__ part2, int wm2, int c2,
-                                                          int hw, int groups, float eps, float* __restrict__ final_stats) {
+                                                          int hw, int groups, float eps, float* __restrict__ final_stats,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ scsh) {
   const int b = blockIdx.y, C = c1 + c2, cpg = C / groups;
   const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (g >= groups) return;
@@ -395,14 +414,22 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
     a += __shfl_xor(a, o);
     q += __shfl_xor(q, o);
   }
+  const double count = (double)hw * (double)cpg;
+  const double mean = a / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float fmean = (float)mean, frstd = (float)(1.0 / sqrt(var + (double)eps));
   if (lane == 0) {
-    const double count = (double)hw * (double)cpg;
-    const double mean = a / count;
-    double var = q / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    final_stats[((int64_t)b * groups + g) * 2 + 0] = (float)mean;
-    final_stats[((int64_t)b * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    final_stats[((int64_t)b * groups + g) * 2 + 0] = fmean;
+    final_stats[((int64_t)b * groups + g) * 2 + 1] = frstd;
   }
+  // per-channel scale / shift of the apply pass, [b][2][C]: computed once here instead of by every one of its blocks
+  if (scsh)
+    for (int ch = lo + lane; ch < hi; ch += 64) {
+      const float sc = frstd * gamma[ch];
+      scsh[((int64_t)b * 2 + 0) * C + ch] = sc;
+      scsh[((int64_t)b * 2 + 1) * C + ch] = beta[ch] - fmean * sc;
+    }
 }
 
 // blocks of the apply pass over the whole batch (each block computes its per-lane scale / shift vectors before it streams: fewer, longer
@@ -469,11 +496,12 @@ int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float
 }
 
 int launch_gn_finalize(int c1, int c2, const float* part1, int wm1, const float* part2, int wm2, int b, int hw, int groups, float eps, float* final_stats,
-                       hipStream_t s) {
+                       hipStream_t s, const float* gamma, const float* beta, float* scsh) {
   ETAINV_CHECK(part1 && final_stats && (c1 + c2) % groups == 0 && groups <= 32, "bad arguments");
   ETAINV_CHECK(wm1 > 0 && hw % wm1 == 0 && (c2 == 0 || (part2 && wm2 > 0 && hw % wm2 == 0)), "row blocks must tile an image");
   ProfScope prof(PROF_GROUPNORM, 0.0, s);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((groups + 3) / 4, b), dim3(256), 0, s, part1, wm1, c1, part2, wm2, c2, hw, groups, eps, final_stats);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((groups + 3) / 4, b), dim3(256), 0, s, part1, wm1, c1, part2, wm2, c2, hw, groups, eps, final_stats, gamma, beta,
+                     scsh);
   ETAINV_LAUNCH_CHECK();
   return 0;
 }
@@ -488,13 +516,14 @@ int launch_groupnorm_pre(const void* x1, const void* x2, int c1, int c2, const f
   ETAINV_CHECK(wm1 > 0 && hw % wm1 == 0 && (c2 == 0 || (wm2 > 0 && hw % wm2 == 0)), "row blocks must tile an image");
   ProfScope prof(PROF_GROUPNORM, 2.0 * 2.0 * (double)b * hw * C, s);
   prof_pause(true);
-  const int rc = launch_gn_finalize(c1, c2, part1, wm1, part2, wm2, b, hw, groups, eps, final_stats, s);
+  float* scsh = final_stats + (int64_t)b * groups * 2;   // final_stats: [b][groups][2] (mean, rstd), then the scale / shift planes [b][2][C]
+  const int rc = launch_gn_finalize(c1, c2, part1, wm1, part2, wm2, b, hw, groups, eps, final_stats, s, gamma, beta, scsh);
   prof_pause(false);
   if (rc) return 1;
   const int chunks_apply = std::max(1, std::min(hw / 4, std::max(std::min(GN_MAX_CHUNKS, std::max(1, std::min(hw / 8, 1024 / std::max(1, b)))), gn_apply_blocks() / std::max(1, b))));
 #define ETAINV_GN_APPLY(VPL_)                                                                                                              \
   hipLaunchKernelGGL((gn_apply_kernel<T, VPL_>), dim3(chunks_apply, b), dim3(256), 0, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups,     \
-                     (const float*)final_stats, 0, (float)hw * (float)(C / groups), eps, gamma, beta, silu, (T*)out);
+                     (const float*)scsh, 0, (float)hw * (float)(C / groups), eps, (const float*)nullptr, (const float*)nullptr, silu, (T*)out);
   ETAINV_DISPATCH_HALF(dtype, T, switch (gn_apply_mode(C)) {
     case 0: ETAINV_GN_APPLY(0) break;
     case 1: ETAINV_GN_APPLY(1) break;

@@ -216,7 +216,8 @@ int etainv_op_ln_finalize(const float* partials, int p, int cw, float eps, float
 /* GroupNorm statistics from the producing GEMM's epilogue (reference: the GroupNorms of [3P] diffusers ResnetBlock2D / Transformer2DModel inside the
  * UNet call, eta_inversion.py:321): etainv_op_gemm_gnstat = etainv_op_gemm that also leaves per-channel (sum, sum of squares) partials of its stored
  * output, part[m / wm][2][n] (*wm_out rows per block; 0 = this launch shape emits none); etainv_op_groupnorm_pre = GroupNorm(+SiLU) of cat[x1, x2]
- * from such partials (no statistics pass over x). */
+ * from such partials (no statistics pass over x); final_stats: b * (2 * groups + 2 * (c1 + c2)) floats of scratch ((mean, rstd) per group, then the
+ * apply pass's per-channel scale / shift planes). */
 int etainv_op_gemm_gnstat(const void* a, const void* w, const float* bias, const void* residual, void* out, float* part, int* wm_out, int m,
                           int n, int k, int rows_per_image, int dtype, void* stream);
 int etainv_op_groupnorm_pre(const void* x1, const void* x2, int c1, int c2, const float* part1, int wm1, const float* part2, int wm2,

@@ -478,7 +478,7 @@ def test_groupnorm_from_producer_partials(capi, dtype, b, hw, c1, c2, silu, expe
     C_ = c1 + c2
     gamma, beta = rnd(C_, seed=2) * 0.1 + 1, rnd(C_, seed=3) * 0.1
     out = torch.empty(b, hw, C_, dtype=dtype, device="cuda")
-    final = torch.empty(b * 32 * 2, dtype=torch.float32, device="cuda")
+    final = torch.empty(b * (32 * 2 + 2 * C_), dtype=torch.float32, device="cuda")   # (mean, rstd) per group, then the scale / shift planes
     eps = 1e-5 if silu else 1e-6
     capi.check(lib.etainv_op_groupnorm_pre(capi.ptr(x1), capi.ptr(x2), c1, c2, capi.ptr(p1), w1, capi.ptr(p2), w2, capi.ptr(gamma), capi.ptr(beta),
                                            capi.ptr(out), b, hw, 32, eps, silu, capi.ptr(final), capi.dtype_code(dtype), capi.stream_ptr()))
@@ -488,8 +488,8 @@ def test_groupnorm_from_producer_partials(capi, dtype, b, hw, c1, c2, silu, expe
         ref = F.silu(ref)
     assert relerr(out, ref.permute(0, 2, 1)) < TOL[dtype]
     g = x.view(b, hw, 32, C_ // 32).permute(0, 2, 1, 3).reshape(b, 32, -1)
-    torch.testing.assert_close(final.view(b, 32, 2)[..., 0], g.mean(-1), rtol=1e-4, atol=1e-5)
-    torch.testing.assert_close(final.view(b, 32, 2)[..., 1], (g.var(-1, unbiased=False) + eps).rsqrt(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(final[: b * 64].view(b, 32, 2)[..., 0], g.mean(-1), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(final[: b * 64].view(b, 32, 2)[..., 1], (g.var(-1, unbiased=False) + eps).rsqrt(), rtol=1e-4, atol=1e-6)
 
 
 def test_gemm_gnstat_ragged_image_reports_none(capi):
