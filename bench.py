@@ -15,6 +15,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -69,13 +71,42 @@ def make_inputs(B, rank, dev, L=L):
     return z0, ctx_src, ctx_tgt, tokens, edit_word
 
 
-def cpu_baseline(S_cpu=2):
-    """The CPU oracle (fp32 PyTorch restatement, kind "port") on the same workload shape: 1 image, etainv + ptp, L = 64,
-    S_cpu of the 50 steps; per-step cost is constant, so images/s = 1 / (t * 50 / S_cpu).  Bounded to tens of seconds:
-    at most 32 threads (256 hardware threads oversubscribe PyTorch-CPU's small ops: measured 66 s per sample-forward)."""
+def host_cpu_info():
+    """os.cpu_count(), the lscpu model string and the physical-core count of this host."""
+    info = {"cpu_count": os.cpu_count() or 1, "model": None, "physical_cores": None, "sockets": None}
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {}
+        for ln in out.splitlines():
+            if ":" in ln:
+                k, v = ln.split(":", 1)
+                kv.setdefault(k.strip(), v.strip())      # (first occurrence: the per-NUMA-node lines repeat some keys)
+        info["model"] = kv.get("Model name")
+        sockets, cps = int(kv.get("Socket(s)", 0) or 0), int(kv.get("Core(s) per socket", 0) or 0)
+        if sockets and cps:
+            info["physical_cores"], info["sockets"] = sockets * cps, sockets
+    except Exception:
+        pass
+    try:                                                  # cores this process may actually run on (cgroup / affinity limits)
+        info["usable_threads"] = len(os.sched_getaffinity(0))
+    except Exception:
+        info["usable_threads"] = info["cpu_count"]
+    return info
+
+
+def cpu_baseline(S_cpu=5):
+    """The CPU oracle (fp32 PyTorch restatement, kind "port") on the same workload shape, as BASELINE.md section 3 lays it out: 1 image,
+    etainv + ptp, L = 64, S = 5 of the 50 steps end to end (30 UNet sample-forwards in the reference's call pattern), one warm-up UNet
+    forward, linear extrapolation to 50 steps (the per-step cost is constant), images/s = 1 / that.  Threads = the host's physical cores
+    (not its hardware threads: 256 SMT threads oversubscribe PyTorch-CPU's small ops, measured 66 s per sample-forward), capped by what this
+    process may run on and by ETAINV_CPU_THREADS.  A host where one sample-forward takes more than 2.5 s gets S = 2 so that the default bench
+    run stays within minutes; the JSON says which S was timed."""
     from oracle.unet import build_unet
     from oracle import loop as oloop, ptp as optp
-    cores = min(os.cpu_count() or 1, int(os.environ.get("ETAINV_CPU_THREADS", 32)))
+    host = host_cpu_info()
+    cores = min(host["physical_cores"] or host["cpu_count"], host["usable_threads"])
+    if os.environ.get("ETAINV_CPU_THREADS"):
+        cores = min(cores, int(os.environ["ETAINV_CPU_THREADS"]))
     torch.set_num_threads(cores)
     unet = build_unet(0)
     g = torch.Generator().manual_seed(1000)
@@ -83,14 +114,14 @@ def cpu_baseline(S_cpu=2):
     ctx_s, ctx_t = torch.randn(2, 77, 768, generator=g), torch.randn(2, 77, 768, generator=g)
     src, tgt = "a b c d e f g h", "a x c d e f g h"
     tok = optp.WordTokenizer()
-    noise = oloop.noise_table(S_cpu, 10, L, seed=0)
     with torch.no_grad():
         unet(z0, torch.tensor(1), encoder_hidden_states=ctx_s[:1])     # warm-up
         t0 = time.time()
         unet(z0, torch.tensor(1), encoder_hidden_states=ctx_s[:1])
-        if time.time() - t0 > 2.5:                                     # slow host: keep the sample within ~30 s
-            S_cpu = 1
-            noise = noise[:1]
+        t_fwd = time.time() - t0
+        if t_fwd > 2.5:                                                # slow host: keep the sample bounded
+            S_cpu = 2
+        noise = oloop.noise_table(S_cpu, 10, L, seed=0)
         t0 = time.time()
         o = oloop.EtaInversionOracle(unet, S=S_cpu, eta=[[0.6, 0], [1, 0.7]], L=L)
         inv = o.invert(z0, ctx_s, src)
@@ -99,8 +130,90 @@ def cpu_baseline(S_cpu=2):
         o.sample(inv, ctx_s, ctx_t, noise, edit_word_idx=(1, 1), controller=ctrl)
         dt = time.time() - t0
     return {"value": 1.0 / (dt * S_STEPS / S_cpu), "unit": "images/s", "cores": cores, "kind": "port",
+            "host": host, "steps_timed": S_cpu, "seconds_timed": dt, "seconds_extrapolated_S50": dt * S_STEPS / S_cpu,
+            "one_sample_forward_s": t_fwd,
             "sample": f"1 image, etainv+ptp 512x512, {S_cpu} of 50 DDIM steps on the CPU oracle (fp32, reference call pattern: "
-                      f"{6 * S_cpu} UNet sample-forwards) in {dt:.1f} s, extrapolated linearly to 50 steps"}
+                      f"{6 * S_cpu} UNet sample-forwards) in {dt:.1f} s on {cores} threads (= physical cores of {host['model']}), "
+                      f"extrapolated linearly to 50 steps"}
+
+
+def free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <argv>` as a child process (never exec: a process that may
+    initialise the GPU must not be replaced), relay rank 0's JSON line on stdout, everything else on stderr, and return the exit code:
+    the child's, or 1 when it exited 0 without a JSON line that reports n_gpus == n."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(Path(__file__).resolve())] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout:
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            try:
+                json.loads(t)
+                line = t
+                continue
+            except ValueError:
+                pass
+        sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc != 0:
+        print(f"bench.py: the {n}-rank child exited with code {rc}", file=sys.stderr)
+        return rc
+    if line is None or json.loads(line).get("n_gpus") != n:
+        print(f"bench.py: the {n}-rank child produced no JSON line with n_gpus == {n}", file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+def stub_main(a, world, rank):
+    """Tests only (`--stub`): the launcher, the rank protocol (barrier + synchronise on both sides of exactly K timed steps, MAX over ranks,
+    one JSON line from rank 0) and the final all_gather, over gloo on the CPU with a placeholder workload.  Never a bench line: data = "stub"."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "RANK" in os.environ:
+        dist.init_process_group("gloo")
+    on = dist.is_initialized()
+    g = torch.Generator().manual_seed(1000 + rank)
+    x = torch.randn(a.batch, 4, 8, 8, generator=g)
+
+    def one_step():
+        out = torch.tanh(x @ x.transpose(-1, -2))
+        if on:
+            gathered = [torch.empty_like(out) for _ in range(world)]
+            dist.all_gather(gathered, out)
+        return out
+
+    for _ in range(a.warmup):
+        one_step()
+    if on:
+        dist.barrier()
+    t0 = time.time()
+    for _ in range(a.steps):
+        one_step()
+    if on:
+        dist.barrier()
+    dt = time.time() - t0
+    if on:
+        tmax = torch.tensor([dt])
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": a.batch * world * a.steps / max(dt, 1e-9), "unit": "images/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "stub", "config": {"workload": "launcher / rank-protocol stub (gloo, CPU)"}}), flush=True)
+    if on:
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -112,6 +225,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="image pairs per GPU per step (default: the configuration's)")
     ap.add_argument("--dtype", default=None, choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # tests only: launcher / rank protocol over gloo, no engine, no GPU
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     if a.batch is None:
@@ -121,10 +235,23 @@ def main():
     L, S_STEPS, F_UNET_TFLOP = cfg["L"], cfg["S"], cfg["f_unet"]
     FWD_PER_IMAGE = 5 * S_STEPS
 
+    # `python bench.py --gpus N` with N > 1 and no torch.distributed.run environment: this process becomes the launcher (it has not touched
+    # the GPU: importing torch does not) and the N ranks run as its CHILD process tree; a rank count that differs from --gpus is an error,
+    # never a silent one-GPU run.
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus} "
+              f"(or plain `python bench.py --gpus {a.gpus}`, which starts the ranks itself)", file=sys.stderr)
+        sys.exit(2)
+    if a.stub:
+        return stub_main(a, world, rank)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+        print(f"bench.py: rank {rank} needs cuda:{local}; {torch.cuda.device_count()} device(s) visible -- no CPU fallback", file=sys.stderr)
+        sys.exit(3)
     dist = None
     if world > 1 or "RANK" in os.environ:          # under torch.distributed.run (also with one rank: exercises the RCCL path)
         import torch.distributed as dist
