@@ -873,16 +873,17 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
 }
 
 template <typename T, int D>
-static int launch_self_t(const void* qkv, void* out, int b, int n, int heads, int mode, int n_img, hipStream_t s) {
+static int launch_self_t(const void* qkv, void* out, int b, int n, int heads, int mode, int n_img, hipStream_t s, int q_prescaled = 0) {
   constexpr int QT = SELF_QT(D);
   constexpr int DP = (D + 31) / 32 * 32, DT = (D + 15) / 16;
   const size_t lds = (size_t)2 * (64 * (DP + 8) + DT * 16 * (64 + 8)) * sizeof(T);
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[kMaxDevices] = {};   // per device
+  const int dev = current_device();
+  if (!attr[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_kernel<T, D, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
+    attr[dev] = true;
   }
-  const float scale_log2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+  const float scale_log2 = q_prescaled ? 1.0f : (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
   ProfScope prof(PROF_SELF_ATTN, 4.0 * (double)b * heads * (double)n * (double)n * D, s);
   static const int stagger = getenv("ETAINV_ATT_STAGGER") ? atoi(getenv("ETAINV_ATT_STAGGER")) : 0;
   hipLaunchKernelGGL((self_attn_kernel<T, D, QT>), dim3(cdiv(n, 64 * QT), heads, b), dim3(256), lds, s, (const T*)qkv, (T*)out, n,
@@ -932,11 +933,11 @@ int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int hea
   if (d == 80 && self_attn40_v2_enabled() && v2_80) {
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 80, 1, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s)));
   }
-  ETAINV_CHECK(!q_prescaled, "pre-scaled queries need the 32x32x16 kernel");
+  // (the generic kernel takes pre-scaled queries with scale 1: ETAINV_ATT80_OLD sends head_dim 80 here while the engine still folds the scale into to_q)
   ETAINV_DISPATCH_HALF(dtype, T, switch (d) {
-    case 40: return launch_self_t<T, 40>(qkv, out, b, n, heads, mode, n_img, s);
-    case 80: return launch_self_t<T, 80>(qkv, out, b, n, heads, mode, n_img, s);
-    case 160: return launch_self_t<T, 160>(qkv, out, b, n, heads, mode, n_img, s);
+    case 40: return launch_self_t<T, 40>(qkv, out, b, n, heads, mode, n_img, s, q_prescaled);
+    case 80: return launch_self_t<T, 80>(qkv, out, b, n, heads, mode, n_img, s, q_prescaled);
+    case 160: return launch_self_t<T, 160>(qkv, out, b, n, heads, mode, n_img, s, q_prescaled);
     default: ETAINV_FAIL("head_dim must be 40, 80 or 160");
   });
   return 0;
@@ -948,11 +949,12 @@ static int launch_cross_t(const void* q, const void* kv, void* out, int b, const
   constexpr int DP = (D + 31) / 32 * 32, DT = (D + 15) / 16;
   const size_t lds_edit = (size_t)(2 * 96 * (DP + 8) + DT * 16 * (96 + 8)) * sizeof(T) + (size_t)(4 * QT * 16 * 81 + 4 * 80) * sizeof(float);
   const size_t lds_plain = (size_t)(96 * (DP + 8) + DT * 16 * (96 + 8)) * sizeof(T);
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[kMaxDevices] = {};   // per device
+  const int dev = current_device();
+  if (!attr[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn_kernel<T, D, QT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_edit);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn_kernel<T, D, QT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_plain);
-    attr = true;
+    attr[dev] = true;
   }
   ProfScope prof(PROF_CROSS_ATTN, 4.0 * (double)b * p.heads * (double)p.N * (double)p.n_ctx * D, s);
   const int nqb = cdiv(p.N, 64 * QT);

@@ -104,6 +104,14 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// one-time per-device state of the launchers (function attributes, zero pages, workspaces) is indexed by the current device
+constexpr int kMaxDevices = 16;
+static inline int current_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return (d >= 0 && d < kMaxDevices) ? d : 0;
+}
+
 // ---- opt-in per-kernel-class timing with HIP events on the launch stream (bench.py roofline numbers).
 // Off by default: the launchers then do nothing extra.  work = algorithmic FLOPs (MFMA kernels) or bytes (HBM-bound).
 enum ProfClass { PROF_IGEMM = 0, PROF_SELF_ATTN = 1, PROF_CROSS_ATTN = 2, PROF_GROUPNORM = 3, PROF_LAYERNORM = 4, PROF_OTHER = 5, PROF_NCLASS = 6 };

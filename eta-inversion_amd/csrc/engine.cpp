@@ -142,7 +142,8 @@ struct etainv_engine {
   bool gn_fold = false;
   bool ln_fused = true;
   bool ln_folded = false;   // the gamma-scaled consumer weights are packed (redone after any set_weight)
-  hipStream_t upload_stream = nullptr;   // stream of the last set_weight (the fold waits for it when the forward runs on another one)
+  std::vector<hipStream_t> upload_streams;   // streams weights were uploaded on since the last fold (the fold waits for each that is not the forward's)
+  uint64_t ctx_gen = 0, ctx_gen_cached = 0;  // caller's generation of the context buffer (etainv_engine_context_generation)
 };
 
 namespace {
@@ -692,14 +693,18 @@ extern "C" int etainv_engine_set_weight(etainv_engine_t* e, const char* name, co
   if ((!s.stage || s.stage_and_pack) && launch_pack_weight(data, s.dst, rows, cols, s.pack, s.taps, s.dst_dtype, (hipStream_t)stream, s.scale)) return 1;
   s.set = true;
   e->ln_folded = false;
-  e->upload_stream = (hipStream_t)stream;
+  bool seen = false;
+  for (hipStream_t u : e->upload_streams) seen = seen || u == (hipStream_t)stream;
+  if (!seen) e->upload_streams.push_back((hipStream_t)stream);
   return 0;
 }
 
 // gamma / beta of norm1/2/3 folded into the staged consumer weights of every transformer block (launch_ln_fold); runs on the forward's stream
 // before the first UNet call after the weights changed
 static int fold_layernorms(etainv_engine* e, hipStream_t s) {
-  if (e->upload_stream != s) ETAINV_HIP(hipStreamSynchronize(e->upload_stream));
+  for (hipStream_t u : e->upload_streams)
+    if (u != s) ETAINV_HIP(hipStreamSynchronize(u));
+  e->upload_streams.clear();
   for (const TBlock& t : e->tb) {
     const int64_t c = t.c, cc = c * c;
     for (int part = 0; part < 3; ++part)
@@ -727,11 +732,32 @@ extern "C" int etainv_engine_cache_context(etainv_engine_t* e, int enable) {
   return 0;
 }
 
+extern "C" int etainv_engine_context_generation(etainv_engine_t* e, uint64_t generation) {
+  ETAINV_CHECK(e, "null engine");
+  e->ctx_gen = generation;
+  return 0;
+}
+
 extern "C" int64_t etainv_engine_workspace_bytes(etainv_engine_t* e) { return e ? (int64_t)e->wsbytes : 0; }
 extern "C" int64_t etainv_engine_weight_bytes(etainv_engine_t* e) { return e ? (int64_t)e->wbytes : 0; }
 
+static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const int64_t* t_host, const void* ctx, int n_rows,
+                     const etainv_attn_ctrl* ctrl, void* out, int io_dtype, void* stream);
+
 extern "C" int etainv_unet_forward(etainv_engine_t* e, const void* latent, int n_lat, const int64_t* t_host, const void* ctx, int n_rows,
                                    const etainv_attn_ctrl* ctrl, void* out, int io_dtype, void* stream) {
+  if (unet_body(e, latent, n_lat, t_host, ctx, n_rows, ctrl, out, io_dtype, stream)) return 1;
+  if (e->ctx_cache_on) {
+    e->ctx_cached = ctx;
+    e->ctx_rows = n_rows;
+    e->ctx_io = io_dtype;
+    e->ctx_gen_cached = e->ctx_gen;
+  }
+  return 0;
+}
+
+static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const int64_t* t_host, const void* ctx, int n_rows,
+                     const etainv_attn_ctrl* ctrl, void* out, int io_dtype, void* stream) {
   ETAINV_CHECK(e && latent && t_host && ctx && out, "null argument");
   ETAINV_CHECK(n_rows >= 1 && n_rows <= e->maxB, "n_rows exceeds max_unet_batch");
   ETAINV_CHECK(n_lat >= 1 && n_rows % n_lat == 0, "n_rows must be a multiple of n_lat");
@@ -769,11 +795,11 @@ extern "C" int etainv_unet_forward(etainv_engine_t* e, const void* latent, int n
     p.rows_per_batch = n_rows;
     if (launch_igemm(p, e->dt, s)) return 1;
   }
-  f.kv_reuse = e->ctx_cache_on && e->ctx_cached == ctx && e->ctx_rows == n_rows && e->ctx_io == io_dtype;
+  f.kv_reuse = e->ctx_cache_on && e->ctx_cached == ctx && e->ctx_rows == n_rows && e->ctx_io == io_dtype && e->ctx_gen_cached == e->ctx_gen;
+  // the cache entry becomes valid only when this forward has enqueued every projection (set at the end of unet_body): an error half-way
+  // leaves it invalid, so the next call projects again
+  e->ctx_cached = nullptr;
   if (!f.kv_reuse && launch_cast_f32(ctx, io_dtype, e->ctxT, e->dt, (int64_t)n_rows * etainv_engine::kCtx * etainv_engine::kCtxDim, s)) return 1;
-  e->ctx_cached = e->ctx_cache_on ? ctx : nullptr;
-  e->ctx_rows = n_rows;
-  e->ctx_io = io_dtype;
 
   // ---- down path
   if (launch_im2col_in(latent, io_dtype, n_lat, n_rows, L, e->gnbuf, e->dt, s)) return 1;

@@ -37,12 +37,6 @@ template <> struct Mfma<bf16> {
 };
 
 constexpr int BK = 64;  // K elements per LDS tile (8 chunks of 16 B per row)
-constexpr int kMaxDevices = 16;
-static inline int current_device() {
-  int d = 0;
-  (void)hipGetDevice(&d);
-  return (d >= 0 && d < kMaxDevices) ? d : 0;
-}
 constexpr int64_t SPLITK_WS_BYTES = 64ll << 20;
 
 
@@ -508,7 +502,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
               sq[q] = row_sum16(sq[q]);
             }
             const int n = n0 + wn * WN + j * 16 + fq * 4;
-            if (fr == 0 && n < p.N) {
+            if (fr == 0 && n < p.N && mw < p.M) {   // (mw < M is wave-uniform: a wave tile entirely past M has no row block in stat_out)
               *reinterpret_cast<f32x4*>(gs + (rt * 2 + 0) * p.N + n) = sm;
               *reinterpret_cast<f32x4*>(gs + (rt * 2 + 1) * p.N + n) = sq;
             }
@@ -1180,6 +1174,7 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   ETAINV_CHECK(!p.rowvec || p.rowvec_stride >= p.N, "rowvec_stride");
   ETAINV_CHECK(!p.ln_stat || (p.ln_s && p.bias && p.taps == 1 && !p.a2), "folded LayerNorm: s / c vectors, plain GEMM");
   ETAINV_CHECK(!p.ln_stat || (!p.residual && !p.rowvec && !p.stat_out), "folded LayerNorm: no residual / row vector / statistics output on the consumer");
+  ETAINV_CHECK(!p.ln_stat || (!p.out_f32 && !p.out_nchw), "folded LayerNorm: the consumer stores the compute dtype, row-major (the fp32 / NCHW epilogues do not apply mean / rstd)");
   // tile choice: big tiles when they still fill the 256 CUs, else 64x64 (GEGLU pairing is per wave tile,
   // so the packing of a GEGLU weight fixes its tile: always 128 wide)
   const int64_t big_tiles = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128);

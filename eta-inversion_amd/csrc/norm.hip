@@ -464,11 +464,11 @@ int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float
   const int vpl = ((C >> 3) + 63) / 64;
 #define ETAINV_GN_LAUNCH(VPL_)                                                                                                             \
   {                                                                                                                                        \
-    static bool attr_ = false;                                                                                                             \
-    if (!attr_) {                                                                                                                          \
+    static bool attr_[kMaxDevices] = {};                                                                                                   \
+    if (!attr_[current_device()]) {                                                                                                        \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_stats_kernel<T, VPL_>), hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                 4 * 64 * VPL_ * 8 * 2 * 4);                                                                                 \
-      attr_ = true;                                                                                                                        \
+      attr_[current_device()] = true;                                                                                                      \
     }                                                                                                                                      \
     hipLaunchKernelGGL((gn_stats_kernel<T, VPL_>), dim3(chunks, b), dim3(256), lds, s, (const T*)x1, (const T*)x2, c1, c2, hw, groups, partial); \
   }

@@ -1,5 +1,6 @@
 """Python handle on the native UNet executor (csrc/engine.cpp) -- plumbing only: it owns nothing but the opaque
 engine pointer and passes device pointers of torch tensors through the C ABI."""
+import contextlib
 import ctypes as C
 import os
 
@@ -25,6 +26,8 @@ class AttnControl:
 
 
 class Engine:
+    _ctx_generation = 0
+
     def __init__(self, dtype=torch.float16, max_unet_batch=4, latent_size=64, max_img=1, device="cuda:0"):
         if not torch.cuda.is_available():
             raise _capi.EtainvError("no HIP device: the etainv engine has no CPU fallback")
@@ -126,6 +129,18 @@ class Engine:
     def cache_context(self, enable):
         """loops that pass one unchanged context tensor to every UNet call: reuse its cross-attention K / V projections (off when the loop ends)"""
         _capi.check(self.lib.etainv_engine_cache_context(self.h, int(bool(enable))))
+
+    @contextlib.contextmanager
+    def cached_context(self):
+        """`with engine.cached_context():` around a loop whose UNet calls all pass the same, unchanged context tensor.  A fresh generation per
+        loop (an allocator may hand a new tensor the old address) and the cache is switched off on every exit path, exceptions included."""
+        Engine._ctx_generation += 1
+        _capi.check(self.lib.etainv_engine_context_generation(self.h, Engine._ctx_generation))
+        self.cache_context(True)
+        try:
+            yield
+        finally:
+            self.cache_context(False)
 
     def local_blend(self, x, n_img, blend_alpha, thres=0.3):
         assert x.dtype == torch.float32

@@ -99,21 +99,20 @@ class EtaLoop:
             e.maps_reset()
         n = B * 4 * L * L
         st = _capi.stream_ptr()
-        e.cache_context(True)                                   # one context tensor for all S calls
-        for j, t in enumerate(self.t_fwd):
-            x_in = lat[j] if teacher is None else teacher[j].contiguous()
-            e.unet(x_in, int(t), ctx, ctrl, out=eps_all)
-            if not self.skip_uncond_fwd:
-                g = float(self.g_fwd_table[int(t)]) if self.g_fwd_table is not None else self.g_fwd
-                _capi.check(self.lib.etainv_cfg_combine(_capi.ptr(eps_all[:B]), _capi.ptr(eps_all[B:]), g, _capi.ptr(eps), n,
-                                                        _capi.F32, st))
-            a_from, a_to = self._alpha(int(t) - self.delta), self._alpha(int(t))   # "sameshift" (scheduling_ddim_inverse.py:127-131)
-            _capi.check(self.lib.etainv_ddim_step(_capi.ptr(x_in), _capi.ptr(eps), a_from, a_to, _capi.ptr(lat[j + 1]), n, _capi.F32, st))
-            if self.use_mask:
-                e.word_maps(B, tokens, j + 1, maps_mean, accumulate=True, scale=1.0 / S)
-                if maps_steps is not None:
-                    e.word_maps(B, tokens, j + 1, maps_steps[j], accumulate=False, scale=1.0)
-        e.cache_context(False)
+        with e.cached_context():                               # one unchanged context tensor for all S calls
+            for j, t in enumerate(self.t_fwd):
+                x_in = lat[j] if teacher is None else teacher[j].contiguous()
+                e.unet(x_in, int(t), ctx, ctrl, out=eps_all)
+                if not self.skip_uncond_fwd:
+                    g = float(self.g_fwd_table[int(t)]) if self.g_fwd_table is not None else self.g_fwd
+                    _capi.check(self.lib.etainv_cfg_combine(_capi.ptr(eps_all[:B]), _capi.ptr(eps_all[B:]), g, _capi.ptr(eps), n,
+                                                            _capi.F32, st))
+                a_from, a_to = self._alpha(int(t) - self.delta), self._alpha(int(t))   # "sameshift" (scheduling_ddim_inverse.py:127-131)
+                _capi.check(self.lib.etainv_ddim_step(_capi.ptr(x_in), _capi.ptr(eps), a_from, a_to, _capi.ptr(lat[j + 1]), n, _capi.F32, st))
+                if self.use_mask:
+                    e.word_maps(B, tokens, j + 1, maps_mean, accumulate=True, scale=1.0 / S)
+                    if maps_steps is not None:
+                        e.word_maps(B, tokens, j + 1, maps_steps[j], accumulate=False, scale=1.0)
         return {"latents": lat, "maps_mean": maps_mean, "maps_steps": maps_steps}
 
     # ---------------------------------------------------------------- backward / eta sampling
@@ -174,38 +173,37 @@ class EtaLoop:
         if ptp is not None:
             e.maps_reset()
         st = _capi.stream_ptr()
-        e.cache_context(True)                                   # one context tensor for all S calls
-        for i, t in enumerate(self.t_bwd):
-            t = int(t)
-            ctrl = None
-            if ptp is not None:
-                ctrl = AttnControl(mode=_capi.ATTN_PTP, n_img=B, store_maps=True, mapper=ptp.mapper, alphas=ptp.alphas,
-                                   replace_mat=ptp.replace_mat, equalizer=ptp.equalizer, cross_alpha=ptp.cross_alpha[i],
-                                   self_replace_active=ptp.self_lo <= i < ptp.self_hi, self_max_tokens=(L // 2) ** 2)
-            elif masactrl is not None:
-                ctrl = AttnControl(mode=_capi.ATTN_MASA, n_img=B, masa_active=masactrl[0] <= i < 50, masa_first_block=masactrl[1])
-            if teacher is not None:
-                x.copy_(teacher[i])
-            e.unet(x, t, ctx, ctrl, out=eps_all)
-            p = t - self.delta
-            a_t, a_p = float(self.ac[t]), (float(self.ac[p]) if p >= 0 else float(self.ac[0]))
-            var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
-            dmap = None
-            if self.use_mask:
-                raw = src_map(self.mask_eta, i)
-                mask_map = shaped(raw) if mask_mode == 2 else raw.contiguous()      # mode 1: the kernel thresholds the raw forward-mean map
-                if self.target_dirinv is not None and self.mask_dirinv is not None:  # 1 - shaped map of the mask_dirinv source (eta_inversion.py:234-256)
-                    dmap = (1.0 - shaped(raw if self.mask_dirinv == self.mask_eta else src_map(self.mask_dirinv, i))).contiguous()
-            _capi.check(self.lib.etainv_eta_backward_step_ex(
-                _capi.ptr(x), _capi.ptr(eps_all), self.g_bwd, _capi.ptr(lat_inv[S - 1 - i]), _capi.ptr(noise[i]), self.n_cand,
-                float(self.etas[t]), _capi.ptr(mask_map), float(self.mask_thres or 0.0), mask_mode, a_t, a_p, var, B, 4, L * L,
-                _capi.ptr(x_new), None, _capi.ptr(best), None, _capi.ptr(scratch), _capi.F32, float(self.target_dirinv or 0.0), _capi.ptr(dmap), st))
-            x, x_new = x_new, x
-            if ptp is not None and ptp.blend_alpha is not None and (i + 1) > int(0.2 * S):
-                e.local_blend(x, B, ptp.blend_alpha, 0.3)                       # LocalBlend, reference ptp.py:31-47
-            if trace is not None:
-                trace.append({"t": t, "latent": x.clone(), "best": best.clone(), "eps_all": eps_all.clone()})
-        e.cache_context(False)
+        with e.cached_context():                               # one unchanged context tensor for all S calls
+            for i, t in enumerate(self.t_bwd):
+                t = int(t)
+                ctrl = None
+                if ptp is not None:
+                    ctrl = AttnControl(mode=_capi.ATTN_PTP, n_img=B, store_maps=True, mapper=ptp.mapper, alphas=ptp.alphas,
+                                       replace_mat=ptp.replace_mat, equalizer=ptp.equalizer, cross_alpha=ptp.cross_alpha[i],
+                                       self_replace_active=ptp.self_lo <= i < ptp.self_hi, self_max_tokens=(L // 2) ** 2)
+                elif masactrl is not None:
+                    ctrl = AttnControl(mode=_capi.ATTN_MASA, n_img=B, masa_active=masactrl[0] <= i < 50, masa_first_block=masactrl[1])
+                if teacher is not None:
+                    x.copy_(teacher[i])
+                e.unet(x, t, ctx, ctrl, out=eps_all)
+                p = t - self.delta
+                a_t, a_p = float(self.ac[t]), (float(self.ac[p]) if p >= 0 else float(self.ac[0]))
+                var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
+                dmap = None
+                if self.use_mask:
+                    raw = src_map(self.mask_eta, i)
+                    mask_map = shaped(raw) if mask_mode == 2 else raw.contiguous()      # mode 1: the kernel thresholds the raw forward-mean map
+                    if self.target_dirinv is not None and self.mask_dirinv is not None:  # 1 - shaped map of the mask_dirinv source (eta_inversion.py:234-256)
+                        dmap = (1.0 - shaped(raw if self.mask_dirinv == self.mask_eta else src_map(self.mask_dirinv, i))).contiguous()
+                _capi.check(self.lib.etainv_eta_backward_step_ex(
+                    _capi.ptr(x), _capi.ptr(eps_all), self.g_bwd, _capi.ptr(lat_inv[S - 1 - i]), _capi.ptr(noise[i]), self.n_cand,
+                    float(self.etas[t]), _capi.ptr(mask_map), float(self.mask_thres or 0.0), mask_mode, a_t, a_p, var, B, 4, L * L,
+                    _capi.ptr(x_new), None, _capi.ptr(best), None, _capi.ptr(scratch), _capi.F32, float(self.target_dirinv or 0.0), _capi.ptr(dmap), st))
+                x, x_new = x_new, x
+                if ptp is not None and ptp.blend_alpha is not None and (i + 1) > int(0.2 * S):
+                    e.local_blend(x, B, ptp.blend_alpha, 0.3)                       # LocalBlend, reference ptp.py:31-47
+                if trace is not None:
+                    trace.append({"t": t, "latent": x.clone(), "best": best.clone(), "eps_all": eps_all.clone()})
         return x
 
 

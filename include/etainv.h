@@ -176,6 +176,10 @@ int etainv_local_blend(etainv_engine_t* e, float* x, int n_img, const float* ble
  * pointer, row count and dtype equal the previous call's -- the caller promises not to change the buffer's contents in between and switches the
  * cache off (enable = 0) when the loop ends.  Off by default: every call projects the context it is given. */
 int etainv_engine_cache_context(etainv_engine_t* e, int enable);
+/* Generation of the context buffer: a cached projection is reused only while the generation equals the one it was computed under.  A caller
+ * that rewrites the context tensor IN PLACE between two calls (same pointer, rows, dtype) bumps it; the built-in loops pass a fresh value per
+ * loop.  The cache entry is recorded only after a forward has succeeded: an error half-way never leaves stale K / V behind. */
+int etainv_engine_context_generation(etainv_engine_t* e, uint64_t generation);
 int64_t etainv_engine_workspace_bytes(etainv_engine_t* e);
 int64_t etainv_engine_weight_bytes(etainv_engine_t* e);
 

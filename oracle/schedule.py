@@ -176,3 +176,43 @@ class DpmStepper:
         self.prev_m = m0
         self.n_lower = min(self.n_lower + 1, 2)
         return out
+
+
+class DpmInverseStepper:
+    """The reference's DPMSolverMultistepInverseScheduler.step (modules/inverse_schedulers/scheduling_dpmsolver_multistep_inverse.py:83-159)
+    with its `inv_steps` modes, over the restated solver pieces above.  PINNED by tests/golden/dpm_inverse.npz (the reference's own class run
+    over a restated [3P] solver, tests/golden/make_golden.py gen_dpm_inverse).
+      samesame   the solver's ascending grid as is
+      sameshift  the UNet is evaluated at grid[i] but the solver steps from grid[i-1] (first step: from the "first negative step"
+                 grid[0] - (grid[1] - grid[0]), :73-80, :110-113)
+      shiftshift the grid itself is shifted one step back (:57-63)
+    Negative timesteps index the 1000-entry tables from the end and a step index of -1 / 0 makes `timesteps[step_index - 1]` wrap, exactly as
+    the reference's tensor indexing does."""
+
+    def __init__(self, ac, S: int, inv_steps: str = "samesame", spacing: str = "leading", lower_order_final: bool = True):
+        assert inv_steps in ("samesame", "sameshift", "shiftshift")
+        self.tabs, self.mode, self.lof = dpm_tables(ac), inv_steps, lower_order_final
+        grid = [int(t) for t in dpm_timesteps_forward(S, spacing)]
+        self.first_neg = grid[0] - (grid[1] - grid[0])                        # get_first_neg_step of the UNSHIFTED grid (:62)
+        if inv_steps == "shiftshift":
+            grid = [self.first_neg] + grid[:-1]
+        self.grid, self.noisiest = grid, NUM_TRAIN - 1
+        self.m, self.n_lower = [None, None], 0
+
+    def step(self, eps, t: int, x):
+        g, n = self.grid, len(self.grid)
+        i = g.index(int(t)) if int(t) in g else n - 1
+        ts = int(t)
+        if self.mode == "sameshift":
+            i -= 1
+            ts = g[i] if i >= 0 else g[0] - (g[1] - g[0])                     # get_first_neg_step on the current grid (:73-80)
+        nxt = self.noisiest if i == n - 1 else g[i + 1]
+        final = i == n - 1 and self.lof and n < 15
+        m0 = dpm_x0(x, eps, self.tabs, ts)
+        self.m = [self.m[1], m0]
+        if self.n_lower < 1 or final:
+            out = dpm_first_order(x, m0, self.tabs, ts, nxt)
+        else:
+            out = dpm_second_order(x, m0, self.m[0], self.tabs, g[i - 1], ts, nxt)
+        self.n_lower = min(self.n_lower + 1, 2)
+        return out

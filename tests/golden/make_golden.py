@@ -98,6 +98,74 @@ class DDIMScheduler:
         return types.SimpleNamespace(prev_sample=prev, pred_original_sample=x0)
 
 
+class DPMSolverMultistepInverseSchedulerStub:
+    """[3P] diffusers 0.21.1 DPMSolverMultistepInverseScheduler, restated (what the reference's wrapper touches: config, tables as fp32
+    tensors, set_timesteps incl. noisiest_timestep, convert_model_output, the first / second order updates, model_outputs,
+    lower_order_nums) for epsilon prediction, "dpmsolver++", midpoint, no Karras sigmas, no thresholding."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", solver_order=2,
+                 prediction_type="epsilon", algorithm_type="dpmsolver++", solver_type="midpoint", lower_order_final=True,
+                 lambda_min_clipped=-float("inf"), timestep_spacing="linspace", steps_offset=0, **kw):
+        assert beta_schedule == "scaled_linear" and prediction_type == "epsilon" and algorithm_type == "dpmsolver++" and solver_type == "midpoint"
+        self.config = _Cfg(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end, beta_schedule=beta_schedule,
+                           solver_order=solver_order, prediction_type=prediction_type, algorithm_type=algorithm_type, solver_type=solver_type,
+                           lower_order_final=lower_order_final, lambda_min_clipped=lambda_min_clipped, timestep_spacing=timestep_spacing,
+                           steps_offset=steps_offset, **kw)
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.alpha_t = torch.sqrt(self.alphas_cumprod)
+        self.sigma_t = torch.sqrt(1 - self.alphas_cumprod)
+        self.lambda_t = torch.log(self.alpha_t) - torch.log(self.sigma_t)
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.linspace(0, num_train_timesteps - 1, num_train_timesteps, dtype=np.float32).copy())
+        self.model_outputs = [None] * solver_order
+        self.lower_order_nums = 0
+
+    @classmethod
+    def from_config(cls, config):
+        return cls(**{k: v for k, v in dict(config).items() if k not in ("clip_sample", "set_alpha_to_one")})
+
+    def set_timesteps(self, num_inference_steps=None, device=None):
+        clipped_idx = torch.searchsorted(torch.flip(self.lambda_t, [0]), self.config.lambda_min_clipped).item()
+        self.noisiest_timestep = self.config.num_train_timesteps - 1 - clipped_idx
+        if self.config.timestep_spacing == "linspace":
+            timesteps = np.linspace(0, self.noisiest_timestep, num_inference_steps + 1).round()[:-1].copy().astype(np.int64)
+        elif self.config.timestep_spacing == "leading":
+            step_ratio = (self.noisiest_timestep + 1) // (num_inference_steps + 1)
+            timesteps = (np.arange(0, num_inference_steps + 1) * step_ratio).round()[:-1].copy().astype(np.int64)
+            timesteps += self.config.steps_offset
+        else:
+            raise ValueError(self.config.timestep_spacing)
+        _, unique_indices = np.unique(timesteps, return_index=True)
+        timesteps = timesteps[np.sort(unique_indices)]
+        self.timesteps = torch.from_numpy(timesteps)
+        self.num_inference_steps = len(timesteps)
+        self.model_outputs = [None] * self.config.solver_order
+        self.lower_order_nums = 0
+
+    def convert_model_output(self, model_output, timestep, sample):
+        alpha_t, sigma_t = self.alpha_t[timestep], self.sigma_t[timestep]
+        return (sample - sigma_t * model_output) / alpha_t
+
+    def dpm_solver_first_order_update(self, model_output, timestep, prev_timestep, sample, noise=None):
+        lambda_t, lambda_s = self.lambda_t[prev_timestep], self.lambda_t[timestep]
+        alpha_t = self.alpha_t[prev_timestep]
+        sigma_t, sigma_s = self.sigma_t[prev_timestep], self.sigma_t[timestep]
+        h = lambda_t - lambda_s
+        return (sigma_t / sigma_s) * sample - (alpha_t * (torch.exp(-h) - 1.0)) * model_output
+
+    def multistep_dpm_solver_second_order_update(self, model_output_list, timestep_list, prev_timestep, sample, noise=None):
+        t, s0, s1 = prev_timestep, timestep_list[-1], timestep_list[-2]
+        m0, m1 = model_output_list[-1], model_output_list[-2]
+        lambda_t, lambda_s0, lambda_s1 = self.lambda_t[t], self.lambda_t[s0], self.lambda_t[s1]
+        alpha_t = self.alpha_t[t]
+        sigma_t, sigma_s0 = self.sigma_t[t], self.sigma_t[s0]
+        h, h_0 = lambda_t - lambda_s0, lambda_s0 - lambda_s1
+        r0 = h_0 / h
+        D0, D1 = m0, (1.0 / r0) * (m0 - m1)
+        return (sigma_t / sigma_s0) * sample - (alpha_t * (torch.exp(-h) - 1.0)) * D0 - 0.5 * (alpha_t * (torch.exp(-h) - 1.0)) * D1
+
+
 class _Dummy:
     def __init__(self, *a, **k):
         pass
@@ -105,7 +173,7 @@ class _Dummy:
 
 def install_stubs():
     _mod("diffusers", DDIMScheduler=DDIMScheduler, DDPMScheduler=_Dummy, DPMSolverMultistepScheduler=_Dummy,
-         StableDiffusionPipeline=_Dummy)
+         DPMSolverMultistepInverseScheduler=DPMSolverMultistepInverseSchedulerStub, StableDiffusionPipeline=_Dummy)
     _mod("diffusers.schedulers")
     _mod("diffusers.schedulers.scheduling_ddim", False, DDIMSchedulerOutput=_Dummy)
     _mod("diffusers.pipelines")
@@ -609,9 +677,47 @@ def gen_resnet_block():
     save("resnet_block", **out)
 
 
+def gen_dpm_inverse():
+    """The reference's OWN DPMSolverMultistepInverseScheduler (modules/inverse_schedulers/scheduling_dpmsolver_multistep_inverse.py:10-159:
+    step-index lookup, the "sameshift" / "shiftshift" timestep shifts incl. the negative first timestep, prev_timestep / noisiest_timestep,
+    order selection, model_outputs history) over the restated [3P] solver above, built the way DiffusionInversion.create_schedulers does
+    (diffusion_inversion.py:139-165: from_config of the model's DDIM scheduler config).  Free-running recursion over all S steps on seeded
+    noise predictions; the test regenerates x0 / eps from the seed (probes stored)."""
+    import contextlib
+    import io
+    from modules.inverse_schedulers import DPMSolverMultistepInverseScheduler
+    out = {}
+    # [3P] diffusers 0.21.1's DDIMScheduler config carries timestep_spacing = "leading" (its default), which from_config hands to the DPM
+    # scheduler -- the DDIMScheduler stub above has no such key, so it is added here; "linspace" (the DPM class's own default) is generated
+    # as a second case
+    for S, spacing in ((10, "leading"), (10, "linspace"), (50, "leading")):
+        base_cfg = {**dict(make_pipe(None).scheduler.config), "timestep_spacing": spacing}
+        fake_bwd = types.SimpleNamespace(config=base_cfg)
+        for mode in ("samesame", "sameshift", "shiftshift"):
+            key = f"S{S}_{spacing}_{mode}"
+            sch = DPMSolverMultistepInverseScheduler.from_scheduler(fake_bwd, inv_steps=mode)
+            sch.set_timesteps(S)
+            ts = [int(t) for t in sch.timesteps]
+            g = torch.Generator().manual_seed(1000 * S + len(mode))
+            x = torch.randn(1, 4, 8, 8, generator=g, dtype=torch.float64)
+            out[f"{key}_timesteps"] = np.asarray(ts, dtype=np.int64)
+            out[f"{key}_x0_probe"] = x.flatten()[:4].clone()
+            xs = []
+            with contextlib.redirect_stdout(io.StringIO()):              # (the reference prints "t -> prev_t" every step)
+                for j, t in enumerate(sch.timesteps):
+                    eps = torch.randn(1, 4, 8, 8, generator=g, dtype=torch.float64)
+                    x = sch.step(eps, t, x).prev_sample
+                    xs.append(x.to(torch.float64))
+            out[f"{key}_eps_last_probe"] = eps.flatten()[:4].clone()
+            keep = list(range(S)) if S <= 10 else [0, 1, 2, 3, S // 2, S - 2, S - 1]
+            out[f"{key}_steps"] = np.asarray(keep, dtype=np.int64)
+            out[f"{key}_x"] = torch.stack([xs[j] for j in keep])
+    save("dpm_inverse", **out)
+
+
 GENS = {"schedule": gen_schedule, "ddim_inverse": gen_ddim_inverse, "eta_step": gen_eta_step, "eta_step_modes": gen_eta_step_modes, "eta_step_dirinv": gen_eta_step_dirinv,
         "ptp_tables": gen_ptp_tables, "ptp_algebra": gen_ptp_algebra, "masactrl": gen_masactrl, "e2e": gen_e2e, "e2e_dirinv": gen_e2e_dirinv, "e2e_bwdmask": gen_e2e_bwdmask, "pie_bench": gen_pie_bench,
-        "resnet_block": gen_resnet_block, "e2e_diffinv": gen_e2e_diffinv}
+        "resnet_block": gen_resnet_block, "e2e_diffinv": gen_e2e_diffinv, "dpm_inverse": gen_dpm_inverse}
 
 
 if __name__ == "__main__":

@@ -262,6 +262,27 @@ def test_dpm_solver_schedulers_vs_oracle():
         torch.testing.assert_close(xn.cpu().double(), xr, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("S,spacing", [(10, "leading"), (10, "linspace"), (50, "leading")])
+@pytest.mark.parametrize("mode", ["samesame", "sameshift", "shiftshift"])
+def test_dpm_inverse_scheduler_vs_reference_golden(golden, S, spacing, mode):
+    """The native DPMSolverMultistepInverseScheduler (latent updates = etainv_lincomb3 on the device) vs the reference's own class
+    (tests/golden/dpm_inverse.npz: modules/inverse_schedulers/scheduling_dpmsolver_multistep_inverse.py:10-159 run free over S steps), all three
+    `inv_steps` modes incl. the negative first timestep of the shifted ones, fp32 latents."""
+    from modules.schedulers import DDIMScheduler, DPMSolverMultistepScheduler
+    from modules.inverse_schedulers import DPMSolverMultistepInverseScheduler
+    from tests.test_oracle_golden import dpm_golden_run
+    g = golden("dpm_inverse")
+    bwd = DPMSolverMultistepScheduler.from_config({**DDIMScheduler().config, "timestep_spacing": spacing})
+
+    def make(ts):
+        fwd = DPMSolverMultistepInverseScheduler.from_scheduler(bwd, inv_steps=mode)
+        fwd.set_timesteps(S)
+        assert [int(t) for t in fwd.timesteps] == ts.tolist()
+        return lambda eps, t, x: fwd.step(eps.cuda(), torch.tensor(t), x.cuda()).prev_sample
+
+    assert dpm_golden_run(g, S, spacing, mode, make, dtype=torch.float32) < 2e-5
+
+
 def test_diffinv_dpm_plugin_vs_oracle():
     """`diffinv --scheduler dpm` + simple editor through the plugin API vs the oracle loop driven by the oracle's DPM steppers"""
     from modules import load_diffusion_model, load_inverter, load_editor

@@ -329,3 +329,42 @@ def test_diffinv_vs_reference(golden, toy_unet):
     np.testing.assert_allclose(z[:1].numpy(), g["pair/latent_inv"], rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(z[1:].numpy(), g["pair/latent"], rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(zt.numpy(), g["target_only/latent"], rtol=1e-3, atol=2e-4)
+
+
+DPM_CASES = [(10, "leading"), (10, "linspace"), (50, "leading")]
+
+
+def dpm_golden_run(g, S, spacing, mode, make_step, dtype=torch.float64):
+    """Regenerates the seeded x0 / eps of tests/golden/make_golden.py gen_dpm_inverse and runs `make_step(timesteps)` -> step(eps, t, x) over all S
+    steps (free-running); returns the worst relative max-abs error over the stored steps."""
+    key = f"S{S}_{spacing}_{mode}"
+    ts = g[f"{key}_timesteps"]
+    gen = torch.Generator().manual_seed(1000 * S + len(mode))
+    x = torch.randn(1, 4, 8, 8, generator=gen, dtype=torch.float64)
+    np.testing.assert_array_equal(x.flatten()[:4].numpy(), g[f"{key}_x0_probe"])
+    step = make_step(ts)
+    xs = []
+    x = x.to(dtype)
+    for t in ts:
+        eps = torch.randn(1, 4, 8, 8, generator=gen, dtype=torch.float64)
+        x = step(eps.to(dtype), int(t), x)
+        xs.append(x)
+    np.testing.assert_array_equal(eps.flatten()[:4].numpy(), g[f"{key}_eps_last_probe"])
+    ref = g[f"{key}_x"]
+    return max(float(np.abs(xs[j].detach().cpu().double().numpy() - ref[k]).max() / np.abs(ref[k]).max()) for k, j in enumerate(g[f"{key}_steps"]))
+
+
+@pytest.mark.parametrize("S,spacing", DPM_CASES)
+@pytest.mark.parametrize("mode", ["samesame", "sameshift", "shiftshift"])
+def test_dpm_inverse_vs_reference_class(golden, S, spacing, mode):
+    """oracle.schedule.DpmInverseStepper vs the reference's own DPMSolverMultistepInverseScheduler (run over a restated [3P] solver whose tables are
+    fp32 tensors, hence 1e-5 and not 1e-12): timestep grids equal, every stored step of the free-running recursion equal."""
+    g = golden("dpm_inverse")
+    ac = sch.alphas_cumprod()
+
+    def make(ts):
+        st = sch.DpmInverseStepper(ac, S, mode, spacing)
+        assert st.grid == ts.tolist()
+        return st.step
+
+    assert dpm_golden_run(g, S, spacing, mode, make) < 1e-5

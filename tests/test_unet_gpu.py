@@ -128,3 +128,33 @@ def test_context_cache_reuses_projections_and_tracks_changes(engines):
     finally:
         e.cache_context(False)
     assert torch.equal(e.unet(x, 300, c1), ref1)
+
+
+def test_context_cache_generation_and_error_paths(engines):
+    """ADVICE r2 / VERDICT r2 item 10: (i) a context rewritten IN PLACE is picked up when the caller bumps the generation
+    (etainv_engine_context_generation) -- and, documented, NOT picked up otherwise; (ii) `with engine.cached_context()` switches the cache off on
+    an exception; (iii) a forward that fails validation does not leave a cache entry behind."""
+    from etainv import _capi
+    e = engines(torch.float16, 16)
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(2, 4, 16, 16, generator=g).cuda()
+    c1, c2 = torch.randn(4, 77, 768, generator=g).cuda(), torch.randn(4, 77, 768, generator=g).cuda()
+    ref1, ref2 = e.unet(x, 300, c1).clone(), e.unet(x, 300, c2).clone()
+    buf = c1.clone()
+    with e.cached_context():
+        assert torch.equal(e.unet(x, 300, buf), ref1)
+        buf.copy_(c2)                                                       # same pointer, rows, dtype -- new contents
+        assert torch.equal(e.unet(x, 300, buf), ref1)                       # the promise "unchanged" was broken: stale K / V (by contract)
+        _capi.check(e.lib.etainv_engine_context_generation(e.h, 1 << 40))   # the caller says so: recomputed
+        assert torch.equal(e.unet(x, 300, buf), ref2)
+    with pytest.raises(RuntimeError):
+        with e.cached_context():
+            e.unet(x, 300, buf)
+            raise RuntimeError("loop body failed")
+    buf.copy_(c1)                                                           # the cache must be off now: every call projects what it is given
+    assert torch.equal(e.unet(x, 300, buf), ref1)
+    with e.cached_context():
+        big = torch.randn(16, 77, 768, generator=g).cuda()                  # 16 rows > max_unet_batch = 8: the call fails before any launch
+        with pytest.raises(_capi.EtainvError):
+            e.unet(x, 300, big)
+        assert torch.equal(e.unet(x, 300, buf), ref1)
