@@ -117,9 +117,10 @@ class EtaInversionOracle:
         return u + g * (c - u)
 
     # eta_inversion.py:378-404 + diffusion_inversion.py:388-418
-    def invert(self, z0, context, prompt):
+    def invert(self, z0, context, prompt, teacher=None):
         """context (2,77,768) = [uncond, cond]; one map per whitespace word of `prompt`; a repeated word
-        reuses the token of its FIRST occurrence (`prompt.split(' ').index(word)`, ptp_editor.py:72)."""
+        reuses the token of its FIRST occurrence (`prompt.split(' ').index(word)`, ptp_editor.py:72).
+        teacher (list of S+1 latents, precision-floor runs only): step j starts from teacher[j] instead of this run's own latent."""
         words = prompt.split(" ")
         n_words = len(words)
         tok_idx = [words.index(w) + 1 for w in words]
@@ -130,7 +131,9 @@ class EtaInversionOracle:
         latent = z0.clone()
         latents, noise_preds, maps_per_t = [z0], [], {}
         try:
-            for t in self.t_fwd:
+            for j, t in enumerate(self.t_fwd):
+                if teacher is not None:
+                    latent = teacher[j].clone()
                 eps = self.predict_noise(latent, t, context, float(self.g_fwd[int(t)]) if isinstance(self.g_fwd, np.ndarray) else self.g_fwd)
                 a_from, a_to = sch.ddim_inverse_coeffs(self.ac, int(t), self.S)
                 latent = sch.ddim_step(latent, eps, a_from, a_to)
@@ -219,9 +222,10 @@ class EtaInversionOracle:
 
     # diffusion_inversion.py:493-528 + eta_inversion.py:275-294
     def sample(self, inv, ctx_src, ctx_tgt, noise_table, edit_word_idx=None, controller=None, masactrl=None,
-               trace=None, gt_mask=None):
+               trace=None, gt_mask=None, teacher=None):
         """noise_table: (S, n, 1, 4, L, L) -- the candidates `sample_variance_noise` would draw at each
-        step from the per-image generator (eta_inversion.py:156,276), injected for reproducibility."""
+        step from the per-image generator (eta_inversion.py:156,276), injected for reproducibility.
+        teacher (list of S latents (2,4,L,L), precision-floor runs only): step i starts from teacher[i]."""
         context = torch.stack([ctx_src, ctx_tgt], 1).reshape(4, *ctx_src.shape[1:])   # [u_s,u_t,c_s,c_t]
         self._edit_word_idx = edit_word_idx
         latent = torch.cat([inv["latents"][-1]] * 2)
@@ -231,6 +235,8 @@ class EtaInversionOracle:
             self.unet.set_ctrl(masactrl)
         try:
             for i, t in enumerate(self.t_bwd):
+                if teacher is not None:
+                    latent = teacher[i].clone()
                 mask_map = dirinv_map = None
                 if self.use_mask and not self.mask_eta.startswith("bwd"):
                     mask_map = self.source_map(self.mask_eta, t, inv, gt_mask, controller)

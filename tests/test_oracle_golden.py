@@ -368,3 +368,22 @@ def test_dpm_inverse_vs_reference_class(golden, S, spacing, mode):
         return st.step
 
     assert dpm_golden_run(g, S, spacing, mode, make) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_lowprec_emulation_matches_cpu_half(dtype):
+    """oracle/lowprec.py (the reference's 16-bit execution emulated on the fp32 graph) vs torch's OWN 16-bit CPU execution of the same toy-width
+    UNet (`.to(dtype)`): both lose the same amount against fp32 (within 25 %) -- the emulation neither flatters nor inflates the floor."""
+    from oracle.unet import build_unet
+    from oracle.lowprec import LowPrecisionUNet
+    ch = (32, 64, 128, 128)
+    g = torch.Generator().manual_seed(1)
+    x, c = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 77, 768, generator=g)
+    rel = lambda p, q: ((p - q).norm() / q.norm()).item()
+    with torch.no_grad():
+        ref = build_unet(0, block_out_channels=ch, groups=8)(x, torch.tensor(481), encoder_hidden_states=c)["sample"]
+        emu = LowPrecisionUNet(build_unet(0, block_out_channels=ch, groups=8), dtype)(x, torch.tensor(481), encoder_hidden_states=c)["sample"]
+        real = build_unet(0, block_out_channels=ch, groups=8).to(dtype)(x.to(dtype), torch.tensor(481), encoder_hidden_states=c.to(dtype))["sample"].float()
+    e_emu, e_real = rel(emu, ref), rel(real, ref)
+    assert 0.75 < e_emu / e_real < 1.25, (e_emu, e_real)
+    assert (5e-4 < e_emu < 5e-3) if dtype == torch.float16 else (4e-3 < e_emu < 4e-2)

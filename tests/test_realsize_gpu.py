@@ -6,8 +6,12 @@
     replay + LocalBlend, word maps) without the recursion amplifying rounding; the free-running result is compared as well;
   * one UNet forward at L = 96 (768^2: 9216 self-attention tokens, d = 40) with the MasaCtrl K/V remap active (config 5).
 
-Tolerances are written next to the asserts; north_star asks rtol 1e-3 / atol 1e-4 on edited latents in fp16 -- the per-step (teacher-forced)
-errors printed by these tests are what DESIGN.md quotes against it.  The oracle costs ~2 s per sample-forward at L = 64 on the GPU box's
+Tolerances are written next to the asserts: each absolute bound is at most 2x the value measured on MI355X (round 3), and next to it sits the
+bound that carries the meaning -- the REFERENCE-PRECISION FLOOR: the oracle run with the reference's own 16-bit execution emulated
+(oracle/lowprec.py: 16-bit parameters, every operator's output rounded to 16 bits) loses `floor` against the fp32 oracle on the same inputs;
+the native engine, compared with the same fp32 oracle, must stay within 1.5 x floor per UNet call and per teacher-forced step.  north_star's
+rtol 1e-3 / atol 1e-4 against an fp32 reference is below that floor for ANY 16-bit-operand execution, the reference's included; the fp32-operand
+engine (tests/test_fp32_gpu.py) is what meets it.  The oracle costs ~2 s per sample-forward at L = 64 on the GPU box's
 host cores, so the whole file is a few minutes."""
 import json
 
@@ -36,8 +40,22 @@ def oracle_unet():
 
 
 # ------------------------------------------------------------------------------------------------ whole UNet, bench tile dispatch
-@pytest.mark.parametrize("dtype,tol", [(torch.float16, 3e-3), (torch.bfloat16, 2e-2)])
-def test_unet_L64_rows16_vs_oracle(oracle_unet, dtype, tol):
+@pytest.fixture(scope="module")
+def lowprec_unets():
+    """the oracle with the reference's 16-bit execution emulated, one per dtype (built on first use; 3.4 GB each)"""
+    from oracle.unet import build_unet
+    from oracle.lowprec import LowPrecisionUNet
+    made = {}
+
+    def get(dtype):
+        if dtype not in made:
+            made[dtype] = LowPrecisionUNet(build_unet(0), dtype)
+        return made[dtype]
+    return get
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2.2e-3), (torch.bfloat16, 1.8e-2)])     # measured 1.1e-3 / 9.2e-3
+def test_unet_L64_rows16_vs_oracle(oracle_unet, lowprec_unets, dtype, tol):
     """16 DIFFERENT rows through the persistent ring kernels: the first and the last are checked against the CPU oracle, all of them
     through batch invariance (the same samples in reversed row order must give bit-identical rows)."""
     from etainv.engine import Engine
@@ -52,10 +70,13 @@ def test_unet_L64_rows16_vs_oracle(oracle_unet, dtype, tol):
     assert torch.equal(out.cpu(), out_p.cpu()[perm]), "a row's result depends on its position in the batch"
     with torch.no_grad():
         ref = oracle_unet(x[[0, 15]], 481, encoder_hidden_states=c[[0, 15]])["sample"]
-    err = relerr(out[[0, 15]].cpu(), ref)
-    print(f"UNet L=64 rows=16 {dtype}: rel L2 {err:.2e}, max abs {maxabs(out[[0, 15]].cpu(), ref):.2e} (|ref| max {float(ref.abs().max()):.2f})")
-    assert err < tol
+        low = lowprec_unets(dtype)(x[[0, 15]], 481, encoder_hidden_states=c[[0, 15]])["sample"]
+    err, floor = relerr(out[[0, 15]].cpu(), ref), relerr(low, ref)
+    print(f"UNet L=64 rows=16 {dtype}: rel L2 {err:.2e}, max abs {maxabs(out[[0, 15]].cpu(), ref):.2e} (|ref| max {float(ref.abs().max()):.2f}); "
+          f"reference-precision floor (oracle with {dtype} execution emulated vs fp32) {floor:.2e} -> ratio {err / floor:.2f}")
     e.close()
+    assert err < tol
+    assert err <= 1.5 * floor, f"native {dtype} UNet is {err / floor:.2f}x the error of the reference's own {dtype} execution"
 
 
 # ------------------------------------------------------------------------------------------------ etainv + ptp, teacher-forced
@@ -91,14 +112,44 @@ def oracle_run(oracle_unet):
     return pairs, z0, ctx_src, ctx_tgt, noise, runs
 
 
+def floor_run(oracle_run, low_unet):
+    """The same two pairs through the oracle loop with the reference's 16-bit UNet execution emulated, TEACHER-FORCED on the fp32 oracle's
+    latents (every step on identical inputs, like the native teacher-forced run): per-step errors of the reference's own precision."""
+    from oracle import loop as oloop, ptp as optp
+    pairs, z0, ctx_src, ctx_tgt, noise, runs = oracle_run
+    tok = optp.WordTokenizer()
+    out = []
+    with torch.no_grad():
+        for i, (src, tgt) in enumerate(pairs):
+            o = oloop.EtaInversionOracle(low_unet, S=S, eta=ETA, L=L, use_mask=True)
+            inv = o.invert(z0[i:i + 1], ctx_src[i], src, teacher=[runs[i]["inv"][j:j + 1] for j in range(S + 1)])
+            bw, tw = src.split(" ")[1], tgt.split(" ")[1]
+            controller = optp.make_edit_controller(src, tgt, S, tok, blend_words=((bw,), (tw,)), equilizer_params={"words": (tw,), "values": (2,)},
+                                                   res=L // 4, thres_n=(L // 2) ** 2, **PTP_CFG)
+            zT = runs[i]["inv"][S:S + 1]
+            teacher = [torch.cat([zT, zT])] + [runs[i]["trace"][k]["latent"] for k in range(S - 1)]
+            inv_tf = dict(inv, latents=[runs[i]["inv"][j:j + 1] for j in range(S + 1)],
+                          attn_maps_mean=[m[None] for m in runs[i]["maps"]])      # backward pass on the fp32 oracle's trajectory and maps
+            trace = []
+            o.sample(inv_tf, ctx_src[i], ctx_tgt[i], noise, edit_word_idx=(1, 1), controller=controller, trace=trace, teacher=teacher)
+            out.append({"inv": torch.cat(inv["latents"]), "trace": trace})
+    fwd = [max(relerr(out[i]["inv"][j + 1], runs[i]["inv"][j + 1]) for i in range(len(pairs))) for j in range(S)]
+    eps = [max(relerr(out[i]["trace"][k]["eps"], runs[i]["trace"][k]["eps"]) for i in range(len(pairs))) for k in range(S)]
+    tgt = [max(relerr(out[i]["trace"][k]["latent"][1], runs[i]["trace"][k]["latent"][1]) for i in range(len(pairs))) for k in range(S)]
+    return {"fwd": fwd, "eps": eps, "tgt": tgt}
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_etainv_ptp_L64_teacher_forced(oracle_run, dtype):
+def test_etainv_ptp_L64_teacher_forced(oracle_run, lowprec_unets, dtype):
     from oracle import ptp as optp
     from etainv.engine import Engine
     from etainv.pipeline import EtaLoop, PtpTables
     pairs, z0, ctx_src, ctx_tgt, noise, runs = oracle_run
     bf = dtype == torch.bfloat16
     fails = []                                                        # every bound is checked (and printed) before the test fails
+    floor = floor_run(oracle_run, lowprec_unets(dtype))
+    print(f"[{dtype}] reference-precision floor per teacher-forced step: fwd latent {['%.2e' % v for v in floor['fwd']]}, guided eps "
+          f"{['%.2e' % v for v in floor['eps']]}, target latent {['%.2e' % v for v in floor['tgt']]}")
 
     def check(ok, what):
         if not ok:
@@ -134,14 +185,16 @@ def test_etainv_ptp_L64_teacher_forced(oracle_run, dtype):
     for j in range(S):
         e = relerr(lat_n[j + 1], ref_inv[j + 1])
         print(f"[{dtype}] fwd step {j}: latent rel L2 {e:.2e}, max abs {maxabs(lat_n[j + 1], ref_inv[j + 1]):.2e}")
-        check(e < (2e-2 if bf else 2e-3), f"fwd step {j}: {e:.2e}")   # one DDIM-inversion step on the oracle's input (UNet error x sqrt(1 - a) scaling)
+        check(e < (1.4e-2 if bf else 1.8e-3), f"fwd step {j}: {e:.2e}")   # one DDIM-inversion step on the oracle's input; measured 7-9e-4 / 6-7e-3
+        check(e <= max(1.5 * floor["fwd"][j], 1e-6),     # (1e-6: the t = 0 step is the identity in both directions: fp32 rounding only)
+               f"fwd step {j}: {e:.2e} vs floor {floor['fwd'][j]:.2e}")
     ref_maps = torch.zeros(B, W, L, L)
     for b in range(B):
         m = runs[sel[b]]["maps"]
         ref_maps[b, :m.shape[0]] = m
     e_map = relerr(torch.stack([inv_n["maps_mean"][b, 1] for b in range(B)]).cpu(), ref_maps[:, 1])
     print(f"[{dtype}] edit-word map (teacher-forced mean over {S} steps): rel L2 {e_map:.2e}")
-    check(e_map < (3e-2 if bf else 5e-3), f"word map {e_map:.2e}")
+    check(e_map < (5e-3 if bf else 7e-4), f"word map {e_map:.2e}")      # measured 3.4e-4 / 2.5e-3
 
     # ---- backward pass, teacher-forced: the oracle's inversion latents, word maps and per-step inputs
     inv_tf = {"latents": ref_inv.cuda(), "maps_mean": ref_maps.cuda(), "maps_steps": None}
@@ -165,7 +218,8 @@ def test_etainv_ptp_L64_teacher_forced(oracle_run, dtype):
         print(f"[{dtype}] bwd step {i} (t={trace[i]['t']}): guided eps rel L2 {e_eps:.2e}; best {best_n} vs {best_r}; latent src rel L2 {e_src:.2e} "
               f"tgt rel L2 {e_tgt:.2e} max abs {maxabs(lat_i[B:], lat_r[B:]):.2e} (|x| max {float(lat_r.abs().max()):.2f})")
         assert torch.equal(lat_i[0], lat_i[2]) and torch.equal(lat_i[B + 1], lat_i[B + 3])
-        check(e_eps < (1e-1 if bf else 1.5e-2), f"bwd step {i} eps {e_eps:.2e}")   # one UNet call (1e-3 fp16 / 9e-3 bf16) x 7.5 CFG amplification of cond - uncond
+        check(e_eps < (1e-1 if bf else 1.5e-2), f"bwd step {i} eps {e_eps:.2e}")   # one UNet call (1e-3 fp16 / 9e-3 bf16) x 7.5 CFG amplification of cond - uncond; measured 8e-3 / 6.5e-2
+        check(e_eps <= 1.5 * floor["eps"][i], f"bwd step {i} eps {e_eps:.2e} vs floor {floor['eps'][i]:.2e}")
         for b in range(B):                                            # the argmin may only differ where the oracle's two best losses nearly tie
             if best_n[b] != best_r[b]:
                 ls = runs[sel[b]]["trace"][i]["losses"]
@@ -174,7 +228,8 @@ def test_etainv_ptp_L64_teacher_forced(oracle_run, dtype):
                 check(gap < (2e-2 if bf else 2e-3), f"bwd step {i} image {b}: best {best_n} vs {best_r}, gap {gap:.2e}")
         check(e_src < 1e-5, f"bwd step {i} source replay {e_src:.2e}")   # exact up to fp32 rounding of x + (x_prev - x)
         if best_n == best_r:
-            check(e_tgt < (1e-1 if bf else 1.2e-2), f"bwd step {i} target latent {e_tgt:.2e}")
+            check(e_tgt < (1e-1 if bf else 1.2e-2), f"bwd step {i} target latent {e_tgt:.2e}")   # measured 2.3e-3 ... 7.6e-3 / 1.9e-2 ... 6e-2
+            check(e_tgt <= max(1.5 * floor["tgt"][i], 1e-6), f"bwd step {i} target latent {e_tgt:.2e} vs floor {floor['tgt'][i]:.2e}")
 
     # ---- free-running native run vs the oracle's result (rounding now recurses through 2 S UNet calls)
     inv_f = loop.invert(z0b, cs, tokens.cuda())
@@ -183,7 +238,8 @@ def test_etainv_ptp_L64_teacher_forced(oracle_run, dtype):
     ref_out = torch.cat([torch.stack([runs[p]["out"][0] for p in sel]), torch.stack([runs[p]["out"][1] for p in sel])])
     e_inv, e_fs, e_ft = relerr(inv_f["latents"].cpu(), ref_inv), relerr(out[:B].cpu(), ref_out[:B]), relerr(out[B:].cpu(), ref_out[B:])
     print(f"[{dtype}] free-running S={S}: inversion trajectory rel L2 {e_inv:.2e}, latent_inv {e_fs:.2e}, edited latent {e_ft:.2e}")
-    check(e_inv < (3e-2 if bf else 3e-3) and e_fs < (3e-2 if bf else 3e-3) and e_ft < (4e-1 if bf else 3e-2), "free-running bounds")
+    # measured (round 2): 5.8e-4 / 8.2e-3 fp16, 4.8e-3 / 6.6e-2 bf16 -- bounds at 2x; the S = 50 figures are in profiles/r03_parity_S50.json
+    check(e_inv < (1e-2 if bf else 1.2e-3) and e_fs < (1e-2 if bf else 1.2e-3) and e_ft < (1.4e-1 if bf else 1.7e-2), "free-running bounds")
     eng.close()
     assert not fails, fails
 
