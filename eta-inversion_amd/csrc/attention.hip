@@ -923,6 +923,10 @@ int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int hea
                                hipStream_t s, int q_prescaled) {
   ETAINV_CHECK(qkv && out && b > 0 && n > 0, "bad arguments");
   ETAINV_CHECK(mode == 0 || (n_img > 0 && b == 4 * n_img), "ptp / masactrl modes need the 4*n_img backward layout");
+  if (dtype == ETAINV_F32) {
+    ETAINV_CHECK(!q_prescaled, "fp32 path: the softmax scale is applied in the kernel");
+    return launch_self_attention_f32(qkv, out, b, n, heads, d, mode, n_img, s);
+  }
   ETAINV_CHECK(!q_prescaled || d == 40 || d == 80, "pre-scaled queries: head_dim 40 / 80 only");
   ETAINV_CHECK(!q_prescaled || self_attn40_v2_enabled(), "pre-scaled queries need the d = 40 kernel");
   if (d == 40 && self_attn40_v2_enabled()) {
@@ -976,6 +980,7 @@ static int launch_cross_t(const void* q, const void* kv, void* out, int b, const
 }
 
 int launch_cross_attention_p(const void* q, const void* kv, void* out, int b, int d, const CrossParams& p, int dtype, hipStream_t s) {
+  if (dtype == ETAINV_F32) return launch_cross_attention_f32(q, kv, out, b, d, p, s);
   ETAINV_CHECK(q && kv && out && b > 0, "bad arguments");
   ETAINV_CHECK(p.n_ctx >= 1 && p.n_ctx <= 77, "n_ctx must be in [1,77]");
   ETAINV_DISPATCH_HALF(dtype, T, switch (d) {

@@ -39,7 +39,7 @@ __global__ void im2col_small_kernel(const TIO* __restrict__ x, int cin, int H, i
   }
   u32x4* o = reinterpret_cast<u32x4*>(out + i * 64);
 #pragma unroll
-  for (int q = 0; q < 8; ++q) o[q] = reinterpret_cast<u32x4*>(v)[q];
+  for (int q = 0; q < (int)(64 * sizeof(T) / 16); ++q) o[q] = reinterpret_cast<u32x4*>(v)[q];
 }
 
 // in place: x[row][:] = softmax(scale * x[row][:]); one 256-thread block per row, three passes over the (L2-resident) row
@@ -128,7 +128,7 @@ extern "C" int etainv_op_im2col3x3(const void* x_nchw, int io_dtype, int cin, in
                                    int dtype, void* stream) {
   ETAINV_CHECK(x_nchw && out && cin >= 1 && cin <= 4 && rows >= 1, "bad arguments");
   const int64_t n = (int64_t)rows * h * w;
-  ETAINV_DISPATCH_HALF(dtype, T, ETAINV_DISPATCH_DTYPE(io_dtype, TIO,
+  ETAINV_DISPATCH_DTYPE(dtype, T, ETAINV_DISPATCH_DTYPE(io_dtype, TIO,
       hipLaunchKernelGGL((im2col_small_kernel<T, TIO>), dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const TIO*)x_nchw, cin, h, w,
                          rows, premix, (T*)out)));
   ETAINV_LAUNCH_CHECK();
@@ -137,7 +137,7 @@ extern "C" int etainv_op_im2col3x3(const void* x_nchw, int io_dtype, int cin, in
 
 extern "C" int etainv_op_row_softmax(void* x, int rows, int n, float scale, int dtype, void* stream) {
   ETAINV_CHECK(x && rows >= 1 && n >= 1, "bad arguments");
-  ETAINV_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL(row_softmax_kernel<T>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (T*)x, n,
+  ETAINV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(row_softmax_kernel<T>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (T*)x, n,
                                                     scale * 1.4426950408889634f));
   ETAINV_LAUNCH_CHECK();
   return 0;
@@ -146,7 +146,7 @@ extern "C" int etainv_op_row_softmax(void* x, int rows, int n, float scale, int 
 extern "C" int etainv_op_quick_gelu(const void* x, void* out, int64_t n, int dtype, void* stream) {
   ETAINV_CHECK(x && out && n >= 0, "bad arguments");
   if (n == 0) return 0;
-  ETAINV_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL(quick_gelu_kernel<T>, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+  ETAINV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(quick_gelu_kernel<T>, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
                                                     (const T*)x, (T*)out, n));
   ETAINV_LAUNCH_CHECK();
   return 0;
@@ -156,7 +156,7 @@ extern "C" int etainv_op_embed(const int64_t* ids, const void* tok, const void* 
                                void* stream) {
   ETAINV_CHECK(ids && tok && pos && out && b >= 1, "bad arguments");
   const int64_t total = (int64_t)b * n_pos * d;
-  ETAINV_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL(embed_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, ids,
+  ETAINV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(embed_kernel<T>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, ids,
                                                     (const T*)tok, (const T*)pos, n_pos, d, (T*)out, total));
   ETAINV_LAUNCH_CHECK();
   return 0;
@@ -164,7 +164,7 @@ extern "C" int etainv_op_embed(const int64_t* ids, const void* tok, const void* 
 
 extern "C" int etainv_op_causal_attention(const void* qkv, void* out, int b, int n, int heads, int d, int dtype, void* stream) {
   ETAINV_CHECK(qkv && out && b >= 1 && n >= 1 && n <= 80 && d == 64, "causal attention supports n <= 80, head_dim 64");
-  ETAINV_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL(causal_attn_small_kernel<T>, dim3(heads, b), dim3(128), 0, (hipStream_t)stream,
+  ETAINV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(causal_attn_small_kernel<T>, dim3(heads, b), dim3(128), 0, (hipStream_t)stream,
                                                     (const T*)qkv, (T*)out, n, heads));
   ETAINV_LAUNCH_CHECK();
   return 0;

@@ -94,6 +94,7 @@ using namespace etainv;
 struct etainv_engine {
   etainv_engine_config cfg{};
   int dt = ETAINV_F16;
+  size_t esz = 2;   // bytes per activation / weight element: 2, or 4 in the fp32-operand mode (compute_dtype ETAINV_F32, f32path.hip)
   int L = 64, maxB = 4, max_img = 1;
   static constexpr int kHeads = 8, kCtx = 77, kCtxDim = 768, kGroups = 32, kTemb = 1280, kCh0 = 320;
 
@@ -205,7 +206,7 @@ struct Builder {
   void linear(const std::string& prefix, Lin& l, int n, int k, bool bias, int pack = PK_PLAIN) {
     l.n = n;
     l.k = k;
-    want(&l.w, (size_t)n * k * 2);
+    want(&l.w, (size_t)n * k * e->esz);
     add_slot(prefix + ".weight", {n, k}, &l.w, 0, pack, 1, e->dt);
     if (bias) {
       want(&l.b, (size_t)n * 4);
@@ -215,7 +216,7 @@ struct Builder {
   void conv1x1(const std::string& prefix, Lin& l, int n, int k) {
     l.n = n;
     l.k = k;
-    want(&l.w, (size_t)n * k * 2);
+    want(&l.w, (size_t)n * k * e->esz);
     add_slot(prefix + ".weight", {n, k, 1, 1}, &l.w, 0, PK_PLAIN, 1, e->dt);
     want(&l.b, (size_t)n * 4);
     add_slot(prefix + ".bias", {n}, reinterpret_cast<void**>(&l.b), 0, PK_PLAIN, 1, ETAINV_F32);
@@ -223,7 +224,7 @@ struct Builder {
   void conv3x3(const std::string& prefix, Lin& l, int n, int k) {
     l.n = n;
     l.k = k;
-    want(&l.w, (size_t)n * k * 9 * 2);
+    want(&l.w, (size_t)n * k * 9 * e->esz);
     add_slot(prefix + ".weight", {n, k, 3, 3}, &l.w, 0, PK_CONV, 9, e->dt);
     want(&l.b, (size_t)n * 4);
     add_slot(prefix + ".bias", {n}, reinterpret_cast<void**>(&l.b), 0, PK_PLAIN, 1, ETAINV_F32);
@@ -239,7 +240,7 @@ struct Builder {
     r.tproj_off = e->tproj_total;
     // time_emb_proj rows live inside the concatenated projection matrix
     add_slot(prefix + ".time_emb_proj.weight", {cout, etainv_engine::kTemb}, &e->tproj.w,
-             (size_t)r.tproj_off * etainv_engine::kTemb * 2, PK_PLAIN, 1, e->dt);
+             (size_t)r.tproj_off * etainv_engine::kTemb * e->esz, PK_PLAIN, 1, e->dt);
     add_slot(prefix + ".time_emb_proj.bias", {cout}, reinterpret_cast<void**>(&e->tproj.b), (size_t)r.tproj_off * 4, PK_PLAIN, 1,
              ETAINV_F32);
     e->tproj_total += cout;
@@ -258,24 +259,24 @@ struct Builder {
     // fused QKV [3c][c]
     t.qkv.n = 3 * c;
     t.qkv.k = c;
-    want(&t.qkv.w, (size_t)3 * c * c * 2);
+    want(&t.qkv.w, (size_t)3 * c * c * e->esz);
     add_slot(tp + ".attn1.to_q.weight", {c, c}, &t.qkv.w, 0, PK_PLAIN, 1, e->dt);
     // head_dim 40 / 80 (the L^2- and (L/2)^2-token levels): softmax scale * log2(e) folded into to_q, so that the self-attention kernel's
     // score accumulator is directly the exponent argument of exp2 (attention.hip, self_attn40_kernel) -- one rounding of W_q * c instead of
     // W_q, none added
-    if (c / etainv_engine::kHeads <= 80 && self_attn40_v2_enabled())
+    if (c / etainv_engine::kHeads <= 80 && self_attn40_v2_enabled() && e->dt != ETAINV_F32)
       e->slots.back().scale = (1.0f / std::sqrt((float)(c / etainv_engine::kHeads))) * 1.4426950408889634f;
     t.q_scale = e->slots.back().scale;
-    add_slot(tp + ".attn1.to_k.weight", {c, c}, &t.qkv.w, (size_t)c * c * 2, PK_PLAIN, 1, e->dt);
-    add_slot(tp + ".attn1.to_v.weight", {c, c}, &t.qkv.w, (size_t)2 * c * c * 2, PK_PLAIN, 1, e->dt);
+    add_slot(tp + ".attn1.to_k.weight", {c, c}, &t.qkv.w, (size_t)c * c * e->esz, PK_PLAIN, 1, e->dt);
+    add_slot(tp + ".attn1.to_v.weight", {c, c}, &t.qkv.w, (size_t)2 * c * c * e->esz, PK_PLAIN, 1, e->dt);
     linear(tp + ".attn1.to_out.0", t.out1, c, c, true);
     norm(tp + ".norm2", t.ln2, c);
     linear(tp + ".attn2.to_q", t.q, c, c, false);
     t.kv.n = 2 * c;
     t.kv.k = etainv_engine::kCtxDim;
-    want(&t.kv.w, (size_t)2 * c * etainv_engine::kCtxDim * 2);
+    want(&t.kv.w, (size_t)2 * c * etainv_engine::kCtxDim * e->esz);
     add_slot(tp + ".attn2.to_k.weight", {c, etainv_engine::kCtxDim}, &t.kv.w, 0, PK_PLAIN, 1, e->dt);
-    add_slot(tp + ".attn2.to_v.weight", {c, etainv_engine::kCtxDim}, &t.kv.w, (size_t)c * etainv_engine::kCtxDim * 2, PK_PLAIN, 1, e->dt);
+    add_slot(tp + ".attn2.to_v.weight", {c, etainv_engine::kCtxDim}, &t.kv.w, (size_t)c * etainv_engine::kCtxDim * e->esz, PK_PLAIN, 1, e->dt);
     linear(tp + ".attn2.to_out.0", t.out2, c, c, true);
     norm(tp + ".norm3", t.ln3, c);
     linear(tp + ".ff.net.0.proj", t.ff1, 8 * c, c, true, PK_GEGLU);
@@ -311,14 +312,14 @@ int build_model(etainv_engine* e) {
   e->tb.reserve(16);
   const int ch[4] = {320, 640, 1280, 1280};
   // conv_in / conv_out keep fp32 weights in their own layouts
-  b.want(&e->conv_in_w, (size_t)64 * ch[0] * 2);   // [320][64] compute dtype: conv_in runs as a K = 64 GEMM on an im2col buffer
+  b.want(&e->conv_in_w, (size_t)64 * ch[0] * e->esz);   // [320][64] compute dtype: conv_in runs as a K = 64 GEMM on an im2col buffer
   b.add_slot("conv_in.weight", {ch[0], 4, 3, 3}, &e->conv_in_w, 0, PK_CONV_IN_GEMM, 9, e->dt);
   b.vec("conv_in.bias", &e->conv_in_b, ch[0]);
   b.linear("time_embedding.linear_1", e->time1, etainv_engine::kTemb, ch[0], true);
   b.linear("time_embedding.linear_2", e->time2, etainv_engine::kTemb, etainv_engine::kTemb, true);
   // concatenated time-embedding projection: total = sum of cout over the 22 resblocks = 21120... computed below;
   // reserve the maximum up front (22 * 1280) and trim logically via tproj_total
-  b.want(&e->tproj.w, (size_t)22 * 1280 * etainv_engine::kTemb * 2);
+  b.want(&e->tproj.w, (size_t)22 * 1280 * etainv_engine::kTemb * e->esz);
   b.want(&e->tproj.b, (size_t)22 * 1280 * 4);
   // down
   int cin = ch[0];
@@ -350,7 +351,7 @@ int build_model(etainv_engine* e) {
     prev = cout;
   }
   b.norm("conv_norm_out", e->norm_out, ch[0]);
-  b.want(&e->conv_out_w, (size_t)9 * ch[0] * 4 * 2);   // [4][9][320] compute dtype: conv_out is an N = 4 implicit GEMM
+  b.want(&e->conv_out_w, (size_t)9 * ch[0] * 4 * e->esz);   // [4][9][320] compute dtype: conv_out is an N = 4 implicit GEMM
   b.add_slot("conv_out.weight", {4, ch[0], 3, 3}, &e->conv_out_w, 0, PK_CONV, 9, e->dt);
   b.vec("conv_out.bias", &e->conv_out_b, 4);
   e->tproj.n = e->tproj_total;
@@ -372,31 +373,31 @@ int build_workspace(etainv_engine* e) {
     size_t off = plan.take(bytes);
     fix.push_back([field, off](char* base) { *field = base + off; });
   };
-  const size_t B = (size_t)e->maxB, L = (size_t)e->L;
+  const size_t B = (size_t)e->maxB, L = (size_t)e->L, esz = e->esz;
   const size_t hw[4] = {L * L, (L / 2) * (L / 2), (L / 4) * (L / 4), (L / 8) * (L / 8)};
   const size_t skip_el[12] = {hw[0] * 320, hw[0] * 320, hw[0] * 320, hw[1] * 320,  hw[1] * 640,  hw[1] * 640,
                               hw[2] * 640, hw[2] * 1280, hw[2] * 1280, hw[3] * 1280, hw[3] * 1280, hw[3] * 1280};
-  for (int i = 0; i < 12; ++i) want(&e->skip[i], B * skip_el[i] * 2);
+  for (int i = 0; i < 12; ++i) want(&e->skip[i], B * skip_el[i] * esz);
   // largest activation [HW x C] over the levels is L^2 x 320 (x2 after an upsample conv never exceeds it)
   const size_t hmax = hw[0] * 320;
   // block outputs: the up_blocks.2 upsample conv emits L^2 x 640
-  for (int i = 0; i < 3; ++i) want(&e->tmp[i], B * hw[0] * 640 * 2);
-  want(&e->gnbuf, B * hw[0] * 960 * 2);
-  want(&e->h1, B * hmax * 2);
-  want(&e->scbuf, B * hmax * 2);
-  want(&e->hsA, B * hmax * 2);
-  want(&e->hsB, B * hmax * 2);
-  want(&e->lnbuf, B * hmax * 2);
-  want(&e->qkvbuf, B * hmax * 3 * 2);
-  want(&e->attnbuf, B * hmax * 2);
-  want(&e->qbuf, B * hmax * 2);
-  want(&e->kvbuf, B * 77 * 2 * 1280 * 2);
-  for (size_t i = 0; i < e->tb.size() && i < 16; ++i) want(&e->kvcache[i], B * 77 * 2 * (size_t)e->tb[i].c * 2);
-  want(&e->ffbuf, B * hmax * 4 * 2);
-  want(&e->ctxT, B * 77 * 768 * 2);
-  want(&e->tembuf, B * 320 * 2);
-  want(&e->temb1, B * 1280 * 2);
-  want(&e->temb2, B * 1280 * 2);
+  for (int i = 0; i < 3; ++i) want(&e->tmp[i], B * hw[0] * 640 * esz);
+  want(&e->gnbuf, B * hw[0] * 960 * esz);
+  want(&e->h1, B * hmax * esz);
+  want(&e->scbuf, B * hmax * esz);
+  want(&e->hsA, B * hmax * esz);
+  want(&e->hsB, B * hmax * esz);
+  want(&e->lnbuf, B * hmax * esz);
+  want(&e->qkvbuf, B * hmax * 3 * esz);
+  want(&e->attnbuf, B * hmax * esz);
+  want(&e->qbuf, B * hmax * esz);
+  want(&e->kvbuf, B * 77 * 2 * 1280 * esz);
+  for (size_t i = 0; i < e->tb.size() && i < 16; ++i) want(&e->kvcache[i], B * 77 * 2 * (size_t)e->tb[i].c * esz);
+  want(&e->ffbuf, B * hmax * 4 * esz);
+  want(&e->ctxT, B * 77 * 768 * esz);
+  want(&e->tembuf, B * 320 * esz);
+  want(&e->temb1, B * 1280 * esz);
+  want(&e->temb2, B * 1280 * esz);
   want(reinterpret_cast<void**>(&e->tprojbuf), B * (size_t)e->tproj_total * 4);
   want(reinterpret_cast<void**>(&e->gn_scratch), B * (GN_MAX_CHUNKS + 1) * etainv_engine::kGroups * 2 * 4);
   // LayerNorm partials [M][P][2]: P = C / (wave tile columns) <= C / 32, M * C <= B * hmax on every level
@@ -571,7 +572,7 @@ struct Fwd {
       if (ctrl->mode == ETAINV_ATTN_PTP && ctrl->self_replace_active && hw <= ctrl->self_max_tokens) mode = 1;
       if (ctrl->mode == ETAINV_ATTN_MASA && ctrl->masa_active && blk >= ctrl->masa_first_block) mode = 2;
     }
-    if (launch_self_attention_mode(e->qkvbuf, e->attnbuf, rows, hw, etainv_engine::kHeads, d, mode, n_img, e->dt, s, /*q_prescaled=*/d <= 80 && self_attn40_v2_enabled())) return 1;
+    if (launch_self_attention_mode(e->qkvbuf, e->attnbuf, rows, hw, etainv_engine::kHeads, d, mode, n_img, e->dt, s, /*q_prescaled=*/d <= 80 && self_attn40_v2_enabled() && e->dt != ETAINV_F32)) return 1;
     if (gemm(e->attnbuf, t.out1, e->hsB, M, e->hsA, 0, nullptr, 0, 0, fold)) return 1;
     // cross-attention
     if (fold) {
@@ -638,7 +639,7 @@ extern "C" const char* etainv_last_error(void) { return g_err.c_str(); }
 
 extern "C" int etainv_engine_create(const etainv_engine_config* cfg, etainv_engine_t** out) {
   ETAINV_CHECK(cfg && out, "null argument");
-  ETAINV_CHECK(cfg->compute_dtype == ETAINV_F16 || cfg->compute_dtype == ETAINV_BF16, "compute_dtype must be f16 or bf16");
+  ETAINV_CHECK(cfg->compute_dtype == ETAINV_F16 || cfg->compute_dtype == ETAINV_BF16 || cfg->compute_dtype == ETAINV_F32, "compute_dtype must be f16, bf16 or f32");
   ETAINV_CHECK(cfg->latent_size >= 8 && cfg->latent_size % 8 == 0 && cfg->latent_size <= 128, "latent_size must be a multiple of 8 in [8,128]");
   ETAINV_CHECK(cfg->max_unet_batch >= 1 && cfg->max_img >= 1, "batch sizes must be positive");
   int ndev = 0;
@@ -650,8 +651,10 @@ extern "C" int etainv_engine_create(const etainv_engine_config* cfg, etainv_engi
   e->L = cfg->latent_size;
   e->maxB = cfg->max_unet_batch;
   e->max_img = cfg->max_img;
-  e->ln_fused = !getenv("ETAINV_LN_UNFUSED");
-  e->gn_fused = !getenv("ETAINV_GN_UNFUSED");
+  e->esz = e->dt == ETAINV_F32 ? 4 : 2;
+  // fp32-operand mode: the standalone norms (the folds are fusions of the 16-bit kernels' epilogues)
+  e->ln_fused = !getenv("ETAINV_LN_UNFUSED") && e->dt != ETAINV_F32;
+  e->gn_fused = !getenv("ETAINV_GN_UNFUSED") && e->dt != ETAINV_F32;
   e->gn_fold = e->gn_fused && getenv("ETAINV_GN_FOLD") != nullptr;
   if (build_model(e) || build_workspace(e)) {
     etainv_engine_destroy(e);

@@ -1154,6 +1154,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p) {
 
 int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P) {
   if (stat_P) *stat_P = 0;
+  if (dtype == ETAINV_F32) return launch_igemm_f32(p_in, s);   // fp32-operand parity mode (f32path.hip)
   static void* zero_pages[kMaxDevices] = {};   // 256 zero bytes read by the halo lanes of the 3x3 taps (one-time allocation per device)
   const int dev = current_device();
   if (!zero_pages[dev]) {

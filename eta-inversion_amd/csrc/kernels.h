@@ -54,6 +54,15 @@ struct IGemmParams {
 // stat_P (optional): receives the number of partials per row written to p.stat_out (0: none written)
 int launch_igemm(const IGemmParams& p, int dtype, hipStream_t s, int* stat_P = nullptr);
 
+// ---- f32path.hip: the fp32-operand execution (dtype == ETAINV_F32 routes here from the launchers of igemm / norm / attention)
+int launch_igemm_f32(const IGemmParams& p, hipStream_t s);
+int launch_groupnorm_f32(const void* x1, const void* x2, int c1, int c2, const float* gamma, const float* beta, void* out, int b, int hw, int groups,
+                         float eps, int silu, float* scratch, hipStream_t s);
+int launch_layernorm_f32(const void* x, const float* gamma, const float* beta, void* out, int rows, int c, float eps, hipStream_t s);
+int launch_self_attention_f32(const void* qkv, void* out, int b, int n, int heads, int d, int mode, int n_img, hipStream_t s);
+struct CrossParams;
+int launch_cross_attention_f32(const void* q, const void* kv, void* out, int b, int d, const CrossParams& p, hipStream_t s);
+
 // ---- norm.hip
 // GroupNorm(32 groups) over NHWC with optional second (concatenated) source and fused SiLU.
 // scratch: >= b * GN_CHUNKS_MAX * groups * 2 floats

@@ -105,7 +105,7 @@ __global__ void im2col_in_kernel(const TIO* __restrict__ x, int n_lat, int L, in
   }
   u32x4* o = reinterpret_cast<u32x4*>(out + i * 64);
 #pragma unroll
-  for (int q = 0; q < 8; ++q) o[q] = reinterpret_cast<u32x4*>(v)[q];
+  for (int q = 0; q < (int)(64 * sizeof(T) / 16); ++q) o[q] = reinterpret_cast<u32x4*>(v)[q];
 }
 
 // The timesteps travel BY VALUE in the kernel arguments (one scalar when every row shares it -- always the case in the loops -- else
@@ -227,7 +227,7 @@ int launch_conv_in(const void* latent, int io_dtype, int n_lat, int rows, int L,
 int launch_im2col_in(const void* latent, int io_dtype, int n_lat, int rows, int L, void* out, int dtype, hipStream_t s) {
   ETAINV_CHECK(latent && out && n_lat > 0 && rows > 0, "bad arguments");
   const int64_t n = (int64_t)rows * L * L;
-  ETAINV_DISPATCH_HALF(dtype, T, ETAINV_DISPATCH_DTYPE(io_dtype, TIO,
+  ETAINV_DISPATCH_DTYPE(dtype, T, ETAINV_DISPATCH_DTYPE(io_dtype, TIO,
       hipLaunchKernelGGL((im2col_in_kernel<T, TIO>), dim3(cdiv(n, 256)), dim3(256), 0, s, (const TIO*)latent, n_lat, L, rows, (T*)out)));
   ETAINV_LAUNCH_CHECK();
   return 0;
@@ -250,12 +250,12 @@ int launch_time_embedding(const int64_t* t_host, int rows, int dim, void* out, i
   TimeVec tv;
   if (uniform) {
     tv.t[0] = (float)t_host[0];
-    ETAINV_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL(time_embedding_kernel<T>, dim3(cdiv(rows * dim, 256)), dim3(256), 0, s, tv, 1, 0, rows, dim, (T*)out));
+    ETAINV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(time_embedding_kernel<T>, dim3(cdiv(rows * dim, 256)), dim3(256), 0, s, tv, 1, 0, rows, dim, (T*)out));
   } else {
     for (int r0 = 0; r0 < rows; r0 += 64) {
       const int n = std::min(64, rows - r0);
       for (int i = 0; i < n; ++i) tv.t[i] = (float)t_host[r0 + i];
-      ETAINV_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL(time_embedding_kernel<T>, dim3(cdiv(n * dim, 256)), dim3(256), 0, s, tv, 0, r0, n, dim, (T*)out));
+      ETAINV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(time_embedding_kernel<T>, dim3(cdiv(n * dim, 256)), dim3(256), 0, s, tv, 0, r0, n, dim, (T*)out));
     }
   }
   ETAINV_LAUNCH_CHECK();
@@ -263,7 +263,7 @@ int launch_time_embedding(const int64_t* t_host, int rows, int dim, void* out, i
 }
 
 int launch_silu(const void* x, void* out, int64_t n, int dtype, hipStream_t s) {
-  ETAINV_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL(silu_kernel<T>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const T*)x, (T*)out, n));
+  ETAINV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(silu_kernel<T>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const T*)x, (T*)out, n));
   ETAINV_LAUNCH_CHECK();
   return 0;
 }

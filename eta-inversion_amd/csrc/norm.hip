@@ -450,6 +450,7 @@ static inline int gn_apply_mode(int C) {
 
 int launch_groupnorm(const void* x1, const void* x2, int c1, int c2, const float* gamma, const float* beta, void* out, int b,
                      int hw, int groups, float eps, int silu, float* scratch, int dtype, hipStream_t s) {
+  if (dtype == ETAINV_F32) return launch_groupnorm_f32(x1, x2, c1, c2, gamma, beta, out, b, hw, groups, eps, silu, scratch, s);
   const int C = c1 + c2;
   ETAINV_CHECK(x1 && gamma && beta && out && scratch, "null pointer");
   ETAINV_CHECK(c1 % 8 == 0 && c2 % 8 == 0 && C % groups == 0 && groups <= 64, "channel layout");
@@ -539,6 +540,7 @@ int launch_groupnorm_pre(const void* x1, const void* x2, int c1, int c2, const f
 
 int launch_layernorm(const void* x, const float* gamma, const float* beta, void* out, int rows, int c, float eps, int dtype,
                      hipStream_t s) {
+  if (dtype == ETAINV_F32) return launch_layernorm_f32(x, gamma, beta, out, rows, c, eps, s);
   ETAINV_CHECK(x && gamma && beta && out, "null pointer");
   ETAINV_CHECK(c % 8 == 0 && (c >> 3) <= 192, "LayerNorm width must be a multiple of 8 and <= 1536");
   ProfScope prof(PROF_LAYERNORM, 2.0 * 2.0 * (double)rows * c, s);

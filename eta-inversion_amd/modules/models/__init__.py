@@ -88,19 +88,17 @@ class StablePostProc:
 
 
 def load_diffusion_model(model="CompVis/stable-diffusion-v1-4", device="cuda", preproc_args=None, variant=None, **kwargs):
-    """reference modules/models/__init__.py:100-138.  Precision: this engine computes with fp16 or bf16 MFMA operands and fp32 accumulation
-    (latents, contexts, scheduler state and the attention softmax stay fp32).  The reference's default `variant=None` means fp32 there;
-    here None selects fp16 and SAYS so, and an explicit "fp32" raises: there is no fp32-operand path (v_mfma_f32_16x16x4_f32 runs at 1/16
-    of the fp16 rate and is not built), and silently narrowing an explicit request would be worse than refusing it."""
-    if variant == "fp32":
-        raise NotImplementedError("variant='fp32': the MI355X engine has no fp32-operand compute path; use 'fp16' or 'bf16' (fp32 accumulation, "
-                                  "fp32 latents / scheduler state) -- measured UNet error vs an fp32 reference: 1.1e-3 (fp16), 9e-3 (bf16) rel L2")
+    """reference modules/models/__init__.py:100-138.  Precision (`variant`, the reference's `--prec`): "fp32" runs the engine with fp32 operands
+    on the f32-input matrix instruction (csrc/f32path.hip; the reference's default precision, about 1/16 of the 16-bit rate -- the parity
+    mode in which the edited latents meet rtol 1e-3 / atol 1e-4 against the fp32 reference path); "fp16" / "bf16" run 16-bit MFMA operands with
+    fp32 accumulation (latents, contexts, scheduler state and the attention softmax stay fp32).  The reference's `variant=None` means fp32
+    there; here None selects fp16 -- the throughput mode -- and SAYS so."""
     if variant is None:
         variant = "fp16"
-        print("precision: fp16 MFMA operands with fp32 accumulation (the reference's fp32 default has no counterpart on this engine)")
+        print("precision: fp16 MFMA operands with fp32 accumulation (pass variant='fp32' / --prec fp32 for the reference's default precision)")
     print(f"Loading model {model} ({variant}) ...")
     if model not in ("sd14", "sd15", "CompVis/stable-diffusion-v1-4", "runwayml/stable-diffusion-v1-5"):
         raise Exception(model)
-    dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[variant]
+    dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[variant]
     pipe = EtaPipeline(device=device, dtype=dtype, **kwargs)
     return pipe, (StablePreprocess(pipe.device, size=8 * pipe.engine.L, **(preproc_args or {})), StablePostProc())

@@ -93,7 +93,9 @@ int etainv_lincomb3(const void* x, float a, const void* y, float b, const void* 
 typedef struct etainv_engine etainv_engine_t;
 
 typedef struct etainv_engine_config {
-  int compute_dtype;      /* ETAINV_F16 or ETAINV_BF16: MFMA operand type (fp32 accumulate)            */
+  int compute_dtype;      /* ETAINV_F16 / ETAINV_BF16: MFMA operand type (fp32 accumulate); ETAINV_F32: fp32 operands on
+                           * v_mfma_f32_32x32x2_f32, fp32 activations -- the reference's default precision (edit_image.py:147),
+                           * 1/16 of the 16-bit matrix rate: the parity mode                                              */
   int max_unet_batch;     /* largest number of UNet rows per call (4 * n_img for the backward pass)      */
   int latent_size;        /* L: 64 for 512x512, 96 for 768x768; multiple of 8                           */
   int max_img;            /* largest n_img (attention-map store is sized for it)                        */
