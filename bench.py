@@ -216,6 +216,39 @@ def stub_main(a, world, rank):
     return 0
 
 
+def nets_figure(eng, dtype, B, S, L, dev, steps):
+    """Secondary figure (never `value`): images/s of `BatchEditor.edit` -- what one rank of the PIE-Bench sweep (eval.py) runs per batch -- on B
+    synthetic 8L x 8L images with prompts: VAE encode, 4 text-encoder calls, per-image prompt-to-prompt tables, the loop, 2 VAE decodes per
+    image.  Same engine (weights resident); the third-party networks get seeded synthetic weights."""
+    from types import SimpleNamespace
+    from etainv.batch import BatchEditor
+    from etainv.nets import NativeCLIPText, NativeVAE
+    from modules.schedulers import DDIMScheduler
+    from modules.utils.tokenizer import load_tokenizer
+    pipe = SimpleNamespace(device=dev, engine=eng, tokenizer=load_tokenizer(), text_encoder=NativeCLIPText(None, dtype, 0), vae=NativeVAE(None, dtype, 0),
+                           scheduler=DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False))
+    editor = BatchEditor(pipe, num_inference_steps=S, edit_method="ptp")
+    g = torch.Generator().manual_seed(77)
+    nouns = ["cat", "dog", "horse", "tiger", "bird", "house", "tower", "bridge"]
+    samples = []
+    for b in range(B):
+        s_w, t_w = nouns[b % 8], nouns[(b + 3) % 8]
+        src, tgt = f"a {s_w} sitting next to a mirror", f"a {t_w} sitting next to a mirror"
+        samples.append(dict(image=(torch.rand(1, 3, 8 * L, 8 * L, generator=g) * 2 - 1).to(dev), source_prompt=src, target_prompt=tgt, edit_word_idx=(1, 1),
+                            ptp=dict(is_replace_controller=False, prompts=[src, tgt], cross_replace_steps={"default_": .4}, self_replace_steps=.6,
+                                     blend_words=((s_w,), (t_w,)), equilizer_params={"words": (t_w,), "values": (2,)})))
+    editor.edit(samples)                                   # warm-up (allocations of the nets' workspaces)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(steps):
+        res = editor.edit(samples)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / steps
+    assert all(r is not None and torch.isfinite(r["image"]).all() for r in res)
+    return {"value": B / dt, "unit": "images/s", "ms_per_step": 1e3 * dt, "steps": steps,
+            "what": "image -> image BatchEditor.edit per batch: VAE encode + text encoder + prompt-to-prompt tables + etainv loop + VAE decode of both rows"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,6 +258,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="image pairs per GPU per step (default: the configuration's)")
     ap.add_argument("--dtype", default=None, choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-nets", action="store_true", help="add a secondary figure: image -> image BatchEditor.edit (VAE encode, CLIP, loop, 2 VAE decodes)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # tests only: launcher / rank protocol over gloo, no engine, no GPU
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
@@ -312,6 +346,9 @@ def main():
         tmax = torch.tensor([dt], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    with_nets = None
+    if a.with_nets and cfg["editor"] == "ptp":
+        with_nets = nets_figure(eng, dtype, B, S_STEPS, L, dev, max(1, min(a.steps, 3)))
     # per-kernel-class HIP-event timing (roofline fields) on ONE extra step OUTSIDE the timed region: the events sit on the launch
     # stream around every launch and would otherwise add their own (small) cost to `value`
     lib.etainv_prof_reset()
@@ -379,6 +416,8 @@ def main():
                 "layernorm": {"gbs": ln_bytes / max(ln_ms, 1e-9) / 1e6, "frac_hbm": ln_bytes / max(ln_ms, 1e-9) / 1e6 / HBM_PEAK_GBS,
                               "share_of_wall": ln_ms * 1e-3 / dt_prof, "launches": ln_n}},
         }
+        if with_nets is not None:
+            line["with_nets"] = with_nets
         if world == 1 and not a.no_cpu_baseline and a.config == 3:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

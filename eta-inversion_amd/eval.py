@@ -39,6 +39,7 @@ def parse_args(argv=None):
     ap.add_argument("--categories", nargs="+", default=None)
     ap.add_argument("--override", action="store_true", help="re-edit images whose output file exists")
     ap.add_argument("--save_latents", action="store_true", help="gather the edited latents of all ranks to rank 0 -> <output>/latents.pt")
+    ap.add_argument("--io_threads", type=int, default=8, help="worker threads for image decode / resize and PNG encoding (overlap the engine)")
     return ap.parse_args(argv)
 
 
@@ -65,18 +66,44 @@ def main(argv=None):
     pipe, (preproc, postproc) = load_diffusion_model(a.model, f"cuda:{local}" if world > 1 and backend == "nccl" else "cuda", variant=a.prec,
                                                      latent_size=a.size // 8, max_img=a.batch)
     editor = BatchEditor(pipe, num_inference_steps=a.steps, edit_method=a.edit_method)
+    from concurrent.futures import ThreadPoolExecutor
     from PIL import Image
-    t0, done, latents = time.time(), 0, {}
-    for b0 in range(0, len(todo), a.batch):
-        chunk = todo[b0:b0 + a.batch]
-        samples = [dict(image=preproc(s["image_file"]), source_prompt=s["source_prompt"], target_prompt=s["edit"]["target_prompt"],
-                        edit_word_idx=s["edit_word_idx"], ptp=s["edit"].get("ptp")) for _, s, _ in chunk]
-        for (i, _, f), res in zip(chunk, editor.edit(samples)):
-            if res is None:
-                continue                                            # failed edit: skipped like the reference (eval.py:103-105)
-            Image.fromarray(postproc(res["image"])).save(str(f))
-            latents[i] = res["latent"][0].cpu()
-            done += 1
+    from modules.models import StablePreprocess
+    # Host work off the engine's critical path: file decode + resize of the NEXT batch and PNG encoding of the PREVIOUS one run on worker
+    # threads (PIL / zlib / numpy release the GIL) while this thread enqueues the current batch's kernels; the device copies stay here.
+    pre_cpu = StablePreprocess("cpu", size=a.size)
+    pool = ThreadPoolExecutor(max_workers=max(1, a.io_threads))
+    chunks = [todo[b0:b0 + a.batch] for b0 in range(0, len(todo), a.batch)]
+    load = lambda chunk: [pool.submit(pre_cpu, s["image_file"]) for _, s, _ in chunk]
+    t0, done, latents, saves = time.time(), 0, {}, []
+    t_wait_load = t_edit = t_post = 0.0
+    nxt = load(chunks[0]) if chunks else None
+    for ci, chunk in enumerate(chunks):
+        ta = time.time()
+        images = [f.result().to(pipe.device) for f in nxt]
+        nxt = load(chunks[ci + 1]) if ci + 1 < len(chunks) else None
+        tb = time.time()
+        samples = [dict(image=img, source_prompt=s["source_prompt"], target_prompt=s["edit"]["target_prompt"],
+                        edit_word_idx=s["edit_word_idx"], ptp=s["edit"].get("ptp")) for img, (_, s, _) in zip(images, chunk)]
+        results = editor.edit(samples)
+        ok = [(i, f, res) for (i, _, f), res in zip(chunk, results) if res is not None]   # failed edits: skipped like the reference (eval.py:103-105)
+        if ok:
+            # one device -> host transfer for the whole batch (this is also where the batch's kernels are waited for)
+            imgs = (torch.cat([res["image"] for _, _, res in ok]) / 2 + 0.5).clamp(0, 1).mul(255).permute(0, 2, 3, 1).to(torch.uint8).cpu().numpy()
+            lats = torch.cat([res["latent"] for _, _, res in ok]).cpu()
+            tc = time.time()
+            for k, (i, f, _) in enumerate(ok):
+                saves.append(pool.submit(lambda arr, path: Image.fromarray(arr).save(path), imgs[k], str(f)))
+                latents[i] = lats[k]
+                done += 1
+        else:
+            tc = time.time()
+        t_wait_load += tb - ta
+        t_edit += tc - tb
+        t_post += time.time() - tc
+    for f in saves:
+        f.result()
+    pool.shutdown()
     if world > 1:
         import torch.distributed as dist
         if a.save_latents:                                         # the one exchange step: RCCL all_gather of 32 KiB per image
@@ -94,7 +121,8 @@ def main(argv=None):
     elif a.save_latents:
         torch.save(latents, str(Path(a.output) / "latents.pt"))
     dt = time.time() - t0
-    print(f"[rank {rank}] edited {done} of {len(todo)} images in {dt:.1f}s ({done / max(dt, 1e-9):.3f} images/s)")
+    print(f"[rank {rank}] edited {done} of {len(todo)} images in {dt:.1f}s ({done / max(dt, 1e-9):.3f} images/s); main thread: waited {t_wait_load:.2f}s for decoded "
+          f"inputs, {t_edit:.2f}s in BatchEditor.edit + device->host, {t_post:.2f}s handing results to the PNG workers")
 
 
 if __name__ == "__main__":
