@@ -160,3 +160,26 @@ def test_load_diffusion_model_fp32_variant():
     rec = p.vae.decode(z)["sample"]
     assert z.shape == (1, 4, 16, 16) and rec.shape == (1, 3, 128, 128) and torch.isfinite(rec).all()
     p.engine.close()
+
+
+# ------------------------------------------------------------------------------------------------ the third-party networks in fp32
+def test_vae_and_clip_f32_vs_oracle():
+    """`--prec fp32` also runs the VAE and the text encoder on the fp32-operand kernels: 1e-4 against the CPU oracle (fp16: 5e-3)"""
+    from oracle.vae import build_vae
+    from oracle.clip import build_clip
+    from etainv.nets import NativeVAE, NativeCLIPText
+    rel = lambda a, b: ((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm()).item()
+    ref, nat = build_vae(0), NativeVAE(None, F32, 0)
+    g = torch.Generator().manual_seed(64)
+    img, z = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1, torch.randn(2, 4, 8, 8, generator=g)
+    with torch.no_grad():
+        want_e, want_d = ref.encode_mean(img), ref.decode(z)
+    e_enc, e_dec = rel(nat.encode(img.cuda())["latent_dist"].mean, want_e), rel(nat.decode(z.cuda())["sample"], want_d)
+    clip_r, clip_n = build_clip(0), NativeCLIPText(None, F32, 0)
+    ids = torch.randint(0, 49408, (2, 77), generator=g)
+    ids[:, 0], ids[:, 20:] = 49406, 49407
+    with torch.no_grad():
+        want_c = clip_r(ids)[0]
+    e_clip = rel(clip_n(ids.cuda())[0], want_c)
+    print(f"fp32 nets vs oracle: VAE encode {e_enc:.2e}, decode {e_dec:.2e}, CLIP {e_clip:.2e}")
+    assert e_enc < 1e-4 and e_dec < 1e-4 and e_clip < 1e-4
