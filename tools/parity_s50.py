@@ -187,7 +187,9 @@ def main():
     ap.add_argument("--cache", default=str(ROOT / "profiles" / "_cache"))
     ap.add_argument("--cache-out", default=None, help="where NEW worker results are written (default: --cache); on the GPU box: gpurun_out/parity_cache")
     ap.add_argument("--out", default=None)
-    ap.add_argument("--max-workers", type=int, default=6)
+    ap.add_argument("--max-workers", type=int, default=2, help="concurrent oracle processes (the host's memory bandwidth, not its core count, bounds the CPU UNet: "
+                                                               "6 at once ran 4.7x slower each on the GPU box)")
+    ap.add_argument("--ref-pairs", type=int, default=None, help="run the ref_* (emulated 16-bit reference) subjects on the first N pairs only")
     # worker mode
     ap.add_argument("--oracle-worker", action="store_true")
     ap.add_argument("--pair", type=int, default=0)
@@ -202,7 +204,9 @@ def main():
     cache_out.mkdir(parents=True, exist_ok=True)
     kinds = ["fp32"] + [s[4:] for s in a.subjects if s.startswith("ref_")]
     name = lambda i, k: f"parity_S{a.S}_L{a.L}_pair{i}_{k}.pt"
-    todo = [(i, k) for i in range(a.pairs) for k in kinds if not (cache / name(i, k)).exists() and not (cache_out / name(i, k)).exists()]
+    ref_pairs = a.pairs if a.ref_pairs is None else a.ref_pairs
+    todo = [(i, k) for i in range(a.pairs) for k in kinds if (k == "fp32" or i < ref_pairs)
+            and not (cache / name(i, k)).exists() and not (cache_out / name(i, k)).exists()]
     procs = []
     if todo:
         nthreads = max(1, physical_cores() // min(len(todo), a.max_workers))
@@ -251,6 +255,8 @@ def main():
                     continue
                 sub = native[s][i]
             else:
+                if i >= ref_pairs:
+                    continue
                 sub = load(i, s[4:])
             report["subjects"].setdefault(s, {})[f"pair{i}"] = compare(sub, ref)
     # summary table
