@@ -967,6 +967,27 @@ extern "C" int etainv_prof_records(int cls, double* ms, double* work, int64_t ca
   return 0;
 }
 
+/* etainv_prof_records + the algorithmic HBM bytes of every launch (0 for classes that record none): joins a per-launch PMC traffic pass
+ * (tools/pmc_per_launch.py) with what each launch had to move at minimum */
+extern "C" int etainv_prof_records_ex(int cls, double* ms, double* work, double* bytes, int64_t cap, int64_t* launches) {
+  ETAINV_CHECK(cls >= 0 && cls < PROF_NCLASS && ms && work && bytes && launches && cap >= 0, "bad arguments");
+  ETAINV_HIP(hipDeviceSynchronize());
+  int64_t n = 0;
+  for (auto& r : g_prof)
+    if (r.cls == cls) {
+      if (n < cap) {
+        float f = 0.f;
+        ETAINV_HIP(hipEventElapsedTime(&f, r.a, r.b));
+        ms[n] = f;
+        work[n] = r.work;
+        bytes[n] = r.bytes;
+      }
+      ++n;
+    }
+  *launches = n;
+  return 0;
+}
+
 /* Roofline split of one class: launches whose arithmetic intensity work / bytes is at least `ridge` (FLOP per byte; MFMA peak / HBM peak) are
  * MFMA-bound, the rest HBM-bound.  out[0..2] = ms, FLOPs, bytes of the MFMA-bound launches; out[3..5] = the same of the HBM-bound ones. */
 extern "C" int etainv_prof_split(int cls, double ridge, double* out6, int64_t* launches2) {

@@ -56,6 +56,7 @@ SIGNATURES = {
     "etainv_prof_reset": [],
     "etainv_prof_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)],
     "etainv_prof_records": [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), _i64, C.POINTER(_i64)],
+    "etainv_prof_records_ex": [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _i64, C.POINTER(_i64)],
     "etainv_prof_split": [_i, C.c_double, C.POINTER(C.c_double), C.POINTER(_i64)],
     "etainv_op_gemm": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "etainv_op_gemm_ln": [_p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_i), _i, _i, _i, _i, _i, _p],

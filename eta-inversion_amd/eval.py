@@ -72,7 +72,20 @@ def main(argv=None):
     # Host work off the engine's critical path: file decode + resize of the NEXT batch and PNG encoding of the PREVIOUS one run on worker
     # threads (PIL / zlib / numpy release the GIL) while this thread enqueues the current batch's kernels; the device copies stay here.
     pre_cpu = StablePreprocess("cpu", size=a.size)
-    pool = ThreadPoolExecutor(max_workers=max(1, a.io_threads))
+    if a.io_threads > 0:
+        pool = ThreadPoolExecutor(max_workers=a.io_threads)
+    else:                                    # --io_threads 0: the host work runs inline on this thread (the unoverlapped baseline)
+        from concurrent.futures import Future
+
+        class _Inline:
+            def submit(self, fn, *args):
+                f = Future()
+                f.set_result(fn(*args))
+                return f
+
+            def shutdown(self):
+                pass
+        pool = _Inline()
     chunks = [todo[b0:b0 + a.batch] for b0 in range(0, len(todo), a.batch)]
     load = lambda chunk: [pool.submit(pre_cpu, s["image_file"]) for _, s, _ in chunk]
     t0, done, latents, saves = time.time(), 0, {}, []

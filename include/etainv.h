@@ -194,6 +194,8 @@ int etainv_prof_read(int cls, double* ms, double* work, int64_t* launches);
 /* The individual launches of one class since the last reset, in launch order: fills ms[i], work[i] for i < min(n, cap) and
  * returns n through *launches (per-shape breakdown of a UNet call: tools/unet_call.py --shapes). */
 int etainv_prof_records(int cls, double* ms, double* work, int64_t cap, int64_t* launches);
+/* same + bytes[i] = the algorithmic HBM bytes of launch i (every operand read once, the result written once; 0 where the class records none) */
+int etainv_prof_records_ex(int cls, double* ms, double* work, double* bytes, int64_t cap, int64_t* launches);
 
 /* Roofline split of the launches of one class by arithmetic intensity (algorithmic FLOPs / algorithmic HBM bytes of each launch): out6 =
  * {ms, FLOPs, bytes} of the launches at or above `ridge` FLOP/byte (MFMA-bound), then of those below it (HBM-bound); launches2 = their counts.

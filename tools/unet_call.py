@@ -15,6 +15,7 @@ ap.add_argument("--rows", type=int, default=128)
 ap.add_argument("--calls", type=int, default=2)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--shapes", action="store_true", help="event-time every launch of the last call and print time per distinct work size")
+ap.add_argument("--dump", default=None, help="with --shapes: write the igemm launches of the last call in launch order (ms, FLOPs, algorithmic bytes) as JSON")
 a = ap.parse_args()
 dt = {"fp16": torch.float16, "bf16": torch.bfloat16}[a.dtype]
 B = a.rows // 4
@@ -51,3 +52,10 @@ if a.shapes:
         for w, (cnt, tm) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
             print(f"   work {w:14.4g}  x{cnt:3d}  {tm:8.3f} ms  ({tm / cnt:7.3f} each)  {w * cnt / tm / 1e9:9.1f} G/s")
     print(f"total event-timed: {total:.2f} ms")
+    if a.dump:
+        import json
+        cap = 4096
+        ms, work, nbytes, n = (C.c_double * cap)(), (C.c_double * cap)(), (C.c_double * cap)(), C.c_int64(0)
+        _capi.check(lib.etainv_prof_records_ex(0, ms, work, nbytes, cap, C.byref(n)))
+        json.dump({"rows": a.rows, "dtype": a.dtype, "igemm": [{"ms": ms[i], "flops": work[i], "bytes": nbytes[i]} for i in range(min(n.value, cap))]},
+                  open(a.dump, "w"))
