@@ -86,13 +86,18 @@ __global__ void __launch_bounds__(256) igemm_f32_kernel(IGemmParams p) {
       rb[i] = n < p.N ? *reinterpret_cast<const f32x4*>(w + (int64_t)n * K + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
-  f32x16 acc[2][2];
+  // Two-level accumulation: the matrix instruction adds its products in k order (one rounding per product, a single chain), so a K = 11520
+  // conv would carry a 11520-term sequential sum; every FLUSH K tiles (64 k) the chain is closed into `tot` and restarted from zero -- the
+  // error of a sum of n terms grows like sqrt(n), and sqrt(64) + sqrt(K / 64) is 5x smaller than sqrt(K) at K = 11520 (measured against a
+  // float64 run of the oracle: tests/test_fp32_gpu.py::test_fp32_noise_floor_against_fp64).  64 v_add per 128 MFMAs.
+  constexpr int FLUSH = 2;
+  f32x16 acc[2][2], tot[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = tot[i][j][r] = 0.f;
 
   load(0);
   for (int kt = 0; kt < nk; ++kt) {
@@ -119,8 +124,22 @@ __global__ void __launch_bounds__(256) igemm_f32_kernel(IGemmParams p) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i][c], fb[j][c], acc[i][j]);
     }
+    if ((kt % FLUSH) == FLUSH - 1 || kt == nk - 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          tot[i][j] += acc[i][j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+    }
     __syncthreads();
   }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = tot[i][j];
 
   // ---- epilogue
   float* out = reinterpret_cast<float*>(p.out);

@@ -47,11 +47,11 @@ def relerr(a, b):
 PTP_CFG = dict(is_replace_controller=False, cross_replace_steps={"default_": .4}, self_replace_steps=.6)
 
 
-CASES = [  # editor, L, dtype, use_mask, tolerance on the edited latent (rel L2)
-    ("simple", 16, torch.float16, True, 3e-2), ("ptp", 16, torch.float16, True, 3e-2), ("masactrl", 16, torch.float16, True, 3e-2),
-    ("ptp_replace", 16, torch.float16, True, 3e-2), ("simple", 16, torch.float16, False, 3e-2),
-    ("ptp", 16, torch.bfloat16, True, 2e-1),
-    ("masactrl", 24, torch.float16, True, 3e-2),          # 768^2-style non-power-of-two token counts (N = 576 / 144 / 36 / 9)
+CASES = [  # editor, L, dtype, use_mask, tolerance on the edited latent (rel L2): 2x the value measured on MI355X in round 3 (8.5e-3 ... 9.2e-3 fp16, 7.0e-2 bf16)
+    ("simple", 16, torch.float16, True, 1.9e-2), ("ptp", 16, torch.float16, True, 1.8e-2), ("masactrl", 16, torch.float16, True, 1.9e-2),
+    ("ptp_replace", 16, torch.float16, True, 1.8e-2), ("simple", 16, torch.float16, False, 1.9e-2),
+    ("ptp", 16, torch.bfloat16, True, 1.4e-1),
+    ("masactrl", 24, torch.float16, True, 1.7e-2),          # 768^2-style non-power-of-two token counts (N = 576 / 144 / 36 / 9)
 ]
 
 
@@ -130,8 +130,9 @@ def test_edit_vs_oracle(setup, editor, L, dtype, use_mask, tol):
     e_tgt = relerr(out[B:].cpu(), ref_out[B:])
     print(f"{editor} L={L} {dtype} mask={use_mask} replace={replace}: inversion traj {e_inv:.2e}, word map {e_map:.2e}, latent_inv {e_src:.2e}, latent {e_tgt:.2e}")
     bf = dtype == torch.bfloat16
-    assert e_inv < (5e-2 if bf else 5e-3) and e_map < (1e-1 if bf else 2e-2)
-    assert e_src < (5e-2 if bf else 5e-3)          # source row replays the stored inversion trajectory (eta_inversion.py:247-249)
+    # measured (round 3): inversion trajectory 6.4e-4 / 5.0e-3, word map 2.3e-4 / 3.2e-3 (fp16 / bf16); bounds at 2x
+    assert e_inv < (1e-2 if bf else 1.3e-3) and e_map < (6.4e-3 if bf else 5e-4)
+    assert e_src < 1e-6                            # source row replays the stored inversion trajectory exactly (eta_inversion.py:247-249)
     assert e_tgt < tol
 
 
@@ -162,7 +163,8 @@ def test_mask_modes_vs_oracle(setup, mode):
     loop = EtaLoop(eng, S=S, eta=(0.0, 0.4), use_mask=True, mask_thres=mode.get("thres", 0.2), mask_eta=mode["mask_eta"], mask_pow=mode.get("pow"))
     inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
     out = loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), noise.reshape(S, 10, 4, L, L).cuda(), edit_word=torch.tensor([1, 1]), gt_mask=gt)
-    assert relerr(out[:B].cpu(), ref[:B]) < 5e-3 and relerr(out[B:].cpu(), ref[B:]) < 3e-2
+    print(f"source row {relerr(out[:B].cpu(), ref[:B]):.2e}, edited latent {relerr(out[B:].cpu(), ref[B:]):.2e}")
+    assert relerr(out[:B].cpu(), ref[:B]) < 1e-6 and relerr(out[B:].cpu(), ref[B:]) < 3e-2
 
 
 @pytest.mark.parametrize("mode", ["bwd_source", "bwd_target", "bwd_source_target"])
@@ -204,7 +206,8 @@ def test_bwd_mask_sources_vs_oracle(setup, mode):
     inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
     out = loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), noise.reshape(S, 10, 4, L, L).cuda(), edit_word=torch.tensor([1, 1]), ptp=ptp,
                       edit_word_tgt=torch.tensor([1, 1]))
-    assert relerr(out[:B].cpu(), ref[:B]) < 5e-3 and relerr(out[B:].cpu(), ref[B:]) < 3e-2
+    print(f"source row {relerr(out[:B].cpu(), ref[:B]):.2e}, edited latent {relerr(out[B:].cpu(), ref[B:]):.2e}")
+    assert relerr(out[:B].cpu(), ref[:B]) < 1e-6 and relerr(out[B:].cpu(), ref[B:]) < 3e-2
 
 
 @pytest.mark.parametrize("mask_eta,mask_dirinv", [("fwd_mean", "fwd_mean"), ("fwd_mean", "gt"), ("gt", "fwd")])
@@ -235,7 +238,8 @@ def test_target_dirinv_vs_oracle(setup, mask_eta, mask_dirinv):
     loop = EtaLoop(eng, S=S, eta=(0.0, 0.4), use_mask=True, mask_thres=0.3, mask_eta=mask_eta, target_dirinv=0.6, mask_dirinv=mask_dirinv)
     inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
     out = loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), noise.reshape(S, 10, 4, L, L).cuda(), edit_word=torch.tensor([1, 1]), gt_mask=gt)
-    assert relerr(out[:B].cpu(), ref[:B]) < 5e-3 and relerr(out[B:].cpu(), ref[B:]) < 3e-2
+    print(f"source row {relerr(out[:B].cpu(), ref[:B]):.2e}, edited latent {relerr(out[B:].cpu(), ref[B:]):.2e}")
+    assert relerr(out[:B].cpu(), ref[:B]) < 1e-6 and relerr(out[B:].cpu(), ref[B:]) < 3e-2
 
 
 def test_forward_guidance_table_vs_oracle(setup):
@@ -253,4 +257,5 @@ def test_forward_guidance_table_vs_oracle(setup):
     loop = EtaLoop(eng, S=S, use_mask=False, guidance_scale_fwd=(1.0, 3.0))
     assert not loop.skip_uncond_fwd
     inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
+    print(f"inversion trajectory {relerr(inv['latents'].cpu(), ref):.2e}")
     assert relerr(inv["latents"].cpu(), ref) < 5e-3

@@ -231,15 +231,33 @@ def test_etainv_ptp_L64_teacher_forced(oracle_run, lowprec_unets, dtype):
             check(e_tgt < (1e-1 if bf else 1.2e-2), f"bwd step {i} target latent {e_tgt:.2e}")   # measured 2.3e-3 ... 7.6e-3 / 1.9e-2 ... 6e-2
             check(e_tgt <= max(1.5 * floor["tgt"][i], 1e-6), f"bwd step {i} target latent {e_tgt:.2e} vs floor {floor['tgt'][i]:.2e}")
 
-    # ---- free-running native run vs the oracle's result (rounding now recurses through 2 S UNet calls)
+    # ---- free-running native run vs the oracle's result (rounding now recurses through 2 S UNet calls).  A best-of-n choice that differs from
+    # the oracle's forks the trajectory (another noise sample): the latent bound applies to runs whose choices all agree; a disagreement must be
+    # between candidates the oracle itself ranks within 2 % (bf16) / 0.2 % (fp16) of each other
     inv_f = loop.invert(z0b, cs, tokens.cuda())
-    out = loop.sample(inv_f, cs, ct, nz, edit_word=edit_word, ptp=ptp)
+    trace_f = []
+    out = loop.sample(inv_f, cs, ct, nz, edit_word=edit_word, ptp=ptp, trace=trace_f)
     torch.cuda.synchronize()
     ref_out = torch.cat([torch.stack([runs[p]["out"][0] for p in sel]), torch.stack([runs[p]["out"][1] for p in sel])])
     e_inv, e_fs, e_ft = relerr(inv_f["latents"].cpu(), ref_inv), relerr(out[:B].cpu(), ref_out[:B]), relerr(out[B:].cpu(), ref_out[B:])
-    print(f"[{dtype}] free-running S={S}: inversion trajectory rel L2 {e_inv:.2e}, latent_inv {e_fs:.2e}, edited latent {e_ft:.2e}")
-    # measured (round 2): 5.8e-4 / 8.2e-3 fp16, 4.8e-3 / 6.6e-2 bf16 -- bounds at 2x; the S = 50 figures are in profiles/r03_parity_S50.json
-    check(e_inv < (1e-2 if bf else 1.2e-3) and e_fs < (1e-2 if bf else 1.2e-3) and e_ft < (1.4e-1 if bf else 1.7e-2), "free-running bounds")
+    forks = []
+    for i in range(S):
+        for b in range(B):
+            bn, br = int(trace_f[i]["best"][b]), runs[sel[b]]["trace"][i]["best"]
+            if bn != br and not any(f[1] == b for f in forks):             # (only the first disagreement of an image is on the oracle's trajectory)
+                ls = runs[sel[b]]["trace"][i]["losses"]
+                forks.append((i, b, abs(float(ls[bn] - ls[br])) / float(ls[br])))
+    print(f"[{dtype}] free-running S={S}: inversion trajectory rel L2 {e_inv:.2e}, latent_inv {e_fs:.2e}, edited latent {e_ft:.2e}; best-of-n forks (step, image, "
+          f"oracle loss gap) {forks}")
+    # measured (rounds 2 / 3): 5.8e-4 / 8.2e-3 fp16, 4.8e-3 / 6.6e-2 bf16 -- bounds at 2x; the S = 50 figures are in profiles/r03_parity_S50.json
+    check(e_inv < (1e-2 if bf else 1.2e-3) and e_fs < (1e-2 if bf else 1.2e-3), "free-running inversion bounds")
+    for i, b, gap in forks:
+        check(gap < (2e-2 if bf else 2e-3), f"free-running: image {b} forks at step {i} between candidates {gap:.2e} apart in the oracle")
+    keep = [b for b in range(B) if not any(f[1] == b for f in forks)]
+    if keep:
+        e_keep = relerr(out[B:].cpu()[keep], ref_out[B:][keep])
+        print(f"[{dtype}] free-running edited latent of the {len(keep)} images without a fork: {e_keep:.2e}")
+        check(e_keep < (1.4e-1 if bf else 1.7e-2), f"free-running edited latent {e_keep:.2e}")
     eng.close()
     assert not fails, fails
 
