@@ -454,6 +454,18 @@ struct Fwd {
     if (idx >= 0) part_wm[idx] = wm;
     return 0;
   }
+  // Context-independent prefix (see unet_body): a tensor computed for the first `half` batch rows is copied to rows half .. 2 half - 1, together
+  // with the GroupNorm partials its producer left (row blocks are batch-row major: the first half is a prefix of the buffer)
+  int dup_rows(void* buf, int half, size_t elems_per_row) {
+    const size_t bytes = (size_t)half * elems_per_row * e->esz;
+    ETAINV_HIP(hipMemcpyAsync(reinterpret_cast<char*>(buf) + bytes, buf, bytes, hipMemcpyDeviceToDevice, s));
+    const int idx = part_of(buf);
+    if (idx >= 0 && part_wm[idx] > 0) {
+      const size_t pbytes = elems_per_row * half / part_wm[idx] * 2 * sizeof(float);   // [rows * hw / wm][2][C]: elems_per_row = hw * C
+      ETAINV_HIP(hipMemcpyAsync(reinterpret_cast<char*>(e->gn_part[idx]) + pbytes, e->gn_part[idx], pbytes, hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+  }
   int groupnorm(const void* x1, const void* x2, int c1, int c2, const Norm& nm, int hw, float eps, int silu) {
     const int i1 = part_of(x1), i2 = x2 ? part_of(x2) : -1;
     const int w1 = i1 >= 0 ? part_wm[i1] : 0, w2 = i2 >= 0 ? part_wm[i2] : 0;
@@ -537,10 +549,23 @@ struct Fwd {
     }
     return conv(e->gnbuf, r.conv2, out, side, side, 1, 0, nullptr, residual);
   }
-  int transformer(const TBlock& t, const void* x, int side, void* out) {
-    const int hw = side * side, M = rows * hw, c = t.c, d = c / etainv_engine::kHeads;
+  // self_rows (0 = all): the sublayers in front of the cross-attention (GroupNorm, proj_in, QKV, self-attention, to_out + residual) do not see
+  // the text context; when batch rows r and r + self_rows carry the same latent and timestep (the uncond / cond halves of a CFG call) they are
+  // computed for the first self_rows rows only and their result (the residual stream entering the cross-attention) is copied to the other half
+  int transformer(const TBlock& t, const void* x, int side, void* out, int self_rows = 0) {
+    const int hw = side * side, c = t.c, d = c / etainv_engine::kHeads;
     const int blk = tblock_idx++;
     const bool fold = e->ln_fused;
+    int mode = 0, n_img = 1;
+    if (ctrl) {
+      n_img = ctrl->n_img;
+      if (ctrl->mode == ETAINV_ATTN_PTP && ctrl->self_replace_active && hw <= ctrl->self_max_tokens) mode = 1;
+      if (ctrl->mode == ETAINV_ATTN_MASA && ctrl->masa_active && blk >= ctrl->masa_first_block) mode = 2;
+    }
+    const int all_rows = rows;
+    if (self_rows <= 0 || self_rows >= all_rows || mode != 0 || e->gn_fold) self_rows = all_rows;   // (a row remap couples the halves: no sharing)
+    rows = self_rows;
+    int M = rows * hw;
     // The GroupNorm in front of proj_in has no activation: with its statistics known from the producer's epilogue it becomes a per-image scaling
     // of proj_in's input channels + a per-image bias -- folded into per-image copies of the (small) weight matrix instead of a pass over x.
     // Levels with C <= 640 (C = 1280: the 128 weight copies would cost more than the pass) and images that are whole M tiles.
@@ -566,14 +591,15 @@ struct Fwd {
       if (launch_layernorm(e->hsA, t.ln1.g, t.ln1.b, e->lnbuf, M, c, 1e-5f, e->dt, s)) return 1;
       if (gemm(e->lnbuf, t.qkv, e->qkvbuf, M)) return 1;
     }
-    int mode = 0, n_img = 1;
-    if (ctrl) {
-      n_img = ctrl->n_img;
-      if (ctrl->mode == ETAINV_ATTN_PTP && ctrl->self_replace_active && hw <= ctrl->self_max_tokens) mode = 1;
-      if (ctrl->mode == ETAINV_ATTN_MASA && ctrl->masa_active && blk >= ctrl->masa_first_block) mode = 2;
-    }
     if (launch_self_attention_mode(e->qkvbuf, e->attnbuf, rows, hw, etainv_engine::kHeads, d, mode, n_img, e->dt, s, /*q_prescaled=*/d <= 80 && self_attn40_v2_enabled() && e->dt != ETAINV_F32)) return 1;
     if (gemm(e->attnbuf, t.out1, e->hsB, M, e->hsA, 0, nullptr, 0, 0, fold)) return 1;
+    if (self_rows != all_rows) {   // the other half of the batch enters the cross-attention with the same residual stream (and LayerNorm statistics)
+      const size_t bytes = (size_t)M * c * e->esz;
+      ETAINV_HIP(hipMemcpyAsync(reinterpret_cast<char*>(e->hsB) + bytes, e->hsB, bytes, hipMemcpyDeviceToDevice, s));
+      if (fold) ETAINV_HIP(hipMemcpyAsync(e->lnfinal + (size_t)M * 2, e->lnfinal, (size_t)M * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+      rows = all_rows;
+      M = rows * hw;
+    }
     // cross-attention
     if (fold) {
       const LnIn ln2{t.s_q, t.c_q};
@@ -805,14 +831,23 @@ static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const in
   if (!f.kv_reuse && launch_cast_f32(ctx, io_dtype, e->ctxT, e->dt, (int64_t)n_rows * etainv_engine::kCtx * etainv_engine::kCtxDim, s)) return 1;
 
   // ---- down path
-  if (launch_im2col_in(latent, io_dtype, n_lat, n_rows, L, e->gnbuf, e->dt, s)) return 1;
+  // Context-independent prefix: with classifier-free guidance the call carries every latent twice (rows r and r + n_lat: uncond / cond context,
+  // same latent, same timestep).  Nothing in front of the first cross-attention reads the context -- conv_in, the first residual block and the first
+  // transformer block's GroupNorm / proj_in / QKV / self-attention (N = L^2: the most expensive launch of the call) / to_out -- so those run on
+  // n_lat rows and their results are copied to the other half (3 device copies, ~0.3 ms, for 2.6 % of a 128-row call).  The reference evaluates
+  // both halves (eta_inversion.py:320-321 `torch.cat([latent] * 2)`); the values are the same.  ETAINV_NO_PREFIX_SHARE=1: A/B switch.
+  bool share = getenv("ETAINV_NO_PREFIX_SHARE") == nullptr && n_rows == 2 * n_lat && !e->gn_fold;
+  for (int r = 0; share && r < n_lat; ++r) share = t_host[r] == t_host[r + n_lat];
+  const int pre_rows = share ? n_lat : n_rows;
+  f.rows = pre_rows;
+  if (launch_im2col_in(latent, io_dtype, n_lat, pre_rows, L, e->gnbuf, e->dt, s)) return 1;
   {
     Lin cin_l;
     cin_l.w = e->conv_in_w;
     cin_l.b = e->conv_in_b;
     cin_l.n = etainv_engine::kCh0;
     cin_l.k = 64;
-    if (f.gemm(e->gnbuf, cin_l, e->skip[0], n_rows * L * L, nullptr, 0, nullptr, 0, 0, false, nullptr, /*gn_out=*/true)) return 1;
+    if (f.gemm(e->gnbuf, cin_l, e->skip[0], pre_rows * L * L, nullptr, 0, nullptr, 0, 0, false, nullptr, /*gn_out=*/true)) return 1;
   }
   const int ch[4] = {320, 640, 1280, 1280};
   int ri = 0, ti = 0, si = 1, side = L;
@@ -823,7 +858,12 @@ static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const in
       if (i < 3) {
         void* r_out = pick_tmp(e, h, nullptr);
         if (f.resblock(e->res[ri++], h, nullptr, hc, 0, side, r_out)) return 1;
-        if (f.transformer(e->tb[ti++], r_out, side, e->skip[si])) return 1;
+        const bool first = i == 0 && j == 0;
+        if (first && share) {   // skip[0] (a skip connection of the up path) and the block input (proj_out's residual) are needed for all rows
+          if (f.dup_rows(e->skip[0], pre_rows, (size_t)L * L * etainv_engine::kCh0) || f.dup_rows(r_out, pre_rows, (size_t)L * L * ch[0])) return 1;
+        }
+        f.rows = n_rows;
+        if (f.transformer(e->tb[ti++], r_out, side, e->skip[si], first && share ? pre_rows : 0)) return 1;
       } else {
         if (f.resblock(e->res[ri++], h, nullptr, hc, 0, side, e->skip[si])) return 1;
       }

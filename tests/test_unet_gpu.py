@@ -158,3 +158,48 @@ def test_context_cache_generation_and_error_paths(engines):
         with pytest.raises(_capi.EtainvError):
             e.unet(x, 300, big)
         assert torch.equal(e.unet(x, 300, buf), ref1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("mode", ["plain", "ptp", "masa"])
+def test_context_independent_prefix_is_shared_not_changed(engines, dtype, mode):
+    """A CFG call carries every latent twice (uncond / cond rows): conv_in, the first residual block and the first transformer block up to its
+    cross-attention do not read the context and run on half the rows (engine.cpp, unet_body).  The result must equal the unshared execution
+    (ETAINV_NO_PREFIX_SHARE=1) bit for bit -- with the attention controls of the backward pass too -- and rows with DIFFERENT timesteps must not
+    be shared."""
+    import os
+    from etainv import _capi
+    from etainv.engine import AttnControl
+    e = engines(dtype, 16)
+    g = torch.Generator().manual_seed(21)
+    n_img = 2
+    x = torch.randn(2 * n_img, 4, 16, 16, generator=g).cuda()              # [src.., tgt..]
+    ctx = torch.randn(4 * n_img, 77, 768, generator=g).cuda()              # [u_s.., u_t.., c_s.., c_t..]
+    ca = torch.ones(n_img, 77).cuda()
+    mapper = torch.arange(77, dtype=torch.int32).repeat(n_img, 1).cuda()
+    al = torch.ones(n_img, 77).cuda()
+
+    def ctrl():
+        if mode == "ptp":
+            return AttnControl(mode=_capi.ATTN_PTP, n_img=n_img, store_maps=False, mapper=mapper, alphas=al, cross_alpha=ca, self_replace_active=True,
+                               self_max_tokens=64)
+        if mode == "masa":
+            return AttnControl(mode=_capi.ATTN_MASA, n_img=n_img, masa_active=True, masa_first_block=10)
+        return None
+    # (split-K picks its part count from the tile count, i.e. from the row count: pinned off for the bit-for-bit comparison, on for the close one)
+    os.environ["ETAINV_NO_SPLITK"] = "1"
+    try:
+        shared = e.unet(x, 481, ctx, ctrl()).clone()
+        os.environ["ETAINV_NO_PREFIX_SHARE"] = "1"
+        full = e.unet(x, 481, ctx, ctrl()).clone()
+    finally:
+        os.environ.pop("ETAINV_NO_PREFIX_SHARE", None)
+        del os.environ["ETAINV_NO_SPLITK"]
+    assert torch.equal(shared, full)
+    assert relerr(e.unet(x, 481, ctx, ctrl()), full) < (1e-5 if dtype == torch.float32 else 2e-3 if dtype == torch.float16 else 1.5e-2)
+    assert not torch.equal(shared[:2 * n_img], shared[2 * n_img:])           # the halves differ (different contexts)
+    if mode == "plain":                                                      # per-row timesteps that differ between the halves: no sharing, still right
+        t = [481] * (2 * n_img) + [301] * (2 * n_img)
+        a = e.unet(x, t, ctx)
+        b = torch.cat([e.unet(x, 481, ctx[:2 * n_img]), e.unet(x, 301, ctx[2 * n_img:])])
+        assert torch.equal(a, b)
