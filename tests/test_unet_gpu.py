@@ -201,5 +201,5 @@ def test_context_independent_prefix_is_shared_not_changed(engines, dtype, mode):
     if mode == "plain":                                                      # per-row timesteps that differ between the halves: no sharing, still right
         t = [481] * (2 * n_img) + [301] * (2 * n_img)
         a = e.unet(x, t, ctx)
-        b = torch.cat([e.unet(x, 481, ctx[:2 * n_img]), e.unet(x, 301, ctx[2 * n_img:])])
-        assert torch.equal(a, b)
+        b = torch.cat([e.unet(x, 481, ctx[:2 * n_img].contiguous()), e.unet(x, 301, ctx[2 * n_img:].contiguous())])
+        assert relerr(a, b) < (1e-5 if dtype == torch.float32 else 2e-3 if dtype == torch.float16 else 1.5e-2)
