@@ -128,6 +128,16 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   const int my_tiles = (total_tiles - (int)blockIdx.x + G - 1) / G;
   auto tile_origin = [&](int i, int& m0, int& n0) -> int {   // returns the K part of virtual tile i
     int v = blockIdx.x + i * G;
+    if (p.xcd_gn > 1) {
+      // 2-D XCD grid (launch_igemm_t checked the divisibilities): XCD x = v & 7 owns M panels [xm * mr, (xm + 1) * mr) x N tiles [xn * nr, (xn + 1) * nr)
+      // and walks them n fastest: its slice of the weight matrix (N / gn rows) is what its L2 keeps or re-streams, not the whole matrix
+      const int gn = p.xcd_gn, x = v & 7, j = v >> 3;
+      const int nr = tiles_n / gn, mr = (total_tiles / tiles_n) / (8 / gn);
+      const int ml = j / nr, nl = j - ml * nr;
+      m0 = ((x / gn) * mr + ml) * BM;
+      n0 = ((x % gn) * nr + nl) * BN;
+      return 0;
+    }
     if ((total_tiles & 7) == 0) v = (v & 7) * (total_tiles >> 3) + (v >> 3);
     const int part = ksplit > 1 ? v % ksplit : 0;
     if (ksplit > 1) v /= ksplit;
@@ -1058,6 +1068,44 @@ static double igemm_algo_bytes(const IGemmParams& p) {
                 (p.residual ? out_el : 0.0));
 }
 
+// Tile order across the 8 XCDs (each has its own 4 MiB L2; workgroup b runs on XCD b & 7).  With the 1-D order every XCD walks ALL N tiles of its
+// M range, so a weight matrix that does not fit its L2 is re-streamed from the fabric once per wave of concurrently running tiles: the PMC pass of
+// round 3 (profiles/r03_pmc_per_shape_rows128.json) shows 3.6 GB fetched for the 0.18 GB of operands of the C = 640 GEGLU projection, 5-10 GB for the
+// deep-K convs -- 3.5-4.3 TB/s at the fabric while the kernel runs.  A gm x gn XCD grid gives every XCD an N range (weights / gn: resident in L2, or
+// re-streamed gn times less often) at the price of reading every activation panel from gn XCDs.  Model per launch, bytes at the fabric:
+//   weights  W / gn per XCD; resident if <= 2.5 MB (read once), else once per wave of concurrently running tiles of that XCD
+//   activations  gn x A
+// gn = the minimiser over {1, 2, 4, 8} that divides the tile grid; ETAINV_XCD_GN=1 restores the 1-D order (A/B), =2/4/8 forces a value where it divides.
+static int pick_xcd_gn(const IGemmParams& p, int BM, int BN, int grid, int tiles) {
+  if (p.ksplit > 1 || (tiles & 7) != 0 || (grid & 7) != 0) return 1;
+  const int tiles_n = cdiv(p.N, BN), tiles_m = tiles / tiles_n;
+  static const int forced = getenv("ETAINV_XCD_GN") ? atoi(getenv("ETAINV_XCD_GN")) : 0;
+  const double esz = 2.0, K = (double)p.taps * (p.c1 + p.c2);
+  const double W = (double)p.N * K * esz;
+  const double batch = (double)p.M / (double)p.rows_per_batch;
+  const double A = (p.taps == 9 ? batch * (double)p.H * (double)p.W : (double)p.M) * (double)(p.c1 + p.c2) * esz;
+  if (forced == 1) return 1;
+  int best = 1;
+  double best_cost = 0.0;
+  const double waves = std::max(1.0, (double)tiles / (double)grid);               // tile rounds of the persistent grid
+  for (int gn = 1; gn <= 8; gn *= 2) {
+    if (gn > 1 && (tiles_n % gn != 0 || tiles_m % (8 / gn) != 0)) continue;   // (gn = 1 is the 1-D order: no divisibility needed)
+    if (forced > 1) {
+      if (gn == forced) return gn;
+      continue;
+    }
+    const double w_slice = W / gn;
+    const double span = std::min(1.0, (double)(grid / 8) / (double)(tiles_n / gn));   // share of the XCD's N range one round of its CUs covers
+    const double w_cost = w_slice <= 2.5e6 ? w_slice * 8.0 : w_slice * span * waves * 8.0;
+    const double cost = w_cost + gn * A;
+    if (best_cost == 0.0 || cost < best_cost * 0.9) {   // (10 % hysteresis towards the smaller gn)
+      best = gn;
+      best_cost = cost;
+    }
+  }
+  return forced > 1 ? 1 : best;
+}
+
 template <typename T, int BM, int BN, int WAVES_M, int STAGES = 2, bool UPS = false, int LN = 0>
 static int launch_igemm_t(const IGemmParams& p_in, hipStream_t s, int* stat_P = nullptr) {
   IGemmParams p = p_in;
@@ -1123,6 +1171,7 @@ static int launch_igemm_t(const IGemmParams& p_in, hipStream_t s, int* stat_P = 
   }
   return 0;
 #endif
+  p.xcd_gn = pick_xcd_gn(p, BM, BN, grid, tiles);
   ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s, igemm_algo_bytes(p));
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS, LN>), dim3(grid), dim3(WAVES_M * 128), lds, s, p);
   ETAINV_LAUNCH_CHECK();

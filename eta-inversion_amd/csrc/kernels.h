@@ -30,6 +30,7 @@ struct IGemmParams {
   int Ho = 1, Wo = 1;         // output spatial dims
   int stride = 1, ups = 0, taps = 1;
   int geglu = 0;
+  int xcd_gn = 1;             // XCD grid along N for the tile order (1, 2, 4 or 8; chosen by launch_igemm_t from a traffic model, see there)
   int ksplit = 1;             // split-K parts (filled in by launch_igemm for small M*N with deep K)
   float* ws = nullptr;        // [ksplit][M][N] fp32 partials
   int rows_per_batch = 1;     // Ho*Wo for convs; M/batch for linears
