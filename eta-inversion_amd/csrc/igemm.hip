@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   const int my_tiles = (total_tiles - (int)blockIdx.x + G - 1) / G;
   auto tile_origin = [&](int i, int& m0, int& n0) -> int {   // returns the K part of virtual tile i
     int v = blockIdx.x + i * G;
-    if (p.xcd_gn > 1) {
+    if (STAGES == 3 && p.xcd_gn > 1) {   // (ring kernels only: the two-slot kernels have no registers to spare for it)
       // 2-D XCD grid (launch_igemm_t checked the divisibilities): XCD x = v & 7 owns M panels [xm * mr, (xm + 1) * mr) x N tiles [xn * nr, (xn + 1) * nr)
       // and walks them n fastest: its slice of the weight matrix (N / gn rows) is what its L2 keeps or re-streams, not the whole matrix
       const int gn = p.xcd_gn, x = v & 7, j = v >> 3;
@@ -1171,7 +1171,7 @@ static int launch_igemm_t(const IGemmParams& p_in, hipStream_t s, int* stat_P = 
   }
   return 0;
 #endif
-  p.xcd_gn = pick_xcd_gn(p, BM, BN, grid, tiles);
+  p.xcd_gn = STAGES == 3 ? pick_xcd_gn(p, BM, BN, grid, tiles) : 1;
   ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s, igemm_algo_bytes(p));
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS, LN>), dim3(grid), dim3(WAVES_M * 128), lds, s, p);
   ETAINV_LAUNCH_CHECK();
