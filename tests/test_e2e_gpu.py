@@ -164,7 +164,7 @@ def test_mask_modes_vs_oracle(setup, mode):
     inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
     out = loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), noise.reshape(S, 10, 4, L, L).cuda(), edit_word=torch.tensor([1, 1]), gt_mask=gt)
     print(f"source row {relerr(out[:B].cpu(), ref[:B]):.2e}, edited latent {relerr(out[B:].cpu(), ref[B:]):.2e}")
-    assert relerr(out[:B].cpu(), ref[:B]) < 1e-6 and relerr(out[B:].cpu(), ref[B:]) < 3e-2
+    assert relerr(out[:B].cpu(), ref[:B]) < 1e-6 and relerr(out[B:].cpu(), ref[B:]) < 1.9e-2     # measured 8.5e-3 ... 9.6e-3 (round 3); bound at 2x
 
 
 @pytest.mark.parametrize("mode", ["bwd_source", "bwd_target", "bwd_source_target"])
@@ -207,7 +207,7 @@ def test_bwd_mask_sources_vs_oracle(setup, mode):
     out = loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), noise.reshape(S, 10, 4, L, L).cuda(), edit_word=torch.tensor([1, 1]), ptp=ptp,
                       edit_word_tgt=torch.tensor([1, 1]))
     print(f"source row {relerr(out[:B].cpu(), ref[:B]):.2e}, edited latent {relerr(out[B:].cpu(), ref[B:]):.2e}")
-    assert relerr(out[:B].cpu(), ref[:B]) < 1e-6 and relerr(out[B:].cpu(), ref[B:]) < 3e-2
+    assert relerr(out[:B].cpu(), ref[:B]) < 1e-6 and relerr(out[B:].cpu(), ref[B:]) < 1.9e-2     # measured 8.5e-3 ... 9.6e-3 (round 3); bound at 2x
 
 
 @pytest.mark.parametrize("mask_eta,mask_dirinv", [("fwd_mean", "fwd_mean"), ("fwd_mean", "gt"), ("gt", "fwd")])
@@ -239,7 +239,7 @@ def test_target_dirinv_vs_oracle(setup, mask_eta, mask_dirinv):
     inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
     out = loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), noise.reshape(S, 10, 4, L, L).cuda(), edit_word=torch.tensor([1, 1]), gt_mask=gt)
     print(f"source row {relerr(out[:B].cpu(), ref[:B]):.2e}, edited latent {relerr(out[B:].cpu(), ref[B:]):.2e}")
-    assert relerr(out[:B].cpu(), ref[:B]) < 1e-6 and relerr(out[B:].cpu(), ref[B:]) < 3e-2
+    assert relerr(out[:B].cpu(), ref[:B]) < 1e-6 and relerr(out[B:].cpu(), ref[B:]) < 1.9e-2     # measured 8.5e-3 ... 9.6e-3 (round 3); bound at 2x
 
 
 def test_forward_guidance_table_vs_oracle(setup):
@@ -258,4 +258,4 @@ def test_forward_guidance_table_vs_oracle(setup):
     assert not loop.skip_uncond_fwd
     inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
     print(f"inversion trajectory {relerr(inv['latents'].cpu(), ref):.2e}")
-    assert relerr(inv["latents"].cpu(), ref) < 5e-3
+    assert relerr(inv["latents"].cpu(), ref) < 2.3e-3                                             # measured 1.13e-3 (round 3); bound at 2x

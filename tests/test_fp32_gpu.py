@@ -86,7 +86,7 @@ def test_unet_f32_vs_oracle(oracle_unet, L, rows):
     err = relerr(out, ref)
     print(f"fp32 UNet L={L} rows={rows}: rel L2 {err:.2e}, max abs {float((out - ref).abs().max()):.2e} (|ref| max {float(ref.abs().max()):.2f})")
     e.close()
-    assert err < 1e-5
+    assert err < 3e-6                                                              # measured 0.9e-6 ... 1.1e-6
     assert torch.allclose(out, ref, rtol=1e-3, atol=1e-4)
 
 
@@ -146,10 +146,10 @@ def within_tol(a, b):
 
 @pytest.mark.parametrize("editor,L,S", [("ptp", 16, 6), ("masactrl", 16, 6), ("simple", 16, 6), ("ptp", 64, 3)])
 def test_etainv_f32_meets_north_star_tolerance(oracle_unet, editor, L, S):
-    """free-running etainv + editor in the fp32-operand mode vs the fp32 oracle.  Measured on MI355X (round 3): edited latent rel L2 2e-5 (north_star:
-    <= 1e-3 latent L2 -- met with a factor 50), inversion trajectory 1.2e-6, max abs 3e-4 on values up to 4: the residual is fp32 summation-order
-    noise of two different fp32 implementations (PyTorch-CPU vs this engine) through the 7.5 x CFG amplification; elementwise, > 99.5 % of the edited
-    latent sits inside rtol 1e-3 / atol 1e-4 and the test below shows the oracle's OWN fp32 run is as far from an fp64 run of the same graph.
+    """free-running etainv + editor in the fp32-operand mode vs the fp32 oracle: north_star's tolerance AS WRITTEN -- torch.allclose(rtol 1e-3, atol 1e-4)
+    on the edited latents, the source row and the whole inversion trajectory, and latent L2 <= 1e-3.  Measured on MI355X (round 3, after the two-level
+    accumulation of csrc/f32path.hip): edited latent rel L2 7e-6 ... 9e-6, max abs 6e-5 ... 1.6e-4 on values up to 4, inversion trajectory 4e-7 ... 6e-7.
+    What is left is fp32 summation-order noise of two fp32 implementations through the 7.5 x CFG amplification (next test: both against float64).
     eta (0.2, 0.7) keeps the best-of-n choice live at every step."""
     inv_n, inv_r, out, ref = _run_pair(oracle_unet, editor, L, S, (0.2, 0.7))
     e_inv, e_src, e_tgt = relerr(inv_n, inv_r), relerr(out[0], ref[0]), relerr(out[1], ref[1])
@@ -159,14 +159,15 @@ def test_etainv_f32_meets_north_star_tolerance(oracle_unet, editor, L, S):
     assert torch.allclose(inv_n, inv_r, rtol=1e-3, atol=1e-4)                      # the inversion trajectory: as written
     assert torch.allclose(out[0], ref[0], rtol=1e-3, atol=1e-4)                    # the source row: as written
     assert e_tgt < 1e-4                                                            # north_star: <= 1e-3 latent L2
-    assert frac > 0.995 and float((out[1] - ref[1]).abs().max()) < 1e-3
+    assert torch.allclose(out[1], ref[1], rtol=1e-3, atol=1e-4), f"share inside the tolerance {frac:.5f}"   # the edited latent: as written
 
 
 def test_fp32_noise_floor_against_fp64(oracle_unet):
     """What elementwise agreement between two fp32 executions of this graph CAN be: the oracle run in float64 is the arithmetic truth; the fp32
     oracle (PyTorch-CPU kernels) and the fp32-operand engine (k-ordered fmaf chains of the f32 MFMA) are two fp32 implementations of it.  The
     engine's error against the truth must be of the oracle's order (<= 3 x: the matrix instruction accumulates K sequentially, blocked CPU kernels
-    reduce in a tree), per UNet call and for the free-running edited latent."""
+    reduce in a tree -- which is why f32path.hip closes its accumulation chain every 64 k: 2.2e-6 -> 6.5e-7 per UNet call, the oracle's 8.9e-7),
+    per UNet call and for the free-running edited latent."""
     import copy
     from etainv.engine import Engine
     L, rows = 16, 4
@@ -183,14 +184,14 @@ def test_fp32_noise_floor_against_fp64(oracle_unet):
     e_nat, e_ora = relerr(out, truth), relerr(ref, truth)
     print(f"fp32 vs fp64 truth, one UNet call L={L}: engine rel L2 {e_nat:.2e} max abs {float((out - truth).abs().max()):.2e}; "
           f"PyTorch-CPU fp32 oracle {e_ora:.2e} max abs {float((ref - truth).abs().max()):.2e}")
-    assert e_nat < 3 * e_ora and e_nat < 1e-5
+    assert e_nat < 2 * e_ora and e_nat < 2e-6                                       # measured 6.5e-7 vs 8.9e-7
     # free-running loop: the fp64 oracle as truth
     inv_n, inv_r, out_n, ref_l = _run_pair(oracle_unet, "ptp", L, 6, (0.2, 0.7))
     _, _, _, truth_l = _run_pair(u64, "ptp", L, 6, (0.2, 0.7), native=False, dtype=torch.float64)
     d_nat, d_ora = float((out_n[1] - truth_l[1]).abs().max()), float((ref_l[1] - truth_l[1]).abs().max())
     print(f"free-running etainv+ptp S=6 vs fp64 truth: edited latent max abs engine {d_nat:.2e} (rel L2 {relerr(out_n[1], truth_l[1]):.2e}, within tol "
           f"{within_tol(out_n[1], truth_l[1]):.5f}); fp32 oracle {d_ora:.2e} (rel L2 {relerr(ref_l[1], truth_l[1]):.2e}, within tol {within_tol(ref_l[1], truth_l[1]):.5f})")
-    assert relerr(out_n[1], truth_l[1]) < 3 * relerr(ref_l[1], truth_l[1]) + 1e-6
+    assert relerr(out_n[1], truth_l[1]) < 2 * relerr(ref_l[1], truth_l[1]) + 1e-6   # measured 4.9e-6 vs 7.3e-6
 
 
 def test_load_diffusion_model_fp32_variant():
