@@ -1068,18 +1068,24 @@ static double igemm_algo_bytes(const IGemmParams& p) {
                 (p.residual ? out_el : 0.0));
 }
 
-// Tile order across the 8 XCDs (each has its own 4 MiB L2; workgroup b runs on XCD b & 7).  With the 1-D order every XCD walks ALL N tiles of its
-// M range, so a weight matrix that does not fit its L2 is re-streamed from the fabric once per wave of concurrently running tiles: the PMC pass of
-// round 3 (profiles/r03_pmc_per_shape_rows128.json) shows 3.6 GB fetched for the 0.18 GB of operands of the C = 640 GEGLU projection, 5-10 GB for the
-// deep-K convs -- 3.5-4.3 TB/s at the fabric while the kernel runs.  A gm x gn XCD grid gives every XCD an N range (weights / gn: resident in L2, or
-// re-streamed gn times less often) at the price of reading every activation panel from gn XCDs.  Model per launch, bytes at the fabric:
-//   weights  W / gn per XCD; resident if <= 2.5 MB (read once), else once per wave of concurrently running tiles of that XCD
-//   activations  gn x A
-// gn = the minimiser over {1, 2, 4, 8} that divides the tile grid; ETAINV_XCD_GN=1 restores the 1-D order (A/B), =2/4/8 forces a value where it divides.
+// Tile order across the 8 XCDs (each has its own 4 MiB L2; workgroup b runs on XCD b & 7) -- an EXPERIMENT OF ROUND 3, OFF BY DEFAULT.  With the 1-D order
+// every XCD walks ALL N tiles of its M range, so a weight matrix that does not fit its L2 is re-streamed from the fabric once per round of concurrently
+// running tiles: the per-launch PMC pass (profiles/r03_pmc_per_shape_rows128.json) shows 3.6 GB fetched for the 0.18 GB of operands of the C = 640 GEGLU
+// projection and 5-10 GB for the deep-K convs (3.5-4.3 TB/s at the fabric while those kernels run; 2.1x the algorithmic bytes over a UNet call).  A
+// gm x gn XCD grid gives every XCD an N range (weights / gn: resident in L2, or re-streamed gn times less often) at the price of reading every
+// activation panel from gn XCDs.  Measured with the model below (ETAINV_XCD_GN=model, profiles/r03_pmc_per_shape_rows128_xcd.json, same box): the
+// GEGLU projections fetch 5x / 1.7x less (3.6 -> 0.7 GB at C = 640) and take the SAME time (1.06 vs 1.04 ms); the 3x3 convs fetch 2-3.6x MORE (their
+// activation panel is re-read per tap and no longer shared by the XCD's N tiles) at +1 % time; a 128-row UNet call 92.4 vs 91.4 ms of igemm, the
+// benchmark 4.117 vs 4.110 images/s.  Conclusion: the fabric traffic (served by the 256 MiB Infinity Cache) is not what bounds these kernels -- the
+// 1-D order stays the default.  ETAINV_XCD_GN=model|2|4|8 switches the 2-D order on for the ring kernels.
+//   model, bytes at the fabric per launch: weights W / gn per XCD, resident if <= 2.5 MB (read once), else once per round of that XCD's tiles;
+//   activations gn x taps x A (taps: a 3x3 conv streams its input once per tap); gn = the minimiser over {1, 2, 4, 8} that divides the tile grid
 static int pick_xcd_gn(const IGemmParams& p, int BM, int BN, int grid, int tiles) {
   if (p.ksplit > 1 || (tiles & 7) != 0 || (grid & 7) != 0) return 1;
   const int tiles_n = cdiv(p.N, BN), tiles_m = tiles / tiles_n;
-  static const int forced = getenv("ETAINV_XCD_GN") ? atoi(getenv("ETAINV_XCD_GN")) : 0;
+  static const char* env = getenv("ETAINV_XCD_GN");
+  if (!env) return 1;
+  static const int forced = atoi(env);   // 0 for "model"
   const double esz = 2.0, K = (double)p.taps * (p.c1 + p.c2);
   const double W = (double)p.N * K * esz;
   const double batch = (double)p.M / (double)p.rows_per_batch;
@@ -1097,7 +1103,7 @@ static int pick_xcd_gn(const IGemmParams& p, int BM, int BN, int grid, int tiles
     const double w_slice = W / gn;
     const double span = std::min(1.0, (double)(grid / 8) / (double)(tiles_n / gn));   // share of the XCD's N range one round of its CUs covers
     const double w_cost = w_slice <= 2.5e6 ? w_slice * 8.0 : w_slice * span * waves * 8.0;
-    const double cost = w_cost + gn * A;
+    const double cost = w_cost + gn * (double)p.taps * A;
     if (best_cost == 0.0 || cost < best_cost * 0.9) {   // (10 % hysteresis towards the smaller gn)
       best = gn;
       best_cost = cost;
