@@ -7,8 +7,9 @@ eta-scheduled backward edit with prompt-to-prompt attention control), batch-shar
 
 One "step" = the whole hot path over one batch of B synthetic image pairs per GPU: 50 forward UNet calls (B rows:
 the uncond half is skipped because guidance_scale_fwd == 1 multiplies it out) + 50 backward UNet calls (4B rows) +
-the fused eta / CFG / best-of-n step, word-map and LocalBlend kernels.  250 sample-forwards = 200.8 TFLOP per image
-(SURVEY.md 8d).  Inputs (latents, contexts, noise table, edit tables, synthetic SD1.x-shaped weights) are resident
+the fused eta / CFG / best-of-n step, word-map and LocalBlend kernels.  The 30 backward steps whose eta(t) is 0 skip the uncond source row
+(its noise prediction is dead work there: etainv/pipeline.py): 220 sample-forwards = 176.7 TFLOP per image executed (the reference's call pattern
+issues 300 = 241.0); `end_to_end_mfma_frac` is computed from the executed count.  Inputs (latents, contexts, noise table, edit tables, synthetic SD1.x-shaped weights) are resident
 in HBM before the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -336,11 +337,15 @@ def main():
     for _ in range(a.warmup):
         one_step()
     barrier()
+    rows0 = loop.rows_executed
     t0 = time.time()
     for _ in range(a.steps):
         out = one_step()
     barrier()
     dt = time.time() - t0
+    # UNet sample-forwards the timed steps actually issued per image: S cond rows forward + 4 per backward step, minus the uncond source row of the
+    # backward steps whose eta(t) is 0 (dead work: EtaLoop.skip_dead_source_rows) -- 220 instead of 250 with the paper's eta schedule
+    FWD_PER_IMAGE = (loop.rows_executed - rows0) / (B * a.steps)
     assert torch.isfinite(out).all(), "non-finite edited latents"
     if dist is not None:
         tmax = torch.tensor([dt], device=dev)
@@ -392,6 +397,7 @@ def main():
                                    f"{B} image pairs per GPU per step, eta {cfg['eta']}, n=10 noise candidates, cfg 7.5/1",
                        "baseline_config": a.config,
                        "images_per_gpu": B, "unet_sample_forwards_per_image": FWD_PER_IMAGE,
+                       "unet_sample_forwards_per_image_reference": 6 * S_STEPS,
                        "tflop_per_image": FWD_PER_IMAGE * F_UNET_TFLOP, "sharding": f"batch-shard x{world}, final all_gather of latents"},
             "end_to_end_mfma_frac": value / world * FWD_PER_IMAGE * F_UNET_TFLOP / MFMA_PEAK_TFLOPS,
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv3x3 / conv1x1 / linear)", "achieved": achieved,

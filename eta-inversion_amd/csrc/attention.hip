@@ -67,7 +67,7 @@ __device__ __forceinline__ void row_roles(int b, int n_img, int& half, int& role
 // of both halves take K,V of their source row)
 template <typename T, int D, int QT>
 __global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads,
-                                                        float scale_log2, int mode, int n_img, int stagger) {
+                                                        float scale_log2, int mode, int n_img, int stagger, int first_row) {
   typedef typename Frag<T>::v8 v8;
   typedef typename Frag<T>::v4 v4;
   constexpr int DP = (D + 31) / 32 * 32;
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qk
   int bq = b, bk = b, bv = b;
   if (mode != 0) {
     int half, role, img;
-    row_roles(b, n_img, half, role, img);
+    row_roles(b + first_row, n_img, half, role, img);   // (first_row: the call carries rows [first_row, 4 n_img) of the [u_s,u_t,c_s,c_t] layout)
     if (mode == 1 && half == 1 && role == 1) { bq = b - n_img; bk = b - n_img; }
     if (mode == 2 && role == 1) { bk = b - n_img; bv = b - n_img; }
   }
@@ -387,7 +387,7 @@ constexpr float A40_THR = 8.0f;
 
 template <typename T, int D, bool XCD_REMAP, int QB, int OCC>
 __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads,
-                                                               float q_scale, int mode, int n_img, int nqb, int stagger) {
+                                                               float q_scale, int mode, int n_img, int nqb, int stagger, int first_row) {
   typedef typename Frag<T>::v8 v8;
   typedef A32<D> GEO;
   constexpr int KV = GEO::KV, KS = GEO::KS, KROW = GEO::KROW, VROW = GEO::VROW, KBUF = GEO::KBUF, VBUF = GEO::VBUF, DT = GEO::DT, NCH = GEO::NCH,
@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
   int bq = b, bk = b, bv = b;
   if (mode != 0) {
     int half, role, img;
-    row_roles(b, n_img, half, role, img);
+    row_roles(b + first_row, n_img, half, role, img);   // (first_row: the call carries rows [first_row, 4 n_img) of the [u_s,u_t,c_s,c_t] layout)
     if (mode == 1 && half == 1 && role == 1) { bq = b - n_img; bk = b - n_img; }
     if (mode == 2 && role == 1) { bk = b - n_img; bv = b - n_img; }
   }
@@ -694,7 +694,7 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
   int img = 0, role = -1, is_cond = 0;
   if (p.layout == 2) {
     int half;
-    row_roles(b, p.n_img, half, role, img);
+    row_roles(b + p.first_row, p.n_img, half, role, img);
     is_cond = half;
   } else if (p.layout == 1) {
     img = b % p.n_img;
@@ -873,7 +873,7 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
 }
 
 template <typename T, int D>
-static int launch_self_t(const void* qkv, void* out, int b, int n, int heads, int mode, int n_img, hipStream_t s, int q_prescaled = 0) {
+static int launch_self_t(const void* qkv, void* out, int b, int n, int heads, int mode, int n_img, hipStream_t s, int q_prescaled = 0, int first_row = 0) {
   constexpr int QT = SELF_QT(D);
   constexpr int DP = (D + 31) / 32 * 32, DT = (D + 15) / 16;
   const size_t lds = (size_t)2 * (64 * (DP + 8) + DT * 16 * (64 + 8)) * sizeof(T);
@@ -887,7 +887,7 @@ static int launch_self_t(const void* qkv, void* out, int b, int n, int heads, in
   ProfScope prof(PROF_SELF_ATTN, 4.0 * (double)b * heads * (double)n * (double)n * D, s);
   static const int stagger = getenv("ETAINV_ATT_STAGGER") ? atoi(getenv("ETAINV_ATT_STAGGER")) : 0;
   hipLaunchKernelGGL((self_attn_kernel<T, D, QT>), dim3(cdiv(n, 64 * QT), heads, b), dim3(256), lds, s, (const T*)qkv, (T*)out, n,
-                     heads, scale_log2, mode, n_img, stagger);
+                     heads, scale_log2, mode, n_img, stagger, first_row);
   ETAINV_LAUNCH_CHECK();
   return 0;
 }
@@ -898,7 +898,7 @@ bool self_attn40_v2_enabled() {
 }
 
 template <typename T, int D, int QB, int OCC>
-static int launch_self40(const void* qkv, void* out, int b, int n, int heads, int mode, int n_img, int q_prescaled, hipStream_t s) {
+static int launch_self40(const void* qkv, void* out, int b, int n, int heads, int mode, int n_img, int q_prescaled, hipStream_t s, int first_row = 0) {
   const int nqb = cdiv(n, 128 * QB);
   const bool remap = ((b * heads) % 8) == 0;
   const float q_scale = q_prescaled ? 1.0f : (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
@@ -912,36 +912,37 @@ static int launch_self40(const void* qkv, void* out, int b, int n, int heads, in
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn40_kernel<T, D, false, QB, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   if (remap)
-    hipLaunchKernelGGL((self_attn40_kernel<T, D, true, QB, OCC>), dim3(nqb * heads * b), dim3(256), lds, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb, stagger);
+    hipLaunchKernelGGL((self_attn40_kernel<T, D, true, QB, OCC>), dim3(nqb * heads * b), dim3(256), lds, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb, stagger, first_row);
   else
-    hipLaunchKernelGGL((self_attn40_kernel<T, D, false, QB, OCC>), dim3(nqb, heads, b), dim3(256), lds, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb, stagger);
+    hipLaunchKernelGGL((self_attn40_kernel<T, D, false, QB, OCC>), dim3(nqb, heads, b), dim3(256), lds, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb, stagger, first_row);
   ETAINV_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int heads, int d, int mode, int n_img, int dtype,
-                               hipStream_t s, int q_prescaled) {
+                               hipStream_t s, int q_prescaled, int first_row) {
   ETAINV_CHECK(qkv && out && b > 0 && n > 0, "bad arguments");
-  ETAINV_CHECK(mode == 0 || (n_img > 0 && b == 4 * n_img), "ptp / masactrl modes need the 4*n_img backward layout");
+  ETAINV_CHECK(mode == 0 || (n_img > 0 && b + first_row == 4 * n_img && (first_row == 0 || (first_row == n_img && mode == 1))),
+               "ptp / masactrl modes need the 4*n_img backward layout (ptp: optionally without its first n_img rows)");
   if (dtype == ETAINV_F32) {
     ETAINV_CHECK(!q_prescaled, "fp32 path: the softmax scale is applied in the kernel");
-    return launch_self_attention_f32(qkv, out, b, n, heads, d, mode, n_img, s);
+    return launch_self_attention_f32(qkv, out, b, n, heads, d, mode, n_img, s, first_row);
   }
   ETAINV_CHECK(!q_prescaled || d == 40 || d == 80, "pre-scaled queries: head_dim 40 / 80 only");
   ETAINV_CHECK(!q_prescaled || self_attn40_v2_enabled(), "pre-scaled queries need the d = 40 kernel");
   if (d == 40 && self_attn40_v2_enabled()) {
     // two 32-query blocks per wave, 2 waves per SIMD (measured: one block per wave with 3 or 4 waves per SIMD is 10-13 % slower)
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 40, 2, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s)));
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 40, 2, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s, first_row)));
   }
   static const bool v2_80 = getenv("ETAINV_ATT80_OLD") == nullptr;   // A/B: head_dim 80 on the 32x32x16 kernel (one 32-query block per wave)
   if (d == 80 && self_attn40_v2_enabled() && v2_80) {
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 80, 1, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s)));
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 80, 1, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s, first_row)));
   }
   // (the generic kernel takes pre-scaled queries with scale 1: ETAINV_ATT80_OLD sends head_dim 80 here while the engine still folds the scale into to_q)
   ETAINV_DISPATCH_HALF(dtype, T, switch (d) {
-    case 40: return launch_self_t<T, 40>(qkv, out, b, n, heads, mode, n_img, s, q_prescaled);
-    case 80: return launch_self_t<T, 80>(qkv, out, b, n, heads, mode, n_img, s, q_prescaled);
-    case 160: return launch_self_t<T, 160>(qkv, out, b, n, heads, mode, n_img, s, q_prescaled);
+    case 40: return launch_self_t<T, 40>(qkv, out, b, n, heads, mode, n_img, s, q_prescaled, first_row);
+    case 80: return launch_self_t<T, 80>(qkv, out, b, n, heads, mode, n_img, s, q_prescaled, first_row);
+    case 160: return launch_self_t<T, 160>(qkv, out, b, n, heads, mode, n_img, s, q_prescaled, first_row);
     default: ETAINV_FAIL("head_dim must be 40, 80 or 160");
   });
   return 0;
@@ -970,8 +971,9 @@ static int launch_cross_t(const void* q, const void* kv, void* out, int b, const
       hipLaunchKernelGGL((cross_attn_kernel<T, D, QT, false>), dim3(gx, p.heads, rows), dim3(256), lds_plain, s, (const T*)q, (const T*)kv, (T*)out, p, row0);
   };
   if (p.edit && p.layout == 2) {          // rows [u_s, u_t, c_s, c_t] x n_img: only the last quarter (cond target) is edited
-    launch(false, 0, 3 * p.n_img);
-    launch(true, 3 * p.n_img, b - 3 * p.n_img);
+    const int edit0 = 3 * p.n_img - p.first_row;   // first cond-target row of this call
+    launch(false, 0, edit0);
+    launch(true, edit0, b - edit0);
   } else {
     launch(false, 0, b);
   }

@@ -456,13 +456,13 @@ struct Fwd {
   }
   // Context-independent prefix (see unet_body): a tensor computed for the first `half` batch rows is copied to rows half .. 2 half - 1, together
   // with the GroupNorm partials its producer left (row blocks are batch-row major: the first half is a prefix of the buffer)
-  int dup_rows(void* buf, int half, size_t elems_per_row) {
-    const size_t bytes = (size_t)half * elems_per_row * e->esz;
-    ETAINV_HIP(hipMemcpyAsync(reinterpret_cast<char*>(buf) + bytes, buf, bytes, hipMemcpyDeviceToDevice, s));
+  int dup_rows(void* buf, int have, int n, size_t elems_per_row) {   // rows [0, n) -> rows [have, have + n)
+    const size_t off = (size_t)have * elems_per_row * e->esz, bytes = (size_t)n * elems_per_row * e->esz;
+    ETAINV_HIP(hipMemcpyAsync(reinterpret_cast<char*>(buf) + off, buf, bytes, hipMemcpyDeviceToDevice, s));
     const int idx = part_of(buf);
     if (idx >= 0 && part_wm[idx] > 0) {
-      const size_t pbytes = elems_per_row * half / part_wm[idx] * 2 * sizeof(float);   // [rows * hw / wm][2][C]: elems_per_row = hw * C
-      ETAINV_HIP(hipMemcpyAsync(reinterpret_cast<char*>(e->gn_part[idx]) + pbytes, e->gn_part[idx], pbytes, hipMemcpyDeviceToDevice, s));
+      const size_t per_row = elems_per_row / part_wm[idx] * 2 * sizeof(float);   // [rows * hw / wm][2][C]: elems_per_row = hw * C
+      ETAINV_HIP(hipMemcpyAsync(reinterpret_cast<char*>(e->gn_part[idx]) + per_row * have, e->gn_part[idx], per_row * n, hipMemcpyDeviceToDevice, s));
     }
     return 0;
   }
@@ -563,7 +563,7 @@ struct Fwd {
       if (ctrl->mode == ETAINV_ATTN_MASA && ctrl->masa_active && blk >= ctrl->masa_first_block) mode = 2;
     }
     const int all_rows = rows;
-    if (self_rows <= 0 || self_rows >= all_rows || mode != 0 || e->gn_fold) self_rows = all_rows;   // (a row remap couples the halves: no sharing)
+    if (self_rows <= 0 || self_rows >= all_rows || 2 * self_rows < all_rows || mode != 0 || e->gn_fold) self_rows = all_rows;   // (a row remap couples the halves: no sharing)
     rows = self_rows;
     int M = rows * hw;
     // The GroupNorm in front of proj_in has no activation: with its statistics known from the producer's epilogue it becomes a per-image scaling
@@ -591,12 +591,12 @@ struct Fwd {
       if (launch_layernorm(e->hsA, t.ln1.g, t.ln1.b, e->lnbuf, M, c, 1e-5f, e->dt, s)) return 1;
       if (gemm(e->lnbuf, t.qkv, e->qkvbuf, M)) return 1;
     }
-    if (launch_self_attention_mode(e->qkvbuf, e->attnbuf, rows, hw, etainv_engine::kHeads, d, mode, n_img, e->dt, s, /*q_prescaled=*/d <= 80 && self_attn40_v2_enabled() && e->dt != ETAINV_F32)) return 1;
+    if (launch_self_attention_mode(e->qkvbuf, e->attnbuf, rows, hw, etainv_engine::kHeads, d, mode, n_img, e->dt, s, /*q_prescaled=*/d <= 80 && self_attn40_v2_enabled() && e->dt != ETAINV_F32, ctrl ? ctrl->first_row : 0)) return 1;
     if (gemm(e->attnbuf, t.out1, e->hsB, M, e->hsA, 0, nullptr, 0, 0, fold)) return 1;
     if (self_rows != all_rows) {   // the other half of the batch enters the cross-attention with the same residual stream (and LayerNorm statistics)
-      const size_t bytes = (size_t)M * c * e->esz;
-      ETAINV_HIP(hipMemcpyAsync(reinterpret_cast<char*>(e->hsB) + bytes, e->hsB, bytes, hipMemcpyDeviceToDevice, s));
-      if (fold) ETAINV_HIP(hipMemcpyAsync(e->lnfinal + (size_t)M * 2, e->lnfinal, (size_t)M * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+      const size_t off = (size_t)M * c * e->esz, Mn = (size_t)(all_rows - self_rows) * hw;   // rows [0, all - self) -> rows [self, all)
+      ETAINV_HIP(hipMemcpyAsync(reinterpret_cast<char*>(e->hsB) + off, e->hsB, Mn * c * e->esz, hipMemcpyDeviceToDevice, s));
+      if (fold) ETAINV_HIP(hipMemcpyAsync(e->lnfinal + (size_t)M * 2, e->lnfinal, Mn * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
       rows = all_rows;
       M = rows * hw;
     }
@@ -621,6 +621,7 @@ struct Fwd {
     if (ctrl && (ctrl->mode == ETAINV_ATTN_PTP || ctrl->mode == ETAINV_ATTN_STORE)) {
       cp.n_img = ctrl->n_img;
       cp.layout = ctrl->mode == ETAINV_ATTN_PTP ? 2 : 1;
+      cp.first_row = ctrl->mode == ETAINV_ATTN_PTP ? ctrl->first_row : 0;
       if (ctrl->mode == ETAINV_ATTN_PTP && ctrl->cross_alpha && (ctrl->mapper || ctrl->replace_mat)) {
         cp.edit = 1;
         cp.mapper = ctrl->mapper;
@@ -793,8 +794,9 @@ static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const in
   ETAINV_CHECK(etainv_engine_weights_ready(e), "weights not fully set");
   if (ctrl) {
     ETAINV_CHECK(ctrl->n_img >= 1 && ctrl->n_img <= e->max_img, "ctrl.n_img exceeds max_img");
+    ETAINV_CHECK(ctrl->first_row == 0 || (ctrl->mode == ETAINV_ATTN_PTP && ctrl->first_row == ctrl->n_img), "first_row: 0, or n_img with prompt-to-prompt");
     if (ctrl->mode == ETAINV_ATTN_PTP || ctrl->mode == ETAINV_ATTN_MASA)
-      ETAINV_CHECK(n_rows == 4 * ctrl->n_img, "ptp / masactrl need 4*n_img UNet rows [u_s,u_t,c_s,c_t]");
+      ETAINV_CHECK(n_rows == 4 * ctrl->n_img - ctrl->first_row, "ptp / masactrl need 4*n_img UNet rows [u_s,u_t,c_s,c_t] (ptp with first_row = n_img: 3*n_img rows [u_t,c_s,c_t])");
     if (ctrl->mode == ETAINV_ATTN_STORE)
       ETAINV_CHECK(n_rows == 2 * ctrl->n_img || n_rows == ctrl->n_img, "store mode needs n_img or 2*n_img rows");
   }
@@ -836,8 +838,11 @@ static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const in
   // transformer block's GroupNorm / proj_in / QKV / self-attention (N = L^2: the most expensive launch of the call) / to_out -- so those run on
   // n_lat rows and their results are copied to the other half (3 device copies, ~0.3 ms, for 2.6 % of a 128-row call).  The reference evaluates
   // both halves (eta_inversion.py:320-321 `torch.cat([latent] * 2)`); the values are the same.  ETAINV_NO_PREFIX_SHARE=1: A/B switch.
-  bool share = getenv("ETAINV_NO_PREFIX_SHARE") == nullptr && n_rows == 2 * n_lat && !e->gn_fold;
-  for (int r = 0; share && r < n_lat; ++r) share = t_host[r] == t_host[r + n_lat];
+  // (general form: n_lat < n_rows <= 2 n_lat -- rows r >= n_lat repeat latent r - n_lat; the 3 n_img-row backward calls of eta == 0 steps carry
+  // latents [tgt, src] and rows [u_t, c_s, c_t]: the last n_img rows repeat the first n_img)
+  bool share = getenv("ETAINV_NO_PREFIX_SHARE") == nullptr && n_rows > n_lat && n_rows <= 2 * n_lat && !e->gn_fold;
+  for (int r = n_lat; share && r < n_rows; ++r) share = t_host[r] == t_host[r - n_lat];
+  const int dup_n = n_rows - n_lat;   // rows copied from the head of every shared tensor to its tail
   const int pre_rows = share ? n_lat : n_rows;
   f.rows = pre_rows;
   if (launch_im2col_in(latent, io_dtype, n_lat, pre_rows, L, e->gnbuf, e->dt, s)) return 1;
@@ -860,7 +865,7 @@ static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const in
         if (f.resblock(e->res[ri++], h, nullptr, hc, 0, side, r_out)) return 1;
         const bool first = i == 0 && j == 0;
         if (first && share) {   // skip[0] (a skip connection of the up path) and the block input (proj_out's residual) are needed for all rows
-          if (f.dup_rows(e->skip[0], pre_rows, (size_t)L * L * etainv_engine::kCh0) || f.dup_rows(r_out, pre_rows, (size_t)L * L * ch[0])) return 1;
+          if (f.dup_rows(e->skip[0], pre_rows, dup_n, (size_t)L * L * etainv_engine::kCh0) || f.dup_rows(r_out, pre_rows, dup_n, (size_t)L * L * ch[0])) return 1;
         }
         f.rows = n_rows;
         if (f.transformer(e->tb[ti++], r_out, side, e->skip[si], first && share ? pre_rows : 0)) return 1;
@@ -1215,6 +1220,7 @@ extern "C" int etainv_op_cross_attention(const void* q, const void* kv, void* ou
   if (ctrl && (ctrl->mode == ETAINV_ATTN_PTP || ctrl->mode == ETAINV_ATTN_STORE)) {
     cp.n_img = ctrl->n_img;
     cp.layout = ctrl->mode == ETAINV_ATTN_PTP ? 2 : 1;
+    cp.first_row = ctrl->mode == ETAINV_ATTN_PTP ? ctrl->first_row : 0;
     if (ctrl->mode == ETAINV_ATTN_PTP && ctrl->cross_alpha && (ctrl->mapper || ctrl->replace_mat)) {
       cp.edit = 1;
       cp.mapper = ctrl->mapper;

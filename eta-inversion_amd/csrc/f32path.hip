@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) layernorm_f32_kernel(const float* __restr
 // mode 1 / 2: the prompt-to-prompt / MasaCtrl batch-row remaps of attention.hip (row_roles).
 template <int D>
 __global__ void __launch_bounds__(256) self_attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int heads, float scale_log2,
-                                                            int mode, int n_img) {
+                                                            int mode, int n_img, int first_row) {
   constexpr int NT = (D + 31) / 32, KSTR = D + 4, VSTR = NT * 32 + 8, KB = 64;
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   float* sK = smem_f;                 // [KB][KSTR]
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256) self_attn_f32_kernel(const float* __restr
   const int b = blockIdx.z, hd = blockIdx.y, C = heads * D, C3 = 3 * C;
   int bq = b, bk = b, bv = b;
   if (mode != 0) {
-    const int half = b / (2 * n_img), role = (b / n_img) & 1;
+    const int bl = b + first_row, half = bl / (2 * n_img), role = (bl / n_img) & 1;
     if (mode == 1 && half == 1 && role == 1) { bq = b - n_img; bk = b - n_img; }
     if (mode == 2 && role == 1) { bk = b - n_img; bv = b - n_img; }
   }
@@ -386,9 +386,10 @@ __global__ void __launch_bounds__(256) cross_attn_f32_kernel(const float* __rest
   const int b = blockIdx.z, h = blockIdx.y, N = p.N, C = p.heads * D, C2 = 2 * C;
   int img = 0, role = -1, is_cond = 0;
   if (p.layout == 2) {
-    is_cond = b / (2 * p.n_img);
-    role = (b / p.n_img) & 1;
-    img = b % p.n_img;
+    const int bl = b + p.first_row;
+    is_cond = bl / (2 * p.n_img);
+    role = (bl / p.n_img) & 1;
+    img = bl % p.n_img;
   } else if (p.layout == 1) {
     img = b % p.n_img;
     is_cond = (p.rows == p.n_img) ? 1 : (b / p.n_img);
@@ -524,7 +525,7 @@ int launch_layernorm_f32(const void* x, const float* gamma, const float* beta, v
 }
 
 template <int D>
-static int launch_self_f32_t(const void* qkv, void* out, int b, int n, int heads, int mode, int n_img, hipStream_t s) {
+static int launch_self_f32_t(const void* qkv, void* out, int b, int n, int heads, int mode, int n_img, hipStream_t s, int first_row) {
   constexpr int NT = (D + 31) / 32;
   const size_t lds = (size_t)64 * ((D + 4) + (NT * 32 + 8)) * sizeof(float);
   static bool attr[kMaxDevices] = {};
@@ -535,16 +536,16 @@ static int launch_self_f32_t(const void* qkv, void* out, int b, int n, int heads
   }
   ProfScope prof(PROF_SELF_ATTN, 4.0 * (double)b * heads * (double)n * (double)n * D, s);
   hipLaunchKernelGGL(self_attn_f32_kernel<D>, dim3(cdiv(n, 128), heads, b), dim3(256), lds, s, (const float*)qkv, (float*)out, n, heads,
-                     (1.0f / sqrtf((float)D)) * 1.4426950408889634f, mode, n_img);
+                     (1.0f / sqrtf((float)D)) * 1.4426950408889634f, mode, n_img, first_row);
   ETAINV_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_self_attention_f32(const void* qkv, void* out, int b, int n, int heads, int d, int mode, int n_img, hipStream_t s) {
+int launch_self_attention_f32(const void* qkv, void* out, int b, int n, int heads, int d, int mode, int n_img, hipStream_t s, int first_row) {
   switch (d) {
-    case 40: return launch_self_f32_t<40>(qkv, out, b, n, heads, mode, n_img, s);
-    case 80: return launch_self_f32_t<80>(qkv, out, b, n, heads, mode, n_img, s);
-    case 160: return launch_self_f32_t<160>(qkv, out, b, n, heads, mode, n_img, s);
+    case 40: return launch_self_f32_t<40>(qkv, out, b, n, heads, mode, n_img, s, first_row);
+    case 80: return launch_self_f32_t<80>(qkv, out, b, n, heads, mode, n_img, s, first_row);
+    case 160: return launch_self_f32_t<160>(qkv, out, b, n, heads, mode, n_img, s, first_row);
     default: ETAINV_FAIL("head_dim must be 40, 80 or 160");
   }
 }

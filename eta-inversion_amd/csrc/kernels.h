@@ -60,7 +60,7 @@ int launch_igemm_f32(const IGemmParams& p, hipStream_t s);
 int launch_groupnorm_f32(const void* x1, const void* x2, int c1, int c2, const float* gamma, const float* beta, void* out, int b, int hw, int groups,
                          float eps, int silu, float* scratch, hipStream_t s);
 int launch_layernorm_f32(const void* x, const float* gamma, const float* beta, void* out, int rows, int c, float eps, hipStream_t s);
-int launch_self_attention_f32(const void* qkv, void* out, int b, int n, int heads, int d, int mode, int n_img, hipStream_t s);
+int launch_self_attention_f32(const void* qkv, void* out, int b, int n, int heads, int d, int mode, int n_img, hipStream_t s, int first_row = 0);
 struct CrossParams;
 int launch_cross_attention_f32(const void* q, const void* kv, void* out, int b, int d, const CrossParams& p, hipStream_t s);
 
@@ -95,14 +95,17 @@ int launch_ln_finalize(const float* partials, int P, int cw, float eps, float* s
 // A/B switch ETAINV_ATT_OLD: head_dim 40 on the generic 16x16x32 kernel (then the engine does not fold the scale into to_q)
 bool self_attn40_v2_enabled();
 // q_prescaled (d == 40 only): the queries already carry softmax scale * log2(e) (the engine folds it into the to_q weights)
+// first_row: the call carries rows [first_row, 4 n_img) of the [u_s, u_t, c_s, c_t] x n_img layout (0, or n_img when the uncond source rows are left out:
+// backward steps with eta == 0, etainv/pipeline.py)
 int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int heads, int d, int mode, int n_img, int dtype,
-                               hipStream_t s, int q_prescaled = 0);
+                               hipStream_t s, int q_prescaled = 0, int first_row = 0);
 struct CrossParams {
   int N = 0, heads = 8, n_ctx = 77;
   float scale_log2 = 0.f;
   int layout = 0;      // 0: no roles (plain); 1: forward store layout [u x B, c x B] or [c x B]; 2: backward 4B layout
   int n_img = 1;
   int rows = 0;        // batch rows in this call
+  int first_row = 0;   // layout 2: the call carries rows [first_row, 4 n_img) of [u_s, u_t, c_s, c_t] x n_img (0 or n_img)
   int edit = 0;        // ptp cross edit on cond target rows
   int map_layer = -1;  // >= 0: accumulate cond-half probabilities into maps_acc layer `map_layer`
   int n_img_cap = 1;

@@ -10,6 +10,7 @@ Replaces, for B independent (source, target) pairs at once (the reference handle
   DiffusionInversion.sample batch layout                        reference modules/inversion/diffusion_inversion.py:462-528
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -44,7 +45,7 @@ def eta_table(eta=(0.0, 0.4)) -> np.ndarray:
 class EtaLoop:
     def __init__(self, engine, S=50, guidance_scale_bwd=7.5, guidance_scale_fwd=1.0, eta=(0.0, 0.4), noise_sample_count=10,
                  use_mask=True, mask_thres=0.2, skip_uncond_fwd=True, steps_offset=0, mask_eta="fwd_mean", mask_pow=None, target_dirinv=None,
-                 mask_dirinv=None):
+                 mask_dirinv=None, skip_dead_source_rows=True):
         self.e, self.S, self.L = engine, S, engine.L
         # guidance_scale_fwd may be a (start, end) pair: linspace over the 1000 training timesteps, indexed by t (eta_inversion.py:108-110,325-326)
         self.g_fwd_table = np.linspace(guidance_scale_fwd[0], guidance_scale_fwd[1], NUM_TRAIN) if isinstance(guidance_scale_fwd, (tuple, list)) else None
@@ -64,6 +65,15 @@ class EtaLoop:
         assert target_dirinv is None or use_mask, "target_dirinv is part of the masked update"
         # u + 1*(c - u) == c up to rounding: the uncond half of the forward pass is dead work when g_fwd == 1
         self.skip_uncond_fwd = skip_uncond_fwd and self.g_fwd == 1.0 and self.g_fwd_table is None
+        # Backward steps with eta(t) == 0 (the whole ramp-free part of the paper's schedule: 30 of 50 steps with eta [[0.6, 0], [1, 0.7]]): the source
+        # row is REPLAYED from the inversion trajectory (eta_inversion.py:247-249) and its guided noise feeds nothing but the best-of-n choice of a
+        # noise sample that is then multiplied by eta sigma = 0 (:232, :330-375) -- eps(uncond source) is dead work.  Those steps run 3 B UNet rows
+        # [u_t, c_s, c_t] with prompt-to-prompt (the cond source row stays: its attention probabilities are what is injected into the target) and
+        # 2 B rows [u_t, c_t] without an attention coupling (simple editor); MasaCtrl couples u_t to u_s and keeps all four.  The source row then is
+        # x_prev_src itself instead of x + (x_prev_src - x): at most one rounding apart (SURVEY E-11).  Like skip_uncond_fwd an exact identity of the
+        # reference's arithmetic, not an approximation; skip_dead_source_rows=False runs the reference's row count.
+        self.skip_dead_source_rows = skip_dead_source_rows and target_dirinv is None and not os.environ.get("ETAINV_NO_DEAD_ROW_SKIP")   # (env: A/B switch)
+        self.rows_executed = 0                                   # UNet sample-forwards issued by invert / sample since construction (bench accounting)
         self.lib = engine.lib
 
     def _alpha(self, tau):
@@ -103,6 +113,7 @@ class EtaLoop:
             for j, t in enumerate(self.t_fwd):
                 x_in = lat[j] if teacher is None else teacher[j].contiguous()
                 e.unet(x_in, int(t), ctx, ctrl, out=eps_all)
+                self.rows_executed += rows
                 if not self.skip_uncond_fwd:
                     g = float(self.g_fwd_table[int(t)]) if self.g_fwd_table is not None else self.g_fwd
                     _capi.check(self.lib.etainv_cfg_combine(_capi.ptr(eps_all[:B]), _capi.ptr(eps_all[B:]), g, _capi.ptr(eps), n,
@@ -172,6 +183,8 @@ class EtaLoop:
                 return m.reshape(B, L, L)
         if ptp is not None:
             e.maps_reset()
+        ctx3 = eps3 = None
+        eps_t = torch.empty(B, 4, L, L, dtype=torch.float32, device=dev)
         st = _capi.stream_ptr()
         with e.cached_context():                               # one unchanged context tensor for all S calls
             for i, t in enumerate(self.t_bwd):
@@ -185,10 +198,39 @@ class EtaLoop:
                     ctrl = AttnControl(mode=_capi.ATTN_MASA, n_img=B, masa_active=masactrl[0] <= i < 50, masa_first_block=masactrl[1])
                 if teacher is not None:
                     x.copy_(teacher[i])
-                e.unet(x, t, ctx, ctrl, out=eps_all)
                 p = t - self.delta
                 a_t, a_p = float(self.ac[t]), (float(self.ac[p]) if p >= 0 else float(self.ac[0]))
                 var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
+                if self.skip_dead_source_rows and float(self.etas[t]) == 0.0 and masactrl is None:
+                    # eta == 0: no eps(uncond source) -- rows [u_t, c_s, c_t] over latents [tgt, src] (ptp) or [u_t, c_t] over [tgt] (no coupling)
+                    if ptp is not None:
+                        if ctx3 is None:
+                            ctx3 = torch.cat([ctx_tgt[:, 0], ctx_src[:, 1], ctx_tgt[:, 1]]).contiguous().float()
+                            eps3 = torch.empty(3 * B, 4, L, L, dtype=torch.float32, device=dev)
+                        ctrl.c.first_row = B
+                        e.unet(torch.cat([x[B:], x[:B]]), t, ctx3, ctrl, out=eps3)
+                        eu, ec = eps3[:B], eps3[2 * B:]
+                    else:
+                        if ctx3 is None:
+                            ctx3 = torch.cat([ctx_tgt[:, 0], ctx_tgt[:, 1]]).contiguous().float()
+                            eps3 = torch.empty(2 * B, 4, L, L, dtype=torch.float32, device=dev)
+                        e.unet(x[B:], t, ctx3, None, out=eps3)
+                        eu, ec = eps3[:B], eps3[B:]
+                    self.rows_executed += ctx3.shape[0]
+                    n_t = B * 4 * L * L
+                    _capi.check(self.lib.etainv_cfg_combine(_capi.ptr(eu), _capi.ptr(ec), self.g_bwd, _capi.ptr(eps_t), n_t, _capi.F32, st))
+                    _capi.check(self.lib.etainv_ddim_eta_step(_capi.ptr(x[B:]), _capi.ptr(eps_t), 0.0, None, 0, None, a_t, a_p, var, B, 4, L * L,
+                                                              _capi.ptr(x_new[B:]), _capi.F32, st))
+                    x_new[:B].copy_(lat_inv[S - 1 - i])                                 # the replayed source row
+                    best.zero_()                                                        # (the reference's argmin over NaN losses: index 0)
+                    x, x_new = x_new, x
+                    if ptp is not None and ptp.blend_alpha is not None and (i + 1) > int(0.2 * S):
+                        e.local_blend(x, B, ptp.blend_alpha, 0.3)
+                    if trace is not None:
+                        trace.append({"t": t, "latent": x.clone(), "best": best.clone(), "eps_all": None, "rows": int(ctx3.shape[0])})
+                    continue
+                e.unet(x, t, ctx, ctrl, out=eps_all)
+                self.rows_executed += 4 * B
                 dmap = None
                 if self.use_mask:
                     raw = src_map(self.mask_eta, i)

@@ -140,7 +140,12 @@ typedef struct etainv_attn_ctrl {
   /* MASA: mutual self-attention active for transformer blocks >= masa_first_block (cur_att_layer // 2) */
   int masa_active;
   int masa_first_block;
-  int reserved[4];
+  /* PTP only: the call carries rows [first_row, 4 n_img) of the [u_s, u_t, c_s, c_t] x n_img layout -- 0 (all rows) or n_img (no uncond source rows:
+   * n_rows == 3 n_img, rows [u_t, c_s, c_t]).  A backward step whose eta(t) is 0 does not need eps(uncond source): the source row is replayed from the
+   * inversion trajectory (modules/inversion/eta_inversion.py:247-249) and its guided noise only feeds the best-of-n choice of a noise that is then
+   * multiplied by eta = 0 (:232, :330-375); the cond source row stays (its attention probabilities are what prompt-to-prompt injects). */
+  int first_row;
+  int reserved[3];
 } etainv_attn_ctrl;
 
 /* eps = UNet(latent, t, ctx).  Replaces `self.unet(latent_input, t, encoder_hidden_states=context)["sample"]`

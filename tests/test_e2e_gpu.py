@@ -259,3 +259,43 @@ def test_forward_guidance_table_vs_oracle(setup):
     inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
     print(f"inversion trajectory {relerr(inv['latents'].cpu(), ref):.2e}")
     assert relerr(inv["latents"].cpu(), ref) < 2.3e-3                                             # measured 1.13e-3 (round 3); bound at 2x
+
+
+@pytest.mark.parametrize("editor", ["ptp", "simple"])
+def test_dead_source_rows_are_skipped_not_changed(setup, editor):
+    """EtaLoop.skip_dead_source_rows: backward steps with eta(t) == 0 run without eps(uncond source) (3 B rows with prompt-to-prompt, 2 B without an
+    attention coupling).  Same edited latent as the reference's row count (the source row differs by at most one rounding: x_prev instead of
+    x + (x_prev - x)), fewer UNet rows issued."""
+    from oracle import ptp as optp
+    from etainv.pipeline import EtaLoop, PtpTables, noise_table
+    unet, get_engine = setup
+    L, S_, eta = 16, 8, [[0.6, 0], [1, 0.7]]                                   # eta == 0 for t <= 580: 5 of the 8 backward steps
+    eng = get_engine(L, torch.float16)
+    pairs, z0, ctx_src, ctx_tgt = _inputs(L)
+    tok = optp.WordTokenizer()
+    W = max(len(s.split(" ")) for s, _ in pairs)
+    tokens = torch.ones(B, W, dtype=torch.int32)
+    mp, al, eq, ba, ca = [], [], [], [], []
+    for i, (src, tgt) in enumerate(pairs):
+        ws = src.split(" ")
+        tokens[i, :len(ws)] = torch.tensor([ws.index(w) + 1 for w in ws], dtype=torch.int32)
+        bw, tw = ws[1], tgt.split(" ")[1]
+        m, a = optp.refinement_mapper(src, tgt, tok)
+        mp.append(m); al.append(a)
+        eq.append(optp.equalizer(tgt, (tw,), (2,), tok))
+        ba.append(optp.blend_alpha_layers([src, tgt], ((bw,), (tw,)), tok))
+        ca.append(optp.time_words_alpha([src, tgt], S_, {"default_": .4}, tok)[:, 0])
+    ptp = PtpTables(np.stack(mp), np.stack(al), np.stack(ca, 1), 0.6, S_, equalizer=np.stack(eq), blend_alpha=np.stack(ba)) if editor == "ptp" else None
+    nz = noise_table(S_, 10, L, seed=0)
+    outs, rows = [], []
+    for skip in (True, False):
+        loop = EtaLoop(eng, S=S_, eta=eta, skip_dead_source_rows=skip)
+        inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
+        r0 = loop.rows_executed
+        outs.append(loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), nz, edit_word=torch.tensor([1, 1]), ptp=ptp).clone())
+        rows.append(loop.rows_executed - r0)
+    n_dead = int(sum(1 for t in loop.t_bwd if loop.etas[int(t)] == 0.0))
+    assert n_dead == 5 and rows[1] == 4 * B * S_ and rows[0] == rows[1] - n_dead * B * (1 if editor == "ptp" else 2)
+    e_src, e_tgt = relerr(outs[0][:B], outs[1][:B]), relerr(outs[0][B:], outs[1][B:])
+    print(f"{editor}: dead-row skipping vs the full row count: source row {e_src:.2e}, edited latent {e_tgt:.2e}; UNet rows {rows[0]} vs {rows[1]}")
+    assert e_src < 1e-6 and e_tgt < 2e-3                                       # (fp16: tile / split-K choices follow the row count)

@@ -203,3 +203,43 @@ def test_context_independent_prefix_is_shared_not_changed(engines, dtype, mode):
         a = e.unet(x, t, ctx)
         b = torch.cat([e.unet(x, 481, ctx[:2 * n_img].contiguous()), e.unet(x, 301, ctx[2 * n_img:].contiguous())])
         assert relerr(a, b) < (1e-5 if dtype == torch.float32 else 2e-3 if dtype == torch.float16 else 1.5e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_three_row_layout_equals_the_four_row_call(engines, dtype):
+    """etainv_attn_ctrl.first_row = n_img: a prompt-to-prompt call WITHOUT its uncond source rows (rows [u_t, c_s, c_t] over latents [tgt, src]; the
+    backward steps with eta == 0, etainv/pipeline.py) gives the same u_t / c_s / c_t outputs as the full [u_s, u_t, c_s, c_t] call -- with the cross
+    edit, the self-replace remap and the map store active -- and the same stored maps."""
+    from etainv import _capi
+    from etainv.engine import AttnControl
+    e = engines(dtype, 16)
+    n = 2
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(2 * n, 4, 16, 16, generator=g).cuda()                       # [src.., tgt..]
+    ctx = torch.randn(4 * n, 77, 768, generator=g).cuda()                       # [u_s, u_t, c_s, c_t]
+    mapper = torch.arange(77, dtype=torch.int32).repeat(n, 1)
+    mapper[:, 2] = -1
+    al = torch.ones(n, 77)
+    al[:, 2] = 0
+    eq = torch.ones(n, 77)
+    eq[:, 2] = 2.0
+    mapper, al, eq, ca = mapper.cuda(), al.cuda(), eq.cuda(), torch.ones(n, 77).cuda()
+    tokens = torch.arange(1, 5, dtype=torch.int32).repeat(n, 1).cuda()
+    mk = lambda first: AttnControl(mode=_capi.ATTN_PTP, n_img=n, store_maps=True, mapper=mapper, alphas=al, equalizer=eq, cross_alpha=ca,
+                                   self_replace_active=True, self_max_tokens=64, first_row=first)
+    os_env = __import__("os").environ
+    os_env["ETAINV_NO_SPLITK"] = "1"                                             # (split-K part counts follow the row count: pinned for bit equality)
+    try:
+        e.maps_reset()
+        full = e.unet(x, 481, ctx, mk(0)).clone()
+        maps_full = e.word_maps(n, tokens, 1, torch.empty(n, 4, 16, 16, device="cuda")).clone()
+        e.maps_reset()
+        three = e.unet(torch.cat([x[n:], x[:n]]), 481, ctx[n:].contiguous(), mk(n)).clone()
+        maps_three = e.word_maps(n, tokens, 1, torch.empty(n, 4, 16, 16, device="cuda")).clone()
+    finally:
+        del os_env["ETAINV_NO_SPLITK"]
+    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    assert relerr(three, full[n:]) < tol and relerr(maps_three, maps_full) < tol
+    assert torch.equal(three[n:], full[2 * n:])                                  # the cond rows do not depend on which uncond rows ride along
+    with pytest.raises(_capi.EtainvError):                                       # MasaCtrl couples u_t to u_s: no three-row form
+        e.unet(torch.cat([x[n:], x[:n]]), 481, ctx[n:].contiguous(), AttnControl(mode=_capi.ATTN_MASA, n_img=n, masa_active=True, first_row=n))
