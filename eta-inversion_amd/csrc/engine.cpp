@@ -790,7 +790,7 @@ static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const in
                      const etainv_attn_ctrl* ctrl, void* out, int io_dtype, void* stream) {
   ETAINV_CHECK(e && latent && t_host && ctx && out, "null argument");
   ETAINV_CHECK(n_rows >= 1 && n_rows <= e->maxB, "n_rows exceeds max_unet_batch");
-  ETAINV_CHECK(n_lat >= 1 && n_rows % n_lat == 0, "n_rows must be a multiple of n_lat");
+  ETAINV_CHECK(n_lat >= 1 && n_lat <= n_rows, "1 <= n_lat <= n_rows (UNet row r reads latent r % n_lat)");
   ETAINV_CHECK(etainv_engine_weights_ready(e), "weights not fully set");
   if (ctrl) {
     ETAINV_CHECK(ctrl->n_img >= 1 && ctrl->n_img <= e->max_img, "ctrl.n_img exceeds max_img");

@@ -150,7 +150,7 @@ typedef struct etainv_attn_ctrl {
 
 /* eps = UNet(latent, t, ctx).  Replaces `self.unet(latent_input, t, encoder_hidden_states=context)["sample"]`
  * (modules/inversion/eta_inversion.py:321).
- * latent  [n_lat][4][L][L]  io_dtype; UNet row r reads latent row r % n_lat (torch.cat([latent]*2), :320)
+ * latent  [n_lat][4][L][L]  io_dtype, 1 <= n_lat <= n_rows; UNet row r reads latent row r % n_lat (torch.cat([latent]*2), :320)
  * t_host  [n_rows] int64 HOST timesteps (one per UNet row)
  * ctx     [n_rows][77][768] io_dtype
  * out     [n_rows][4][L][L] io_dtype */
