@@ -240,6 +240,7 @@ def test_three_row_layout_equals_the_four_row_call(engines, dtype):
         del os_env["ETAINV_NO_SPLITK"]
     tol = 1e-5 if dtype == torch.float32 else 2e-3
     assert relerr(three, full[n:]) < tol and relerr(maps_three, maps_full) < tol
-    assert torch.equal(three[n:], full[2 * n:])                                  # the cond rows do not depend on which uncond rows ride along
+    if dtype == torch.float32:                                                   # (the 16-bit GEMMs pick their tile shape from the row count; the fp32 kernel does not)
+        assert torch.equal(three[n:], full[2 * n:])                              # the cond rows do not depend on which uncond rows ride along
     with pytest.raises(_capi.EtainvError):                                       # MasaCtrl couples u_t to u_s: no three-row form
         e.unet(torch.cat([x[n:], x[:n]]), 481, ctx[n:].contiguous(), AttnControl(mode=_capi.ATTN_MASA, n_img=n, masa_active=True, first_row=n))
