@@ -191,8 +191,9 @@ class EtaLoop:
                 t = int(t)
                 ctrl = None
                 if ptp is not None:
-                    ctrl = AttnControl(mode=_capi.ATTN_PTP, n_img=B, store_maps=True, mapper=ptp.mapper, alphas=ptp.alphas,
-                                       replace_mat=ptp.replace_mat, equalizer=ptp.equalizer, cross_alpha=ptp.cross_alpha[i],
+                    live = bool(ptp.cross_active[i])
+                    ctrl = AttnControl(mode=_capi.ATTN_PTP, n_img=B, store_maps=True, mapper=ptp.mapper if live else None, alphas=ptp.alphas,
+                                       replace_mat=ptp.replace_mat if live else None, equalizer=ptp.equalizer, cross_alpha=ptp.cross_alpha[i],
                                        self_replace_active=ptp.self_lo <= i < ptp.self_hi, self_max_tokens=(L // 2) ** 2)
                 elif masactrl is not None:
                     ctrl = AttnControl(mode=_capi.ATTN_MASA, n_img=B, masa_active=masactrl[0] <= i < 50, masa_first_block=masactrl[1])
@@ -262,6 +263,10 @@ class PtpTables:
         self.replace_mat = T(replace_mat, torch.float32)  # (B,77,77)
         self.blend_alpha = T(blend_alpha, torch.float32)  # (B,2,77)
         self.cross_alpha = T(cross_alpha, torch.float32)  # (S+1,B,77)
+        # steps whose cross_replace_alpha row is all zero: the cross edit is the identity there (rep * 0 + 1 * own, reference ptp.py:228) -- the loop
+        # then runs the plain cross-attention launch for the cond-target rows too (no source-probability recomputation); the map store stays on
+        ca = np.asarray(cross_alpha, dtype=np.float32)
+        self.cross_active = (ca.reshape(ca.shape[0], -1) != 0).any(1)
         if isinstance(self_replace_steps, float):
             self_replace_steps = (0, self_replace_steps)
         self.self_lo, self.self_hi = int(S * self_replace_steps[0]), int(S * self_replace_steps[1])
