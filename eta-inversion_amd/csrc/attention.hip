@@ -700,6 +700,11 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
     img = b % p.n_img;
     is_cond = (p.rows == p.n_img) ? 1 : (b / p.n_img);
     role = 0;
+  } else if (p.layout == 3) {   // rows [u_t, c_t, c_s] x n_img (store only: etainv_attn_ctrl.src_exit_block)
+    const int g = b / p.n_img;
+    img = b % p.n_img;
+    is_cond = g >= 1;
+    role = g == 1 ? 1 : 0;
   }
   const bool do_edit = EDIT && p.edit && p.layout == 2 && is_cond && role == 1;
   const bool do_store = p.map_layer >= 0 && is_cond;

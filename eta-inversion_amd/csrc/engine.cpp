@@ -620,7 +620,7 @@ struct Fwd {
     cp.maps_acc = e->maps_acc;
     if (ctrl && (ctrl->mode == ETAINV_ATTN_PTP || ctrl->mode == ETAINV_ATTN_STORE)) {
       cp.n_img = ctrl->n_img;
-      cp.layout = ctrl->mode == ETAINV_ATTN_PTP ? 2 : 1;
+      cp.layout = ctrl->mode == ETAINV_ATTN_PTP ? (ctrl->src_exit_block ? 3 : 2) : 1;   // 3: rows [u_t, c_t, c_s] (cond source rows leave early)
       cp.first_row = ctrl->mode == ETAINV_ATTN_PTP ? ctrl->first_row : 0;
       if (ctrl->mode == ETAINV_ATTN_PTP && ctrl->cross_alpha && (ctrl->mapper || ctrl->replace_mat)) {
         cp.edit = 1;
@@ -795,6 +795,9 @@ static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const in
   if (ctrl) {
     ETAINV_CHECK(ctrl->n_img >= 1 && ctrl->n_img <= e->max_img, "ctrl.n_img exceeds max_img");
     ETAINV_CHECK(ctrl->first_row == 0 || (ctrl->mode == ETAINV_ATTN_PTP && ctrl->first_row == ctrl->n_img), "first_row: 0, or n_img with prompt-to-prompt");
+    ETAINV_CHECK(ctrl->src_exit_block == 0 || (ctrl->mode == ETAINV_ATTN_PTP && ctrl->first_row == ctrl->n_img && !ctrl->self_replace_active && !ctrl->mapper &&
+                                               !ctrl->replace_mat && ctrl->src_exit_block >= 9 && ctrl->src_exit_block < 15),
+                 "src_exit_block: prompt-to-prompt three-row call without self-replace / cross edit, exit after block 9..14");
     if (ctrl->mode == ETAINV_ATTN_PTP || ctrl->mode == ETAINV_ATTN_MASA)
       ETAINV_CHECK(n_rows == 4 * ctrl->n_img - ctrl->first_row, "ptp / masactrl need 4*n_img UNet rows [u_s,u_t,c_s,c_t] (ptp with first_row = n_img: 3*n_img rows [u_t,c_s,c_t])");
     if (ctrl->mode == ETAINV_ATTN_STORE)
@@ -910,6 +913,8 @@ static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const in
         void* t_out = pick_tmp(e, h, nullptr);
         if (f.transformer(e->tb[ti++], h, side, t_out)) return 1;
         h = t_out;
+        // the cond source rows (last n_img of [u_t, c_t, c_s]) have fed their last stored attention layer: everything after runs on the other rows
+        if (ctrl && ctrl->src_exit_block && ti == ctrl->src_exit_block + 1) f.rows = 2 * ctrl->n_img;
       }
     }
     if (i < 3) {
@@ -932,7 +937,7 @@ static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const in
     p.c1 = 320;
     p.H = p.W = p.Ho = p.Wo = L;
     p.taps = 9;
-    p.M = n_rows * L * L;
+    p.M = f.rows * L * L;
     p.N = 4;
     p.rows_per_batch = L * L;
     return launch_igemm(p, e->dt, s);

@@ -24,7 +24,7 @@ class AttnCtrl(C.Structure):
                 ("mapper", C.c_void_p), ("alphas", C.c_void_p), ("replace_mat", C.c_void_p), ("equalizer", C.c_void_p),
                 ("cross_alpha", C.c_void_p),
                 ("self_replace_active", C.c_int), ("self_max_tokens", C.c_int),
-                ("masa_active", C.c_int), ("masa_first_block", C.c_int), ("first_row", C.c_int), ("reserved", C.c_int * 3)]
+                ("masa_active", C.c_int), ("masa_first_block", C.c_int), ("first_row", C.c_int), ("src_exit_block", C.c_int), ("reserved", C.c_int * 2)]
 
 
 _p, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64

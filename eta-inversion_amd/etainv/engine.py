@@ -16,13 +16,13 @@ class AttnControl:
 
     def __init__(self, mode=_capi.ATTN_PLAIN, n_img=1, store_maps=False, mapper=None, alphas=None, replace_mat=None,
                  equalizer=None, cross_alpha=None, self_replace_active=False, self_max_tokens=32 ** 2, masa_active=False,
-                 masa_first_block=10, first_row=0):
+                 masa_first_block=10, first_row=0, src_exit_block=0):
         self._keep = (mapper, alphas, replace_mat, equalizer, cross_alpha)
         self.c = _capi.AttnCtrl(mode=mode, n_img=n_img, store_maps=int(store_maps), mapper=_capi.ptr(mapper),
                                 alphas=_capi.ptr(alphas), replace_mat=_capi.ptr(replace_mat), equalizer=_capi.ptr(equalizer),
                                 cross_alpha=_capi.ptr(cross_alpha), self_replace_active=int(self_replace_active),
                                 self_max_tokens=int(self_max_tokens), masa_active=int(masa_active),
-                                masa_first_block=int(masa_first_block), first_row=int(first_row))
+                                masa_first_block=int(masa_first_block), first_row=int(first_row), src_exit_block=int(src_exit_block))
 
 
 class Engine:

@@ -43,6 +43,8 @@ def eta_table(eta=(0.0, 0.4)) -> np.ndarray:
 
 
 class EtaLoop:
+    SRC_EXIT_SHARE = 0.509      # share of a UNet sample-forward's FLOPs in front of the exit after transformer block 9 (204.3 of 401.6 GMAC: the layer walk of SURVEY App. A / G)
+
     def __init__(self, engine, S=50, guidance_scale_bwd=7.5, guidance_scale_fwd=1.0, eta=(0.0, 0.4), noise_sample_count=10,
                  use_mask=True, mask_thres=0.2, skip_uncond_fwd=True, steps_offset=0, mask_eta="fwd_mean", mask_pow=None, target_dirinv=None,
                  mask_dirinv=None, skip_dead_source_rows=True):
@@ -73,6 +75,10 @@ class EtaLoop:
         # x_prev_src itself instead of x + (x_prev_src - x): at most one rounding apart (SURVEY E-11).  Like skip_uncond_fwd an exact identity of the
         # reference's arithmetic, not an approximation; skip_dead_source_rows=False runs the reference's row count.
         self.skip_dead_source_rows = skip_dead_source_rows and target_dirinv is None and not os.environ.get("ETAINV_NO_DEAD_ROW_SKIP")   # (env: A/B switch)
+        # ... and once nothing is injected from the source (no cross replacement, self-replace over: steps >= 30 of 50 with the PIE settings) the cond source
+        # row of such a step leaves the network after the last stored (L/4)^2 cross layer (transformer block 9; etainv_attn_ctrl.src_exit_block): its
+        # noise prediction is unused.  ETAINV_NO_SRC_EXIT=1: A/B switch.
+        self.src_exit = self.skip_dead_source_rows and not os.environ.get("ETAINV_NO_SRC_EXIT")
         self.rows_executed = 0                                   # UNet sample-forwards issued by invert / sample since construction (bench accounting)
         self.lib = engine.lib
 
@@ -183,7 +189,7 @@ class EtaLoop:
                 return m.reshape(B, L, L)
         if ptp is not None:
             e.maps_reset()
-        ctx3 = eps3 = None
+        ctx3 = eps3 = ctx3x = eps3x = None
         eps_t = torch.empty(B, 4, L, L, dtype=torch.float32, device=dev)
         st = _capi.stream_ptr()
         with e.cached_context():                               # one unchanged context tensor for all S calls
@@ -204,20 +210,31 @@ class EtaLoop:
                 var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
                 if self.skip_dead_source_rows and float(self.etas[t]) == 0.0 and masactrl is None:
                     # eta == 0: no eps(uncond source) -- rows [u_t, c_s, c_t] over latents [tgt, src] (ptp) or [u_t, c_t] over [tgt] (no coupling)
-                    if ptp is not None:
+                    if ptp is not None and not live and not (ptp.self_lo <= i < ptp.self_hi) and self.src_exit:
+                        # nothing is injected from the source any more (cross alpha row zero, self-replace over): the cond source row only feeds the
+                        # AttentionStore of the five (L/4)^2 cross layers (LocalBlend / bwd_* masks) -- rows [u_t, c_t, c_s], c_s leaves after block 9
+                        if ctx3x is None:
+                            ctx3x = torch.cat([ctx_tgt[:, 0], ctx_tgt[:, 1], ctx_src[:, 1]]).contiguous().float()
+                            eps3x = torch.empty(3 * B, 4, L, L, dtype=torch.float32, device=dev)
+                        ctrl.c.first_row, ctrl.c.src_exit_block = B, 9
+                        e.unet(torch.cat([x[B:], x[B:], x[:B]]), t, ctx3x, ctrl, out=eps3x)
+                        eu, ec = eps3x[:B], eps3x[B:2 * B]
+                        self.rows_executed += 2 * B + B * self.SRC_EXIT_SHARE          # (the exited rows ran 51 % of the UNet's FLOPs)
+                    elif ptp is not None:
                         if ctx3 is None:
                             ctx3 = torch.cat([ctx_tgt[:, 0], ctx_src[:, 1], ctx_tgt[:, 1]]).contiguous().float()
                             eps3 = torch.empty(3 * B, 4, L, L, dtype=torch.float32, device=dev)
                         ctrl.c.first_row = B
                         e.unet(torch.cat([x[B:], x[:B]]), t, ctx3, ctrl, out=eps3)
                         eu, ec = eps3[:B], eps3[2 * B:]
+                        self.rows_executed += 3 * B
                     else:
                         if ctx3 is None:
                             ctx3 = torch.cat([ctx_tgt[:, 0], ctx_tgt[:, 1]]).contiguous().float()
                             eps3 = torch.empty(2 * B, 4, L, L, dtype=torch.float32, device=dev)
                         e.unet(x[B:], t, ctx3, None, out=eps3)
                         eu, ec = eps3[:B], eps3[B:]
-                    self.rows_executed += ctx3.shape[0]
+                        self.rows_executed += 2 * B
                     n_t = B * 4 * L * L
                     _capi.check(self.lib.etainv_cfg_combine(_capi.ptr(eu), _capi.ptr(ec), self.g_bwd, _capi.ptr(eps_t), n_t, _capi.F32, st))
                     _capi.check(self.lib.etainv_ddim_eta_step(_capi.ptr(x[B:]), _capi.ptr(eps_t), 0.0, None, 0, None, a_t, a_p, var, B, 4, L * L,
@@ -228,7 +245,7 @@ class EtaLoop:
                     if ptp is not None and ptp.blend_alpha is not None and (i + 1) > int(0.2 * S):
                         e.local_blend(x, B, ptp.blend_alpha, 0.3)
                     if trace is not None:
-                        trace.append({"t": t, "latent": x.clone(), "best": best.clone(), "eps_all": None, "rows": int(ctx3.shape[0])})
+                        trace.append({"t": t, "latent": x.clone(), "best": best.clone(), "eps_all": None})
                     continue
                 e.unet(x, t, ctx, ctrl, out=eps_all)
                 self.rows_executed += 4 * B

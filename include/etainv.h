@@ -145,7 +145,13 @@ typedef struct etainv_attn_ctrl {
    * inversion trajectory (modules/inversion/eta_inversion.py:247-249) and its guided noise only feeds the best-of-n choice of a noise that is then
    * multiplied by eta = 0 (:232, :330-375); the cond source row stays (its attention probabilities are what prompt-to-prompt injects). */
   int first_row;
-  int reserved[3];
+  /* PTP with first_row = n_img only.  != 0: the 3 n_img rows are ordered [u_t, c_t, c_s] and the cond source rows LEAVE the network after transformer block
+   * `src_exit_block` (execution order 0..15): from there on only the first 2 n_img rows are computed and the last n_img rows of `out` are not written.
+   * For backward steps with eta == 0 in which nothing is injected from the source any more (cross_replace_alpha row all zero, self-replace over): the
+   * cond source row then only feeds the AttentionStore of the five (L/4)^2 cross layers (LocalBlend, modules/utils/ptp.py:37-39), the last of which is
+   * block 9 -- its noise prediction is unused (the source latent is replayed).  Needs self_replace_active == 0 and no mapper / replace_mat. */
+  int src_exit_block;
+  int reserved[2];
 } etainv_attn_ctrl;
 
 /* eps = UNet(latent, t, ctx).  Replaces `self.unet(latent_input, t, encoder_hidden_states=context)["sample"]`

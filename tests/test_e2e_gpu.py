@@ -299,3 +299,48 @@ def test_dead_source_rows_are_skipped_not_changed(setup, editor):
     e_src, e_tgt = relerr(outs[0][:B], outs[1][:B]), relerr(outs[0][B:], outs[1][B:])
     print(f"{editor}: dead-row skipping vs the full row count: source row {e_src:.2e}, edited latent {e_tgt:.2e}; UNet rows {rows[0]} vs {rows[1]}")
     assert e_src < 1e-6 and e_tgt < 2e-3                                       # (fp16: tile / split-K choices follow the row count)
+
+
+def test_cond_source_rows_exit_early_not_changed(setup):
+    """etainv_attn_ctrl.src_exit_block: in eta == 0 backward steps after the cross replacement and the self-replace have ended, the cond source rows
+    leave the UNet after transformer block 9 (their last stored attention layer).  Same edited latent, same LocalBlend masks (the store is what
+    they still feed), fewer FLOPs.  ETAINV_NO_SRC_EXIT=1 is the A/B switch."""
+    import os
+    from oracle import ptp as optp
+    from etainv.pipeline import EtaLoop, PtpTables, noise_table
+    unet, get_engine = setup
+    L, S_, eta = 16, 10, [[0.6, 0], [1, 0.7]]        # eta == 0 for t <= 500: 6 steps; cross alpha zero from step 4, self-replace ends at 6: exit in steps 6..9
+    eng = get_engine(L, torch.float16)
+    pairs, z0, ctx_src, ctx_tgt = _inputs(L)
+    tok = optp.WordTokenizer()
+    W = max(len(s.split(" ")) for s, _ in pairs)
+    tokens = torch.ones(B, W, dtype=torch.int32)
+    mp, al, eq, ba, ca = [], [], [], [], []
+    for i, (src, tgt) in enumerate(pairs):
+        ws = src.split(" ")
+        tokens[i, :len(ws)] = torch.tensor([ws.index(w) + 1 for w in ws], dtype=torch.int32)
+        bw, tw = ws[1], tgt.split(" ")[1]
+        m, a = optp.refinement_mapper(src, tgt, tok)
+        mp.append(m); al.append(a)
+        eq.append(optp.equalizer(tgt, (tw,), (2,), tok))
+        ba.append(optp.blend_alpha_layers([src, tgt], ((bw,), (tw,)), tok))
+        ca.append(optp.time_words_alpha([src, tgt], S_, {"default_": .4}, tok)[:, 0])
+    ptp = PtpTables(np.stack(mp), np.stack(al), np.stack(ca, 1), 0.6, S_, equalizer=np.stack(eq), blend_alpha=np.stack(ba))
+    nz = noise_table(S_, 10, L, seed=0)
+    outs, rows = [], []
+    for off in (False, True):
+        if off:
+            os.environ["ETAINV_NO_SRC_EXIT"] = "1"
+        try:
+            loop = EtaLoop(eng, S=S_, eta=eta)
+        finally:
+            os.environ.pop("ETAINV_NO_SRC_EXIT", None)
+        inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
+        r0 = loop.rows_executed
+        outs.append(loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), nz, edit_word=torch.tensor([1, 1]), ptp=ptp).clone())
+        rows.append(loop.rows_executed - r0)
+    n_exit = sum(1 for i, t in enumerate(loop.t_bwd) if loop.etas[int(t)] == 0.0 and not ptp.cross_active[i] and not (ptp.self_lo <= i < ptp.self_hi))
+    assert n_exit == 4 and abs((rows[1] - rows[0]) - n_exit * B * (1 - EtaLoop.SRC_EXIT_SHARE)) < 1e-6
+    e_src, e_tgt = relerr(outs[0][:B], outs[1][:B]), relerr(outs[0][B:], outs[1][B:])
+    print(f"cond source rows exit after block 9 in {n_exit} steps: source row {e_src:.2e}, edited latent {e_tgt:.2e}; UNet row-equivalents {rows[0]:.1f} vs {rows[1]:.1f}")
+    assert e_src == 0.0 and e_tgt < 2e-3
