@@ -288,8 +288,13 @@ def test_dead_source_rows_are_skipped_not_changed(setup, editor):
     ptp = PtpTables(np.stack(mp), np.stack(al), np.stack(ca, 1), 0.6, S_, equalizer=np.stack(eq), blend_alpha=np.stack(ba)) if editor == "ptp" else None
     nz = noise_table(S_, 10, L, seed=0)
     outs, rows = [], []
+    import os
     for skip in (True, False):
-        loop = EtaLoop(eng, S=S_, eta=eta, skip_dead_source_rows=skip)
+        os.environ["ETAINV_NO_SRC_EXIT"] = "1"            # (the early exit of the cond source rows has its own test below)
+        try:
+            loop = EtaLoop(eng, S=S_, eta=eta, skip_dead_source_rows=skip)
+        finally:
+            del os.environ["ETAINV_NO_SRC_EXIT"]
         inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
         r0 = loop.rows_executed
         outs.append(loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), nz, edit_word=torch.tensor([1, 1]), ptp=ptp).clone())
