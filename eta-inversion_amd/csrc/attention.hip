@@ -94,9 +94,13 @@ __global__ void __launch_bounds__(256) self_attn_kernel(const T* __restrict__ qk
   int bq = b, bk = b, bv = b;
   if (mode != 0) {
     int half, role, img;
-    row_roles(b + first_row, n_img, half, role, img);   // (first_row: the call carries rows [first_row, 4 n_img) of the [u_s,u_t,c_s,c_t] layout)
-    if (mode == 1 && half == 1 && role == 1) { bq = b - n_img; bk = b - n_img; }
-    if (mode == 2 && role == 1) { bk = b - n_img; bv = b - n_img; }
+    if (first_row < 0) {   // rows [u_t, c_t, c_s] x n_img (etainv_attn_ctrl.src_exit_block): the cond target rows take Q, K of the cond source rows BEHIND them
+      if (mode == 1 && b / n_img == 1) { bq = b + n_img; bk = b + n_img; }
+    } else {
+      row_roles(b + first_row, n_img, half, role, img);   // (first_row: the call carries rows [first_row, 4 n_img) of the [u_s,u_t,c_s,c_t] layout)
+      if (mode == 1 && half == 1 && role == 1) { bq = b - n_img; bk = b - n_img; }
+      if (mode == 2 && role == 1) { bk = b - n_img; bv = b - n_img; }
+    }
   }
   const int q_base = blockIdx.x * (64 * QT) + wid * (16 * QT);
   // De-phase the two blocks that share a CU (one wave of each per SIMD): both run [QK^T MFMAs | softmax VALU | PV MFMAs] with the
@@ -418,9 +422,13 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
   int bq = b, bk = b, bv = b;
   if (mode != 0) {
     int half, role, img;
-    row_roles(b + first_row, n_img, half, role, img);   // (first_row: the call carries rows [first_row, 4 n_img) of the [u_s,u_t,c_s,c_t] layout)
-    if (mode == 1 && half == 1 && role == 1) { bq = b - n_img; bk = b - n_img; }
-    if (mode == 2 && role == 1) { bk = b - n_img; bv = b - n_img; }
+    if (first_row < 0) {   // rows [u_t, c_t, c_s] x n_img (etainv_attn_ctrl.src_exit_block): the cond target rows take Q, K of the cond source rows BEHIND them
+      if (mode == 1 && b / n_img == 1) { bq = b + n_img; bk = b + n_img; }
+    } else {
+      row_roles(b + first_row, n_img, half, role, img);   // (first_row: the call carries rows [first_row, 4 n_img) of the [u_s,u_t,c_s,c_t] layout)
+      if (mode == 1 && half == 1 && role == 1) { bq = b - n_img; bk = b - n_img; }
+      if (mode == 2 && role == 1) { bk = b - n_img; bv = b - n_img; }
+    }
   }
   const int q_base = qblk * (128 * QB) + wid * (32 * QB);
   // experiment (ETAINV_A40_STAGGER, 64-cycle ticks): delay the second co-resident block of each CU (ids 256 .. 511 of every 512 under
@@ -927,8 +935,9 @@ static int launch_self40(const void* qkv, void* out, int b, int n, int heads, in
 int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int heads, int d, int mode, int n_img, int dtype,
                                hipStream_t s, int q_prescaled, int first_row) {
   ETAINV_CHECK(qkv && out && b > 0 && n > 0, "bad arguments");
-  ETAINV_CHECK(mode == 0 || (n_img > 0 && b + first_row == 4 * n_img && (first_row == 0 || (first_row == n_img && mode == 1))),
-               "ptp / masactrl modes need the 4*n_img backward layout (ptp: optionally without its first n_img rows)");
+  ETAINV_CHECK(mode == 0 || (n_img > 0 && ((first_row >= 0 && b + first_row == 4 * n_img && (first_row == 0 || (first_row == n_img && mode == 1))) ||
+                                           (first_row < 0 && b == 3 * n_img && mode == 1))),
+               "ptp / masactrl modes need the 4*n_img backward layout (ptp: optionally without its first n_img rows, or rows [u_t, c_t, c_s] with first_row < 0)");
   if (dtype == ETAINV_F32) {
     ETAINV_CHECK(!q_prescaled, "fp32 path: the softmax scale is applied in the kernel");
     return launch_self_attention_f32(qkv, out, b, n, heads, d, mode, n_img, s, first_row);

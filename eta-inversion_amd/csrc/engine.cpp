@@ -591,7 +591,8 @@ struct Fwd {
       if (launch_layernorm(e->hsA, t.ln1.g, t.ln1.b, e->lnbuf, M, c, 1e-5f, e->dt, s)) return 1;
       if (gemm(e->lnbuf, t.qkv, e->qkvbuf, M)) return 1;
     }
-    if (launch_self_attention_mode(e->qkvbuf, e->attnbuf, rows, hw, etainv_engine::kHeads, d, mode, n_img, e->dt, s, /*q_prescaled=*/d <= 80 && self_attn40_v2_enabled() && e->dt != ETAINV_F32, ctrl ? ctrl->first_row : 0)) return 1;
+    if (launch_self_attention_mode(e->qkvbuf, e->attnbuf, rows, hw, etainv_engine::kHeads, d, mode, n_img, e->dt, s, /*q_prescaled=*/d <= 80 && self_attn40_v2_enabled() && e->dt != ETAINV_F32,
+                                   ctrl ? (ctrl->src_exit_block ? -1 : ctrl->first_row) : 0)) return 1;
     if (gemm(e->attnbuf, t.out1, e->hsB, M, e->hsA, 0, nullptr, 0, 0, fold)) return 1;
     if (self_rows != all_rows) {   // the other half of the batch enters the cross-attention with the same residual stream (and LayerNorm statistics)
       const size_t off = (size_t)M * c * e->esz, Mn = (size_t)(all_rows - self_rows) * hw;   // rows [0, all - self) -> rows [self, all)
@@ -795,9 +796,10 @@ static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const in
   if (ctrl) {
     ETAINV_CHECK(ctrl->n_img >= 1 && ctrl->n_img <= e->max_img, "ctrl.n_img exceeds max_img");
     ETAINV_CHECK(ctrl->first_row == 0 || (ctrl->mode == ETAINV_ATTN_PTP && ctrl->first_row == ctrl->n_img), "first_row: 0, or n_img with prompt-to-prompt");
-    ETAINV_CHECK(ctrl->src_exit_block == 0 || (ctrl->mode == ETAINV_ATTN_PTP && ctrl->first_row == ctrl->n_img && !ctrl->self_replace_active && !ctrl->mapper &&
-                                               !ctrl->replace_mat && ctrl->src_exit_block >= 9 && ctrl->src_exit_block < 15),
-                 "src_exit_block: prompt-to-prompt three-row call without self-replace / cross edit, exit after block 9..14");
+    // (the self-replace reaches up to the (L/2)^2-token layers: transformer blocks <= 12 -- an exit in front of that would starve it)
+    ETAINV_CHECK(ctrl->src_exit_block == 0 || (ctrl->mode == ETAINV_ATTN_PTP && ctrl->first_row == ctrl->n_img && !ctrl->mapper && !ctrl->replace_mat &&
+                                               ctrl->src_exit_block >= (ctrl->self_replace_active ? 12 : 9) && ctrl->src_exit_block < 15),
+                 "src_exit_block: prompt-to-prompt three-row call without cross edit; exit after block 9..14 (12..14 while the self-replace is active)");
     if (ctrl->mode == ETAINV_ATTN_PTP || ctrl->mode == ETAINV_ATTN_MASA)
       ETAINV_CHECK(n_rows == 4 * ctrl->n_img - ctrl->first_row, "ptp / masactrl need 4*n_img UNet rows [u_s,u_t,c_s,c_t] (ptp with first_row = n_img: 3*n_img rows [u_t,c_s,c_t])");
     if (ctrl->mode == ETAINV_ATTN_STORE)

@@ -282,9 +282,13 @@ __global__ void __launch_bounds__(256) self_attn_f32_kernel(const float* __restr
   const int b = blockIdx.z, hd = blockIdx.y, C = heads * D, C3 = 3 * C;
   int bq = b, bk = b, bv = b;
   if (mode != 0) {
-    const int bl = b + first_row, half = bl / (2 * n_img), role = (bl / n_img) & 1;
-    if (mode == 1 && half == 1 && role == 1) { bq = b - n_img; bk = b - n_img; }
-    if (mode == 2 && role == 1) { bk = b - n_img; bv = b - n_img; }
+    if (first_row < 0) {   // rows [u_t, c_t, c_s] x n_img: the cond target rows take Q, K of the cond source rows behind them
+      if (mode == 1 && b / n_img == 1) { bq = b + n_img; bk = b + n_img; }
+    } else {
+      const int bl = b + first_row, half = bl / (2 * n_img), role = (bl / n_img) & 1;
+      if (mode == 1 && half == 1 && role == 1) { bq = b - n_img; bk = b - n_img; }
+      if (mode == 2 && role == 1) { bk = b - n_img; bv = b - n_img; }
+    }
   }
   const int query = blockIdx.x * 128 + wid * 32 + l31;
   const bool q_ok = query < N;

@@ -43,6 +43,7 @@ def eta_table(eta=(0.0, 0.4)) -> np.ndarray:
 
 
 class EtaLoop:
+    SRC_EXIT_SHARE_12 = 0.716   # ... and in front of the exit after block 12 (the last (L/2)^2-token self-attention: 287.7 GMAC)
     SRC_EXIT_SHARE = 0.509      # share of a UNet sample-forward's FLOPs in front of the exit after transformer block 9 (204.3 of 401.6 GMAC: the layer walk of SURVEY App. A / G)
 
     def __init__(self, engine, S=50, guidance_scale_bwd=7.5, guidance_scale_fwd=1.0, eta=(0.0, 0.4), noise_sample_count=10,
@@ -210,16 +211,18 @@ class EtaLoop:
                 var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
                 if self.skip_dead_source_rows and float(self.etas[t]) == 0.0 and masactrl is None:
                     # eta == 0: no eps(uncond source) -- rows [u_t, c_s, c_t] over latents [tgt, src] (ptp) or [u_t, c_t] over [tgt] (no coupling)
-                    if ptp is not None and not live and not (ptp.self_lo <= i < ptp.self_hi) and self.src_exit:
-                        # nothing is injected from the source any more (cross alpha row zero, self-replace over): the cond source row only feeds the
-                        # AttentionStore of the five (L/4)^2 cross layers (LocalBlend / bwd_* masks) -- rows [u_t, c_t, c_s], c_s leaves after block 9
+                    if ptp is not None and not live and self.src_exit:
+                        # no cross replacement any more: the cond source row only feeds the AttentionStore of the five (L/4)^2 cross layers (LocalBlend /
+                        # bwd_* masks; last one = block 9) and, while the self-replace runs, the (L/2)^2-token self-attentions (last one = block 12) --
+                        # rows [u_t, c_t, c_s], c_s leaves after that block
                         if ctx3x is None:
                             ctx3x = torch.cat([ctx_tgt[:, 0], ctx_tgt[:, 1], ctx_src[:, 1]]).contiguous().float()
                             eps3x = torch.empty(3 * B, 4, L, L, dtype=torch.float32, device=dev)
-                        ctrl.c.first_row, ctrl.c.src_exit_block = B, 9
+                        self_on = ptp.self_lo <= i < ptp.self_hi
+                        ctrl.c.first_row, ctrl.c.src_exit_block = B, 12 if self_on else 9
                         e.unet(torch.cat([x[B:], x[B:], x[:B]]), t, ctx3x, ctrl, out=eps3x)
                         eu, ec = eps3x[:B], eps3x[B:2 * B]
-                        self.rows_executed += 2 * B + B * self.SRC_EXIT_SHARE          # (the exited rows ran 51 % of the UNet's FLOPs)
+                        self.rows_executed += 2 * B + B * (self.SRC_EXIT_SHARE_12 if self_on else self.SRC_EXIT_SHARE)   # (share of the UNet's FLOPs the exited rows ran)
                     elif ptp is not None:
                         if ctx3 is None:
                             ctx3 = torch.cat([ctx_tgt[:, 0], ctx_src[:, 1], ctx_tgt[:, 1]]).contiguous().float()

@@ -149,7 +149,8 @@ typedef struct etainv_attn_ctrl {
    * `src_exit_block` (execution order 0..15): from there on only the first 2 n_img rows are computed and the last n_img rows of `out` are not written.
    * For backward steps with eta == 0 in which nothing is injected from the source any more (cross_replace_alpha row all zero, self-replace over): the
    * cond source row then only feeds the AttentionStore of the five (L/4)^2 cross layers (LocalBlend, modules/utils/ptp.py:37-39), the last of which is
-   * block 9 -- its noise prediction is unused (the source latent is replayed).  Needs self_replace_active == 0 and no mapper / replace_mat. */
+   * block 9 -- its noise prediction is unused (the source latent is replayed).  Needs mapper == replace_mat == NULL; while self_replace_active the exit
+   * must lie behind the last (L/2)^2-token self-attention (block 12). */
   int src_exit_block;
   int reserved[2];
 } etainv_attn_ctrl;

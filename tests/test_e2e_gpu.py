@@ -314,7 +314,7 @@ def test_cond_source_rows_exit_early_not_changed(setup):
     from oracle import ptp as optp
     from etainv.pipeline import EtaLoop, PtpTables, noise_table
     unet, get_engine = setup
-    L, S_, eta = 16, 10, [[0.6, 0], [1, 0.7]]        # eta == 0 for t <= 500: 6 steps; cross alpha zero from step 4, self-replace ends at 6: exit in steps 6..9
+    L, S_, eta = 16, 10, [[0.6, 0], [1, 0.7]]        # eta == 0 for t <= 500: steps 4..9; cross alpha zero from step 4; self-replace until step 6: exit after block 12 in steps 4, 5, after block 9 in 6..9
     eng = get_engine(L, torch.float16)
     pairs, z0, ctx_src, ctx_tgt = _inputs(L)
     tok = optp.WordTokenizer()
@@ -344,8 +344,10 @@ def test_cond_source_rows_exit_early_not_changed(setup):
         r0 = loop.rows_executed
         outs.append(loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), nz, edit_word=torch.tensor([1, 1]), ptp=ptp).clone())
         rows.append(loop.rows_executed - r0)
-    n_exit = sum(1 for i, t in enumerate(loop.t_bwd) if loop.etas[int(t)] == 0.0 and not ptp.cross_active[i] and not (ptp.self_lo <= i < ptp.self_hi))
-    assert n_exit == 4 and abs((rows[1] - rows[0]) - n_exit * B * (1 - EtaLoop.SRC_EXIT_SHARE)) < 1e-6
+    dead = [i for i, t in enumerate(loop.t_bwd) if loop.etas[int(t)] == 0.0 and not ptp.cross_active[i]]
+    n12 = sum(1 for i in dead if ptp.self_lo <= i < ptp.self_hi)
+    n_exit = len(dead) - n12
+    assert (n_exit, n12) == (4, 2) and abs((rows[1] - rows[0]) - B * (n_exit * (1 - EtaLoop.SRC_EXIT_SHARE) + n12 * (1 - EtaLoop.SRC_EXIT_SHARE_12))) < 1e-6
     e_src, e_tgt = relerr(outs[0][:B], outs[1][:B]), relerr(outs[0][B:], outs[1][B:])
-    print(f"cond source rows exit after block 9 in {n_exit} steps: source row {e_src:.2e}, edited latent {e_tgt:.2e}; UNet row-equivalents {rows[0]:.1f} vs {rows[1]:.1f}")
+    print(f"cond source rows exit after block 9 in {n_exit} steps, after block 12 in {n12}: source row {e_src:.2e}, edited latent {e_tgt:.2e}; UNet row-equivalents {rows[0]:.1f} vs {rows[1]:.1f}")
     assert e_src == 0.0 and e_tgt < 2e-3

@@ -242,5 +242,21 @@ def test_three_row_layout_equals_the_four_row_call(engines, dtype):
     assert relerr(three, full[n:]) < tol and relerr(maps_three, maps_full) < tol
     if dtype == torch.float32:                                                   # (the 16-bit GEMMs pick their tile shape from the row count; the fp32 kernel does not)
         assert torch.equal(three[n:], full[2 * n:])                              # the cond rows do not depend on which uncond rows ride along
+    # src_exit_block: rows [u_t, c_t, c_s], no cross edit; the cond source rows leave after block 12 (self-replace still active: the (L/2)^2-token
+    # self-attentions read their Q, K) or after block 9 (store only) -- the u_t / c_t outputs and the stored maps equal the full call's
+    for self_on, exit_block in ((True, 12), (False, 9)):
+        mk2 = lambda first, ex: AttnControl(mode=_capi.ATTN_PTP, n_img=n, store_maps=True, equalizer=eq, cross_alpha=ca, self_replace_active=self_on,
+                                            self_max_tokens=64, first_row=first, src_exit_block=ex)
+        e.maps_reset()
+        full2 = e.unet(x, 481, ctx, mk2(0, 0)).clone()
+        maps_full2 = e.word_maps(n, tokens, 1, torch.empty(n, 4, 16, 16, device="cuda")).clone()
+        e.maps_reset()
+        ctx_x = torch.cat([ctx[n:2 * n], ctx[3 * n:], ctx[2 * n:3 * n]]).contiguous()                  # [u_t, c_t, c_s]
+        ex = e.unet(torch.cat([x[n:], x[n:], x[:n]]), 481, ctx_x, mk2(n, exit_block)).clone()
+        maps_ex = e.word_maps(n, tokens, 1, torch.empty(n, 4, 16, 16, device="cuda")).clone()
+        assert relerr(ex[:n], full2[n:2 * n]) < tol and relerr(ex[n:2 * n], full2[3 * n:]) < tol and relerr(maps_ex, maps_full2) < tol
+    with pytest.raises(_capi.EtainvError):                                       # an exit in front of the last self-replace layer would starve it
+        e.unet(torch.cat([x[n:], x[n:], x[:n]]), 481, ctx_x, mk2(n, 9) if False else AttnControl(
+            mode=_capi.ATTN_PTP, n_img=n, store_maps=True, cross_alpha=ca, self_replace_active=True, self_max_tokens=64, first_row=n, src_exit_block=9))
     with pytest.raises(_capi.EtainvError):                                       # MasaCtrl couples u_t to u_s: no three-row form
         e.unet(torch.cat([x[n:], x[:n]]), 481, ctx[n:].contiguous(), AttnControl(mode=_capi.ATTN_MASA, n_img=n, masa_active=True, first_row=n))
