@@ -80,6 +80,7 @@ class EtaLoop:
         # row of such a step leaves the network after the last stored (L/4)^2 cross layer (transformer block 9; etainv_attn_ctrl.src_exit_block): its
         # noise prediction is unused.  ETAINV_NO_SRC_EXIT=1: A/B switch.
         self.src_exit = self.skip_dead_source_rows and not os.environ.get("ETAINV_NO_SRC_EXIT")
+        self.src_exit_9_only = bool(os.environ.get("ETAINV_SRC_EXIT_9_ONLY"))   # A/B: no exit while the self-replace runs
         self.rows_executed = 0                                   # UNet sample-forwards issued by invert / sample since construction (bench accounting)
         self.lib = engine.lib
 
@@ -211,7 +212,7 @@ class EtaLoop:
                 var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
                 if self.skip_dead_source_rows and float(self.etas[t]) == 0.0 and masactrl is None:
                     # eta == 0: no eps(uncond source) -- rows [u_t, c_s, c_t] over latents [tgt, src] (ptp) or [u_t, c_t] over [tgt] (no coupling)
-                    if ptp is not None and not live and self.src_exit:
+                    if ptp is not None and not live and self.src_exit and not (self.src_exit_9_only and ptp.self_lo <= i < ptp.self_hi):
                         # no cross replacement any more: the cond source row only feeds the AttentionStore of the five (L/4)^2 cross layers (LocalBlend /
                         # bwd_* masks; last one = block 9) and, while the self-replace runs, the (L/2)^2-token self-attentions (last one = block 12) --
                         # rows [u_t, c_t, c_s], c_s leaves after that block
