@@ -9,7 +9,7 @@ One "step" = the whole hot path over one batch of B synthetic image pairs per GP
 the uncond half is skipped because guidance_scale_fwd == 1 multiplies it out) + 50 backward UNet calls (4B rows) +
 the fused eta / CFG / best-of-n step, word-map and LocalBlend kernels.  The 30 backward steps whose eta(t) is 0 skip the uncond source row
 (its noise prediction is dead work there) and in the 20 of them that come after prompt-to-prompt's source injection has ended the cond source row
-leaves the UNet after its last stored attention layer (etainv/pipeline.py): 210.2 sample-forward equivalents = 168.8 TFLOP per image executed (the
+leaves the UNet after the last layer that needs it (etainv/pipeline.py): 207.3 sample-forward equivalents = 166.6 TFLOP per image executed (the
 reference's call pattern issues 300 = 241.0); `end_to_end_mfma_frac` is computed from the executed count.  Inputs (latents, contexts, noise table, edit tables, synthetic SD1.x-shaped weights) are resident
 in HBM before the timed region.  Prints ONE JSON line on rank 0.
 """
@@ -356,7 +356,7 @@ def main():
     dt = time.time() - t0
     # UNet sample-forwards the timed steps actually issued per image: S cond rows forward + 4 per backward step, minus the uncond source row of the
     # backward steps whose eta(t) is 0 (dead work: EtaLoop.skip_dead_source_rows) and the tail of the cond source row once nothing is injected from it
-    # (EtaLoop.src_exit) -- 210.2 instead of 250 with the paper's eta schedule and the PIE prompt-to-prompt settings
+    # (EtaLoop.src_exit) -- 207.3 instead of 250 with the paper's eta schedule and the PIE prompt-to-prompt settings
     FWD_PER_IMAGE = (loop.rows_executed - rows0) / (B * a.steps)
     assert torch.isfinite(out).all(), "non-finite edited latents"
     if dist is not None:
