@@ -271,9 +271,13 @@ def main():
     ap.add_argument("--dtype", default=None, choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-nets", action="store_true", help="add a secondary figure: image -> image BatchEditor.edit (VAE encode, CLIP, loop, 2 VAE decodes)")
+    ap.add_argument("--all-rows", action="store_true", help="run every UNet row the reference's call pattern has in the backward pass (250 sample-forwards per image: "
+                                                           "no dead-row skipping, no early exit of the cond source rows) -- for A/B; the default is the engine as shipped")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # tests only: launcher / rank protocol over gloo, no engine, no GPU
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
+    if a.all_rows:
+        os.environ["ETAINV_NO_DEAD_ROW_SKIP"] = "1"
     if a.batch is None:
         a.batch = int(os.environ.get("ETAINV_BENCH_BATCH", cfg["batch"])) if a.config == 3 else cfg["batch"]
     if a.dtype is None:
@@ -410,6 +414,10 @@ def main():
                        "baseline_config": a.config,
                        "images_per_gpu": B, "unet_sample_forwards_per_image": FWD_PER_IMAGE,
                        "unet_sample_forwards_per_image_reference": 6 * S_STEPS,
+                       "row_economy": "executed count = S cond rows forward (guidance_scale_fwd == 1 multiplies the uncond half out) + per backward step 4 rows while eta(t) > 0, "
+                                      "3 rows [u_t, c_s, c_t] while eta(t) == 0 (the source row is replayed and its guided noise only picks a noise sample that is multiplied by "
+                                      "eta = 0), the cond source row leaving the UNet after transformer block 12 / 9 once no cross replacement / no self-replace reads it; same edited "
+                                      "latents (tests/test_e2e_gpu.py, profiles/r03_parity_S50.json); `--all-rows` runs 5 S rows per image",
                        "tflop_per_image": FWD_PER_IMAGE * F_UNET_TFLOP, "sharding": f"batch-shard x{world}, final all_gather of latents"},
             "end_to_end_mfma_frac": value / world * FWD_PER_IMAGE * F_UNET_TFLOP / MFMA_PEAK_TFLOPS,
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv3x3 / conv1x1 / linear)", "achieved": achieved,
