@@ -430,6 +430,7 @@ struct Fwd {
   int rows;
   const etainv_attn_ctrl* ctrl;
   int tblock_idx = 0;
+  int ctx_rows = 0;        // rows of the context tensor of this call (== n_rows; `rows` shrinks behind a src_exit_block)
   bool kv_reuse = false;   // the K / V projections of this context are already in e->kvcache (etainv_engine_cache_context)
 
   // rows per GroupNorm partial block of the tensor now in each tracked buffer (0: no partials -- the GroupNorm runs its statistics pass)
@@ -610,7 +611,8 @@ struct Fwd {
       if (gemm(e->lnbuf, t.q, e->qbuf, M)) return 1;
     }
     void* kvb = e->kvcache[blk];
-    if (!kv_reuse && gemm(e->ctxT, t.kv, kvb, rows * etainv_engine::kCtx)) return 1;
+    // (all rows of the call's context, also behind a src_exit_block: a later call that reuses the cache may exit later)
+    if (!kv_reuse && gemm(e->ctxT, t.kv, kvb, ctx_rows * etainv_engine::kCtx)) return 1;
     CrossParams cp;
     cp.N = hw;
     cp.heads = etainv_engine::kHeads;
@@ -809,6 +811,7 @@ static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const in
   const int L = e->L;
   if (e->ln_fused && !e->ln_folded && fold_layernorms(e, s)) return 1;
   Fwd f{e, s, n_rows, ctrl};
+  f.ctx_rows = n_rows;
 
   // timesteps (by value in the kernel arguments: no host buffer outlives this call) -> embedding, MLP, all 22 projections in one GEMM
   if (launch_time_embedding(t_host, n_rows, etainv_engine::kCh0, e->tembuf, e->dt, s)) return 1;

@@ -255,6 +255,16 @@ def test_three_row_layout_equals_the_four_row_call(engines, dtype):
         ex = e.unet(torch.cat([x[n:], x[n:], x[:n]]), 481, ctx_x, mk2(n, exit_block)).clone()
         maps_ex = e.word_maps(n, tokens, 1, torch.empty(n, 4, 16, 16, device="cuda")).clone()
         assert relerr(ex[:n], full2[n:2 * n]) < tol and relerr(ex[n:2 * n], full2[3 * n:]) < tol and relerr(maps_ex, maps_full2) < tol
+    # the same context tensor under the context cache, block-9 exit FIRST: the later block-12 exit must find K / V of all rows in the cache
+    ctx_x = torch.cat([ctx[n:2 * n], ctx[3 * n:], ctx[2 * n:3 * n]]).contiguous()
+    mk3 = lambda self_on, ex: AttnControl(mode=_capi.ATTN_PTP, n_img=n, store_maps=True, equalizer=eq, cross_alpha=ca, self_replace_active=self_on,
+                                          self_max_tokens=64, first_row=n, src_exit_block=ex)
+    lat_x = torch.cat([x[n:], x[n:], x[:n]])
+    want = e.unet(lat_x, 481, ctx_x, mk3(True, 12)).clone()
+    with e.cached_context():
+        e.unet(lat_x, 481, ctx_x, mk3(False, 9))
+        got = e.unet(lat_x, 481, ctx_x, mk3(True, 12)).clone()
+    assert torch.equal(got[:2 * n], want[:2 * n])
     with pytest.raises(_capi.EtainvError):                                       # an exit in front of the last self-replace layer would starve it
         e.unet(torch.cat([x[n:], x[n:], x[:n]]), 481, ctx_x, mk2(n, 9) if False else AttnControl(
             mode=_capi.ATTN_PTP, n_img=n, store_maps=True, cross_alpha=ca, self_replace_active=True, self_max_tokens=64, first_row=n, src_exit_block=9))
