@@ -261,6 +261,7 @@ def test_three_row_layout_equals_the_four_row_call(engines, dtype):
                                           self_max_tokens=64, first_row=n, src_exit_block=ex)
     lat_x = torch.cat([x[n:], x[n:], x[:n]])
     want = e.unet(lat_x, 481, ctx_x, mk3(True, 12)).clone()
+    e.unet(lat_x, 481, torch.randn(3 * n, 77, 768, generator=g).cuda(), mk3(True, 12))       # (another context: the K / V buffers now hold foreign rows)
     with e.cached_context():
         e.unet(lat_x, 481, ctx_x, mk3(False, 9))
         got = e.unet(lat_x, 481, ctx_x, mk3(True, 12)).clone()
