@@ -266,3 +266,74 @@ def test_dpm_solver_oracle_properties():
     assert sch.dpm_timesteps_backward(50).tolist()[:3] == [950, 931, 912] and sch.dpm_timesteps_backward(50)[-1] == 19
     assert sch.dpm_timesteps_forward(50).tolist()[:3] == [0, 19, 38] and len(sch.dpm_timesteps_forward(50)) == 50
     assert sch.dpm_timesteps_backward(10, "linspace").tolist() == [999, 899, 799, 699, 599, 500, 400, 300, 200, 100]
+
+
+def test_backward_loop_row_economy_host_logic(monkeypatch):
+    """Which UNet rows EtaLoop.sample issues per backward step (round 3; no GPU: the engine and the C ABI are replaced by recorders).  With the paper's eta
+    schedule and the PIE prompt-to-prompt settings at S = 50: steps 0..19 (eta > 0, cross replacement live) the reference's four row groups; steps 20..29
+    (eta == 0, no cross replacement, self-replace live) rows [u_t, c_t, c_s] with the cond source rows leaving after block 12; steps 30..49 after block 9.
+    Without attention coupling the eta == 0 steps run [u_t, c_t]; MasaCtrl keeps all rows; skip_dead_source_rows=False restores 4 B rows everywhere."""
+    from etainv import _capi, pipeline
+    from etainv.pipeline import EtaLoop, PtpTables
+
+    class FakeLib:
+        def __getattr__(self, name):
+            return lambda *a, **k: 0
+
+    class FakeEngine:
+        L, lib = 8, FakeLib()
+
+        def __init__(self):
+            self.calls = []
+
+        def unet(self, latent, t, ctx, ctrl=None, out=None):
+            c = ctrl.c if ctrl is not None else None
+            self.calls.append(dict(rows=ctx.shape[0], n_lat=latent.shape[0], t=int(t), first_row=c.first_row if c else 0, exit=c.src_exit_block if c else 0,
+                                   edit=bool(c.mapper) if c else False, self_on=bool(c.self_replace_active) if c else False))
+            out.zero_()
+            return out
+
+        def maps_reset(self): pass
+        def word_maps(self, *a, **k): pass
+        def local_blend(self, x, *a, **k): return x
+
+        import contextlib
+
+        @contextlib.contextmanager
+        def cached_context(self):
+            yield
+    monkeypatch.setattr(_capi, "ptr", lambda t: None if t is None else t.data_ptr())
+    monkeypatch.setattr(_capi, "stream_ptr", lambda: None)
+    monkeypatch.setattr(_capi, "check", lambda rc: None)
+    monkeypatch.setattr(pipeline, "AttnControl", lambda **kw: type("C", (), {"c": _capi.AttnCtrl(
+        mode=kw.get("mode", 0), n_img=kw.get("n_img", 1), mapper=1 if kw.get("mapper") is not None else None,
+        self_replace_active=int(kw.get("self_replace_active", False)), masa_active=int(kw.get("masa_active", False)))})())
+    S, B, L = 50, 2, 8
+    ca = np.zeros((S + 1, B, 77), np.float32)
+    ca[: int(0.4 * (S + 1))] = 1.0
+    ptp = PtpTables(np.tile(np.arange(77, dtype=np.int32), (B, 1)), np.ones((B, 77), np.float32), ca, 0.6, S, equalizer=np.ones((B, 77), np.float32),
+                    blend_alpha=np.zeros((B, 2, 77), np.float32), device="cpu")
+    assert ptp.cross_active[:20].all() and not ptp.cross_active[20:].any() and (ptp.self_lo, ptp.self_hi) == (0, 30)
+    inv = {"latents": torch.zeros(S + 1, B, 4, L, L), "maps_mean": torch.zeros(B, 3, L, L), "maps_steps": None}
+    ctx = torch.zeros(B, 2, 77, 768)
+    noise = torch.zeros(S, 10, 4, L, L)
+
+    def run(**kw):
+        eng = FakeEngine()
+        loop = EtaLoop(eng, S=S, eta=[[0.6, 0], [1, 0.7]], **kw.pop("loop", {}))
+        loop.sample(inv, ctx, ctx, noise, edit_word=torch.ones(B, dtype=torch.int64), **kw)
+        return eng.calls, loop
+    calls, loop = run(ptp=ptp)
+    assert [c["rows"] for c in calls] == [4 * B] * 20 + [3 * B] * 30
+    assert all(c["edit"] and c["first_row"] == 0 and c["exit"] == 0 and c["n_lat"] == 2 * B for c in calls[:20])
+    assert all(not c["edit"] and c["first_row"] == B and c["exit"] == 12 and c["self_on"] and c["n_lat"] == 3 * B for c in calls[20:30])
+    assert all(not c["edit"] and c["first_row"] == B and c["exit"] == 9 and not c["self_on"] for c in calls[30:])
+    want = B * (20 * 4 + 10 * (2 + EtaLoop.SRC_EXIT_SHARE_12) + 20 * (2 + EtaLoop.SRC_EXIT_SHARE))
+    assert abs(loop.rows_executed - want) < 1e-9 and abs(50 + want / B - 207.34) < 0.01       # + the S cond rows of the forward pass
+    calls, _ = run()                                                                            # no attention coupling (simple editor)
+    assert [c["rows"] for c in calls] == [4 * B] * 20 + [2 * B] * 30 and all(c["n_lat"] == B for c in calls[20:])
+    calls, _ = run(masactrl=(4, 10))                                                            # MasaCtrl couples u_t to u_s
+    assert [c["rows"] for c in calls] == [4 * B] * 50
+    calls, loop = run(ptp=ptp, loop=dict(skip_dead_source_rows=False))                          # the reference's row count
+    assert [c["rows"] for c in calls] == [4 * B] * 50 and loop.rows_executed == 4 * B * 50
+    assert [c["edit"] for c in calls] == [True] * 20 + [False] * 30                             # (the identity cross edit is still skipped)
