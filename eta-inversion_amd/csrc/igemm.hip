@@ -1246,9 +1246,10 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   const int64_t huge_tiles = (int64_t)cdiv(p.M, 256) * cdiv(p.N, 160);
   // a LayerNorm consumer on a ring kernel: fast epilogue only (64-row wave tiles inside one image)
   const bool ln_ring_ok = !p.ln_stat || p.rows_per_batch % 64 == 0;
-  // (ring from `ring_min` 256 x 160 tiles on: 256 = one per CU.  The 96- and 64-row backward calls of round 3 bring 192 / 128 tiles at the 8 x 8 level;
-  // ETAINV_RING_MIN_TILES tunes the threshold)
-  static const int ring_min = getenv("ETAINV_RING_MIN_TILES") ? atoi(getenv("ETAINV_RING_MIN_TILES")) : 256;
+  // (ring from `ring_min` 256 x 160 tiles on.  256 = one per CU was the round-2 threshold; the 96-row backward calls of round 3 bring 192 tiles at the
+  // 8 x 8 level, where the ring on 3/4 of the CUs still beats the two-slot 128 x 160 kernel: same-box bench 4.897 (256) / 4.937 (192) / 4.910 (128)
+  // images/s.  ETAINV_RING_MIN_TILES tunes it)
+  static const int ring_min = getenv("ETAINV_RING_MIN_TILES") ? atoi(getenv("ETAINV_RING_MIN_TILES")) : 192;
   if (!p.geglu && p.ups && p.N % 160 == 0 && huge_tiles >= ring_min && !getenv("ETAINV_NO_RING")) {
     // the ring's issue is branch-free, so the fused-upsample addressing is its own instantiation
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, true, 0>(p, s, stat_P)));
