@@ -69,8 +69,8 @@ class DPMSolverMultistepScheduler:
     """Backward DPM-Solver++(2M) scheduler ([3P] diffusers `DPMSolverMultistepScheduler` in the reference, built by
     DiffusionInversion.create_schedulers for `--scheduler dpm`, modules/inversion/diffusion_inversion.py:139-146).  Restated from the
     published method (arXiv:2211.01095, eqs. 11-13) for the configuration the reference ends up with: solver_order 2, "dpmsolver++",
-    midpoint, epsilon prediction, lower_order_final, no Karras sigmas; diffusers itself is absent here, so parity with it is unpinned
-    (what is checked: first order == DDIM exactly, agreement with the oracle's independent restatement).  The latent update is one
+    midpoint, epsilon prediction, lower_order_final, no Karras sigmas; diffusers itself is absent here: the solver pieces are checked through
+    the first order == DDIM identity, and the inverse scheduler built on them is pinned by the reference's own class (tests/golden/dpm_inverse.npz).  The latent update is one
     etainv_lincomb3 launch; all coefficients are host float64 scalars."""
     Output = namedtuple("DPMSolverMultistepSchedulerOutput", ("prev_sample",))
     order = 2

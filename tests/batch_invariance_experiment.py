@@ -17,7 +17,7 @@ for dt in (torch.float16,):
         same = all(torch.equal(out[0], out[i]) for i in range(rows))
         print(rows, "rows identical within batch:", same, " vs rows=1 rel:", ((out[0] - outs[1][0]).norm() / outs[1][0].norm()).item(), "finite", bool(torch.isfinite(out).all()))
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from oracle.unet import build_unet
 torch.set_num_threads(32)
 u = build_unet(0)

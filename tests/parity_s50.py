@@ -16,8 +16,8 @@ script; they run concurrently on disjoint thread budgets while the GPU runs fini
 default profiles/_cache/, git-ignored but shipped to the GPU box) so that a later call -- e.g. after a kernel change -- only redoes the
 GPU side.
 
-    python tools/parity_s50.py --out gpurun_out/r03_parity_S50.json            # on the GPU box (through gpurun)
-    python tools/parity_s50.py --S 4 --L 16 --pairs 1 --subjects ref_fp16      # CPU-only smoke of the harness
+    python tests/parity_s50.py --out gpurun_out/r03_parity_S50.json            # on the GPU box (through gpurun)
+    python tests/parity_s50.py --S 4 --L 16 --pairs 1 --subjects ref_fp16      # CPU-only smoke of the harness
 """
 import argparse
 import json
