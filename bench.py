@@ -101,8 +101,8 @@ def cpu_baseline(S_cpu=5):
     etainv + ptp, L = 64, S = 5 of the 50 steps end to end (30 UNet sample-forwards in the reference's call pattern), one warm-up UNet
     forward, linear extrapolation to 50 steps (the per-step cost is constant), images/s = 1 / that.  Threads = the host's physical cores
     (not its hardware threads: 256 SMT threads oversubscribe PyTorch-CPU's small ops, measured 66 s per sample-forward), capped by what this
-    process may run on and by ETAINV_CPU_THREADS.  A host where one sample-forward takes more than 2.5 s gets S = 2 so that the default bench
-    run stays within minutes; the JSON says which S was timed."""
+    process may run on and by ETAINV_CPU_THREADS.  S = 5 as BASELINE.md says (30 sample-forwards: 60-90 s on the GPU box's host); only a host
+    where one sample-forward takes more than 8 s gets S = 2 so that the default bench run stays within minutes; the JSON says which S was timed."""
     from oracle.unet import build_unet
     from oracle import loop as oloop, ptp as optp
     host = host_cpu_info()
@@ -130,7 +130,7 @@ def cpu_baseline(S_cpu=5):
         torch.set_num_threads(cores)
         t_fwd = tried[cores]
         host["one_sample_forward_s_by_threads"] = {str(k): v for k, v in tried.items()}
-        if t_fwd > 2.5:                                                # slow host: keep the sample bounded
+        if t_fwd > 8.0:                                                # very slow host (30 sample-forwards would take > 4 min): keep the sample bounded
             S_cpu = 2
         noise = oloop.noise_table(S_cpu, 10, L, seed=0)
         t0 = time.time()
@@ -276,8 +276,9 @@ def main():
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # tests only: launcher / rank protocol over gloo, no engine, no GPU
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
-    if a.all_rows:
+    if a.all_rows:                                 # the reference's backward row count AND every row through every layer (no shared prefix)
         os.environ["ETAINV_NO_DEAD_ROW_SKIP"] = "1"
+        os.environ["ETAINV_NO_PREFIX_SHARE"] = "1"
     if a.batch is None:
         a.batch = int(os.environ.get("ETAINV_BENCH_BATCH", cfg["batch"])) if a.config == 3 else cfg["batch"]
     if a.dtype is None:
@@ -403,6 +404,9 @@ def main():
         break
     images = B * world * a.steps
     value = images / dt
+    # MFMA FLOPs the kernels EXECUTED per image (implicit GEMMs + both attentions of the profiled step: the launchers record 2 M N K / 4 B h N^2 d
+    # of every launch), i.e. after dead rows, early exits and the shared context-independent prefix -- not a row count times a constant
+    exec_tflop_per_image = (ig_flop + sa_flop + ca_flop) / B / 1e12
     if rank == 0:
         achieved = ig_flop / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
         line = {
@@ -418,8 +422,12 @@ def main():
                                       "3 rows [u_t, c_s, c_t] while eta(t) == 0 (the source row is replayed and its guided noise only picks a noise sample that is multiplied by "
                                       "eta = 0), the cond source row leaving the UNet after transformer block 12 / 9 once no cross replacement / no self-replace reads it; same edited "
                                       "latents (tests/test_e2e_gpu.py, profiles/r03_parity_S50.json); `--all-rows` runs 5 S rows per image",
-                       "tflop_per_image": FWD_PER_IMAGE * F_UNET_TFLOP, "sharding": f"batch-shard x{world}, final all_gather of latents"},
-            "end_to_end_mfma_frac": value / world * FWD_PER_IMAGE * F_UNET_TFLOP / MFMA_PEAK_TFLOPS,
+                       "tflop_per_image": exec_tflop_per_image,
+                       "tflop_per_image_note": "executed MFMA FLOPs (sum over the launches of one step, after row skipping, early exits and prefix sharing); "
+                                               f"row count x {F_UNET_TFLOP} TFLOP would give {FWD_PER_IMAGE * F_UNET_TFLOP:.1f}, the reference's call pattern "
+                                               f"{6 * S_STEPS * F_UNET_TFLOP:.1f}",
+                       "sharding": f"batch-shard x{world}, final all_gather of latents"},
+            "end_to_end_mfma_frac": value / world * exec_tflop_per_image / MFMA_PEAK_TFLOPS,
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv3x3 / conv1x1 / linear)", "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "note": "achieved = GEMM FLOPs only over the kernel's whole duration; its epilogues also carry bias / time row / residual / GEGLU and, "

@@ -457,13 +457,18 @@ struct Fwd {
   }
   // Context-independent prefix (see unet_body): a tensor computed for the first `half` batch rows is copied to rows half .. 2 half - 1, together
   // with the GroupNorm partials its producer left (row blocks are batch-row major: the first half is a prefix of the buffer)
-  int dup_rows(void* buf, int have, int n, size_t elems_per_row) {   // rows [0, n) -> rows [have, have + n)
+  int dup_rows(void* buf, int have, int n, int hw, int c) {   // rows [0, n) -> rows [have, have + n); a batch row holds hw pixels of c channels
+    const size_t elems_per_row = (size_t)hw * c;
     const size_t off = (size_t)have * elems_per_row * e->esz, bytes = (size_t)n * elems_per_row * e->esz;
     ETAINV_HIP(hipMemcpyAsync(reinterpret_cast<char*>(buf) + off, buf, bytes, hipMemcpyDeviceToDevice, s));
     const int idx = part_of(buf);
     if (idx >= 0 && part_wm[idx] > 0) {
-      const size_t per_row = elems_per_row / part_wm[idx] * 2 * sizeof(float);   // [rows * hw / wm][2][C]: elems_per_row = hw * C
-      ETAINV_HIP(hipMemcpyAsync(reinterpret_cast<char*>(e->gn_part[idx]) + per_row * have, e->gn_part[idx], per_row * n, hipMemcpyDeviceToDevice, s));
+      if (hw % part_wm[idx] == 0) {   // [rows * hw / wm][2][C]: a batch row owns hw / wm whole row blocks
+        const size_t per_row = (size_t)(hw / part_wm[idx]) * 2 * c * sizeof(float);
+        ETAINV_HIP(hipMemcpyAsync(reinterpret_cast<char*>(e->gn_part[idx]) + per_row * have, e->gn_part[idx], per_row * n, hipMemcpyDeviceToDevice, s));
+      } else {
+        part_wm[idx] = 0;             // row blocks straddle batch rows (small L): no per-row slice to copy -- the consumer runs the statistics pass
+      }
     }
     return 0;
   }
@@ -873,7 +878,7 @@ static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const in
         if (f.resblock(e->res[ri++], h, nullptr, hc, 0, side, r_out)) return 1;
         const bool first = i == 0 && j == 0;
         if (first && share) {   // skip[0] (a skip connection of the up path) and the block input (proj_out's residual) are needed for all rows
-          if (f.dup_rows(e->skip[0], pre_rows, dup_n, (size_t)L * L * etainv_engine::kCh0) || f.dup_rows(r_out, pre_rows, dup_n, (size_t)L * L * ch[0])) return 1;
+          if (f.dup_rows(e->skip[0], pre_rows, dup_n, L * L, etainv_engine::kCh0) || f.dup_rows(r_out, pre_rows, dup_n, L * L, ch[0])) return 1;
         }
         f.rows = n_rows;
         if (f.transformer(e->tb[ti++], r_out, side, e->skip[si], first && share ? pre_rows : 0)) return 1;

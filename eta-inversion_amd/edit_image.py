@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Single-image edit on the MI355X engine; command line of the reference's edit_image.py:133-149 (same flags, same
 default prompt-to-prompt config, same outputs `<output>` + `<output stem>_inv<suffix>`, `Saved result to` / `Took` lines).
-Without `ETAINV_SD_PATH` the UNet has synthetic weights and the VAE / text encoder are stand-ins (plumbing run)."""
+The UNet, the VAE, the CLIP text encoder and the BPE tokenizer all run natively; without `ETAINV_SD_PATH` (a local diffusers snapshot) they carry
+seeded synthetic weights and a word-level tokenizer (plumbing run: no checkpoint exists offline).  `--prec` absent = fp32 like the reference."""
 import argparse
 import time
 from pathlib import Path
@@ -79,7 +80,7 @@ def parse_args():
     p.add_argument("--steps", type=int, help="How many diffusion steps to use.")
     p.add_argument("--guidance_scale_bwd", type=int, help="Classifier free guidance scale to use for backward diffusion (denoising).")
     p.add_argument("--guidance_scale_fwd", type=int, help="Classifier free guidance scale to use for forward diffusion (inversion).")
-    p.add_argument("--prec", choices=["fp16", "fp32", "bf16"], help="Precision for diffusion.")
+    p.add_argument("--prec", choices=["fp16", "fp32", "bf16"], help="Precision for diffusion (default: fp32, like the reference; fp16 / bf16 = MFMA throughput modes).")
     return vars(p.parse_args())
 
 

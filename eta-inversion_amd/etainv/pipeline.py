@@ -17,6 +17,7 @@ import torch
 
 from . import _capi
 from .engine import AttnControl
+from .flops import exit_share
 
 NUM_TRAIN = 1000
 
@@ -42,9 +43,12 @@ def eta_table(eta=(0.0, 0.4)) -> np.ndarray:
     return np.clip(etas, 0, None)
 
 
+def _env_on(name):
+    """A/B switches: set and not "" / "0" """
+    return os.environ.get(name, "0") not in ("", "0")
+
+
 class EtaLoop:
-    SRC_EXIT_SHARE_12 = 0.716   # ... and in front of the exit after block 12 (the last (L/2)^2-token self-attention: 287.7 GMAC)
-    SRC_EXIT_SHARE = 0.509      # share of a UNet sample-forward's FLOPs in front of the exit after transformer block 9 (204.3 of 401.6 GMAC: the layer walk of SURVEY App. A / G)
 
     def __init__(self, engine, S=50, guidance_scale_bwd=7.5, guidance_scale_fwd=1.0, eta=(0.0, 0.4), noise_sample_count=10,
                  use_mask=True, mask_thres=0.2, skip_uncond_fwd=True, steps_offset=0, mask_eta="fwd_mean", mask_pow=None, target_dirinv=None,
@@ -75,12 +79,15 @@ class EtaLoop:
         # 2 B rows [u_t, c_t] without an attention coupling (simple editor); MasaCtrl couples u_t to u_s and keeps all four.  The source row then is
         # x_prev_src itself instead of x + (x_prev_src - x): at most one rounding apart (SURVEY E-11).  Like skip_uncond_fwd an exact identity of the
         # reference's arithmetic, not an approximation; skip_dead_source_rows=False runs the reference's row count.
-        self.skip_dead_source_rows = skip_dead_source_rows and target_dirinv is None and not os.environ.get("ETAINV_NO_DEAD_ROW_SKIP")   # (env: A/B switch)
+        self.skip_dead_source_rows = skip_dead_source_rows and target_dirinv is None and not _env_on("ETAINV_NO_DEAD_ROW_SKIP")   # (env: A/B switch)
         # ... and once nothing is injected from the source (no cross replacement, self-replace over: steps >= 30 of 50 with the PIE settings) the cond source
         # row of such a step leaves the network after the last stored (L/4)^2 cross layer (transformer block 9; etainv_attn_ctrl.src_exit_block): its
         # noise prediction is unused.  ETAINV_NO_SRC_EXIT=1: A/B switch.
-        self.src_exit = self.skip_dead_source_rows and not os.environ.get("ETAINV_NO_SRC_EXIT")
-        self.src_exit_9_only = bool(os.environ.get("ETAINV_SRC_EXIT_9_ONLY"))   # A/B: no exit while the self-replace runs
+        self.src_exit = self.skip_dead_source_rows and not _env_on("ETAINV_NO_SRC_EXIT")
+        self.src_exit_9_only = _env_on("ETAINV_SRC_EXIT_9_ONLY")   # A/B: no exit while the self-replace runs
+        # share of a sample-forward's FLOPs a row has run when it leaves after transformer block 9 / 12 (layer walk at THIS latent size:
+        # 0.509 / 0.716 at L = 64, 0.492 / 0.677 at L = 96 where the N^2 self-attention terms weigh more)
+        self.SRC_EXIT_SHARE, self.SRC_EXIT_SHARE_12 = exit_share(self.L, 9), exit_share(self.L, 12)
         self.rows_executed = 0                                   # UNet sample-forwards issued by invert / sample since construction (bench accounting)
         self.lib = engine.lib
 
@@ -223,6 +230,7 @@ class EtaLoop:
                         ctrl.c.first_row, ctrl.c.src_exit_block = B, 12 if self_on else 9
                         e.unet(torch.cat([x[B:], x[B:], x[:B]]), t, ctx3x, ctrl, out=eps3x)
                         eu, ec = eps3x[:B], eps3x[B:2 * B]
+                        rows_out, layout = eps3x[:2 * B], "u_t,c_t"                    # (the exited c_s rows have no output)
                         self.rows_executed += 2 * B + B * (self.SRC_EXIT_SHARE_12 if self_on else self.SRC_EXIT_SHARE)   # (share of the UNet's FLOPs the exited rows ran)
                     elif ptp is not None:
                         if ctx3 is None:
@@ -231,6 +239,7 @@ class EtaLoop:
                         ctrl.c.first_row = B
                         e.unet(torch.cat([x[B:], x[:B]]), t, ctx3, ctrl, out=eps3)
                         eu, ec = eps3[:B], eps3[2 * B:]
+                        rows_out, layout = eps3, "u_t,c_s,c_t"
                         self.rows_executed += 3 * B
                     else:
                         if ctx3 is None:
@@ -238,6 +247,7 @@ class EtaLoop:
                             eps3 = torch.empty(2 * B, 4, L, L, dtype=torch.float32, device=dev)
                         e.unet(x[B:], t, ctx3, None, out=eps3)
                         eu, ec = eps3[:B], eps3[B:]
+                        rows_out, layout = eps3, "u_t,c_t"
                         self.rows_executed += 2 * B
                     n_t = B * 4 * L * L
                     _capi.check(self.lib.etainv_cfg_combine(_capi.ptr(eu), _capi.ptr(ec), self.g_bwd, _capi.ptr(eps_t), n_t, _capi.F32, st))
@@ -249,7 +259,8 @@ class EtaLoop:
                     if ptp is not None and ptp.blend_alpha is not None and (i + 1) > int(0.2 * S):
                         e.local_blend(x, B, ptp.blend_alpha, 0.3)
                     if trace is not None:
-                        trace.append({"t": t, "latent": x.clone(), "best": best.clone(), "eps_all": None})
+                        # the rows this step executed, with their layout (B rows per name); "eps_all" (the 4 B-row layout) does not exist here
+                        trace.append({"t": t, "latent": x.clone(), "best": best.clone(), "eps_all": None, "eps_rows": rows_out.clone(), "layout": layout})
                     continue
                 e.unet(x, t, ctx, ctrl, out=eps_all)
                 self.rows_executed += 4 * B
@@ -267,7 +278,8 @@ class EtaLoop:
                 if ptp is not None and ptp.blend_alpha is not None and (i + 1) > int(0.2 * S):
                     e.local_blend(x, B, ptp.blend_alpha, 0.3)                       # LocalBlend, reference ptp.py:31-47
                 if trace is not None:
-                    trace.append({"t": t, "latent": x.clone(), "best": best.clone(), "eps_all": eps_all.clone()})
+                    trace.append({"t": t, "latent": x.clone(), "best": best.clone(), "eps_all": eps_all.clone(), "eps_rows": eps_all.clone(),
+                                  "layout": "u_s,u_t,c_s,c_t"})
         return x
 
 

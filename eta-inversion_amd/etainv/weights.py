@@ -9,10 +9,29 @@ import torch
 _RES_OUT = ("conv2.weight", ".to_out.", ".ff.net.2.", ".proj_out.")
 
 
+_memo = None          # process-level memo of the synthetic tensors (3.4 GB of host memory for the UNet): off unless asked for
+
+
+def memoize_synthetic(on: bool = True):
+    """Keep every synthetic tensor generated from now on in host memory, so that a process which builds several engines (the test suite,
+    A/B benchmarks) pays the 860 M single-threaded `randn` draws once.  Callers must not modify the returned tensors."""
+    global _memo
+    _memo = {} if on else None
+
+
 def synthetic_tensor(name: str, shape, seed: int = 0) -> torch.Tensor:
     """Synthetic value of one parameter, a pure function of (name, shape, seed):
     norm scales 1 + 0.1 N(0,1); biases 0.05 N(0,1); matrices / kernels N(0,1)/sqrt(fan_in), halved on the
     residual-branch output layers so the random network stays well inside fp16 range."""
+    if _memo is not None:
+        key = (name, tuple(int(s) for s in shape), seed)
+        if key not in _memo:
+            _memo[key] = _synthetic_tensor(name, shape, seed)
+        return _memo[key]
+    return _synthetic_tensor(name, shape, seed)
+
+
+def _synthetic_tensor(name, shape, seed):
     g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + 1000003 * seed) & 0x7FFFFFFF)
     shape = tuple(int(s) for s in shape)
     if len(shape) == 1:

@@ -111,6 +111,10 @@ def main(argv=None):
                 done += 1
         else:
             tc = time.time()
+        # bound the encodes in flight (a slow disk must not let uint8 images pile up in host memory for the whole sweep) and surface a failed save
+        # now, not after all the GPU work: everything but the last two batches' worth is waited for
+        while len(saves) > 2 * a.batch:
+            saves.pop(0).result()
         t_wait_load += tb - ta
         t_edit += tc - tb
         t_post += time.time() - tc

@@ -88,14 +88,13 @@ class StablePostProc:
 
 
 def load_diffusion_model(model="CompVis/stable-diffusion-v1-4", device="cuda", preproc_args=None, variant=None, **kwargs):
-    """reference modules/models/__init__.py:100-138.  Precision (`variant`, the reference's `--prec`): "fp32" runs the engine with fp32 operands
-    on the f32-input matrix instruction (csrc/f32path.hip; the reference's default precision, about 1/16 of the 16-bit rate -- the parity
-    mode in which the edited latents meet rtol 1e-3 / atol 1e-4 against the fp32 reference path); "fp16" / "bf16" run 16-bit MFMA operands with
-    fp32 accumulation (latents, contexts, scheduler state and the attention softmax stay fp32).  The reference's `variant=None` means fp32
-    there; here None selects fp16 -- the throughput mode -- and SAYS so."""
+    """reference modules/models/__init__.py:100-138.  Precision (`variant`, the reference's `--prec`): None / "fp32" -- the reference's default
+    (`edit_image.py:147` without `--prec`, `modules/models/__init__.py:104-138`) -- runs the engine with fp32 operands on the f32-input matrix
+    instruction (csrc/f32path.hip; about 1/16 of the 16-bit rate: the parity mode in which the edited latents meet rtol 1e-3 / atol 1e-4 against
+    the fp32 reference path); "fp16" / "bf16" run 16-bit MFMA operands with fp32 accumulation (latents, contexts, scheduler state and the attention
+    softmax stay fp32) -- the throughput modes; eval.py and bench.py pass their precision explicitly."""
     if variant is None:
-        variant = "fp16"
-        print("precision: fp16 MFMA operands with fp32 accumulation (pass variant='fp32' / --prec fp32 for the reference's default precision)")
+        variant = "fp32"
     print(f"Loading model {model} ({variant}) ...")
     if model not in ("sd14", "sd15", "CompVis/stable-diffusion-v1-4", "runwayml/stable-diffusion-v1-5"):
         raise Exception(model)

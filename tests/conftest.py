@@ -16,6 +16,10 @@ def pytest_configure(config):
     import torch
     # the CPU oracle's small PyTorch ops crawl when oversubscribed (256 hardware threads on the GPU box)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
+    if torch.cuda.is_available():
+        # every Engine() of the GPU suite loads the same seeded synthetic weights: draw them once per session (3.4 GB of host memory)
+        from etainv.weights import memoize_synthetic
+        memoize_synthetic(True)
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long CPU oracle replay")
 

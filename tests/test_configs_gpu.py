@@ -23,38 +23,52 @@ def relerr(a, b):
 L96 = 96
 
 
-@pytest.fixture(scope="module")
-def oracle_unet():
-    from oracle.unet import build_unet
-    return build_unet(0)
+from tests.oracle_cache import oracle_leg, oracle_unet, lowprec_unet  # noqa: E402
+
+S5, ETA5 = 4, (0.2, 0.7)
 
 
-def test_masactrl_loop_L96_vs_oracle(oracle_unet):
+def _cfg5_inputs():
     from oracle import loop as oloop
-    from oracle.lowprec import LowPrecisionUNet
-    from oracle.unet import build_unet
-    from etainv.engine import Engine
-    from etainv.pipeline import EtaLoop
-    S, L, eta = 4, L96, (0.2, 0.7)
     src = json.load(open(__file__.rsplit("/", 1)[0] + "/golden/prompt_pairs.json"))[0][0]
     g = torch.Generator().manual_seed(96)
-    z0 = 0.8 * torch.randn(1, 4, L, L, generator=g)
+    z0 = 0.8 * torch.randn(1, 4, L96, L96, generator=g)
     ctx_s, ctx_t = torch.randn(2, 77, 768, generator=g), torch.randn(2, 77, 768, generator=g)
     ctx_t[0] = ctx_s[0]
-    noise = oloop.noise_table(S, 10, L, seed=0)
+    return src, z0, ctx_s, ctx_t, oloop.noise_table(S5, 10, L96, seed=0)
+
+
+@oracle_leg()
+def leg_masactrl_loop_L96():
+    """etainv + masactrl at L = 96, S = 4, one pair: the fp32 oracle free-running with its trace, and the reference-precision floor
+    (fp16 execution of the oracle emulated, teacher-forced backward pass on the fp32 oracle's inputs)"""
+    from oracle import loop as oloop
+    src, z0, ctx_s, ctx_t, noise = _cfg5_inputs()
+    S, L, eta = S5, L96, ETA5
     with torch.no_grad():
-        o = oloop.EtaInversionOracle(oracle_unet, S=S, eta=eta, L=L, use_mask=True)
+        o = oloop.EtaInversionOracle(oracle_unet(), S=S, eta=eta, L=L, use_mask=True)
         inv_o = o.invert(z0, ctx_s, src)
         trace_o = []
         ref = o.sample(inv_o, ctx_s, ctx_t, noise, edit_word_idx=(1, 1), masactrl=oloop.MasaCtrl(start_step=1, start_layer=10), trace=trace_o)
-        # reference-precision floor, teacher-forced backward pass (fp16 execution of the oracle on the fp32 oracle's inputs)
-        low = LowPrecisionUNet(build_unet(0), torch.float16)
         zT = inv_o["latents"][-1]
         teacher_o = [torch.cat([zT, zT])] + [t["latent"] for t in trace_o[:-1]]
-        ol = oloop.EtaInversionOracle(low, S=S, eta=eta, L=L, use_mask=True)
+        ol = oloop.EtaInversionOracle(lowprec_unet(torch.float16), S=S, eta=eta, L=L, use_mask=True)
         trace_l = []
         ol.sample(inv_o, ctx_s, ctx_t, noise, edit_word_idx=(1, 1), masactrl=oloop.MasaCtrl(start_step=1, start_layer=10), trace=trace_l, teacher=teacher_o)
     floor = [relerr(trace_l[i]["latent"][1], trace_o[i]["latent"][1]) for i in range(S)]
+    return {"inv_latents": torch.cat(inv_o["latents"]), "maps_mean": torch.cat(inv_o["attn_maps_mean"]), "ref": ref, "floor": floor,
+            "trace": [{"latent": t["latent"], "best": t["best"]} for t in trace_o]}
+
+
+def test_masactrl_loop_L96_vs_oracle():
+    from etainv.engine import Engine
+    from etainv.pipeline import EtaLoop
+    S, L, eta = S5, L96, ETA5
+    src, z0, ctx_s, ctx_t, noise = _cfg5_inputs()
+    R = leg_masactrl_loop_L96()
+    inv_lat_o, ref, floor, trace_o = R["inv_latents"], R["ref"], R["floor"], R["trace"]
+    zT = inv_lat_o[-1:]
+    teacher_o = [torch.cat([zT, zT])] + [t["latent"] for t in trace_o[:-1]]
     # native: the same pair twice (B = 2): batch invariance for free
     B = 2
     eng = Engine(dtype=torch.float16, max_unet_batch=4 * B, latent_size=L, max_img=B)
@@ -67,14 +81,14 @@ def test_masactrl_loop_L96_vs_oracle(oracle_unet):
     nz = noise.reshape(S, 10, 4, L, L).cuda()
     out = loop.sample(inv, rep(ctx_s), rep(ctx_t), nz, edit_word=torch.tensor([1] * B), masactrl=(1, 10))
     # teacher-forced on the oracle's trajectory
-    inv_tf = {"latents": torch.stack([torch.cat([x] * B) for x in inv_o["latents"]]).cuda(),
-              "maps_mean": torch.stack([torch.cat(inv_o["attn_maps_mean"])] * B).cuda(), "maps_steps": None}
+    inv_tf = {"latents": torch.stack([torch.cat([x[None]] * B) for x in inv_lat_o]).cuda(),
+              "maps_mean": torch.stack([R["maps_mean"]] * B).cuda(), "maps_steps": None}
     teacher = torch.stack([torch.cat([t[:1]] * B + [t[1:]] * B) for t in teacher_o]).cuda()
     trace = []
     loop.sample(inv_tf, rep(ctx_s), rep(ctx_t), nz, edit_word=torch.tensor([1] * B), masactrl=(1, 10), teacher=teacher, trace=trace)
     torch.cuda.synchronize()
     assert torch.equal(out[0], out[1]) and torch.equal(out[2], out[3]), "batch position changes the result"
-    e_inv = relerr(inv["latents"][:, 0].cpu(), torch.cat(inv_o["latents"]))
+    e_inv = relerr(inv["latents"][:, 0].cpu(), inv_lat_o)
     e_src, e_tgt = relerr(out[0].cpu(), ref[0]), relerr(out[2].cpu(), ref[1])
     print(f"etainv+masactrl L=96 S={S} fp16: free-running inversion trajectory {e_inv:.2e}, latent_inv {e_src:.2e}, edited latent {e_tgt:.2e}")
     fails = []

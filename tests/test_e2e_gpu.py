@@ -11,11 +11,12 @@ pytestmark = pytest.mark.gpu
 S, B = 4, 2
 
 
+from tests.oracle_cache import oracle_leg, oracle_unet  # noqa: E402
+
+
 @pytest.fixture(scope="module")
 def setup():
-    from oracle.unet import build_unet
     from etainv.engine import Engine
-    unet = build_unet(0)
     engines = {}
 
     def get(L, dtype=torch.float16):
@@ -24,7 +25,7 @@ def setup():
             e.load_synthetic(0)
             engines[(L, dtype)] = e
         return engines[(L, dtype)]
-    yield unet, get
+    yield None, get
     for e in engines.values():
         e.close()
 
@@ -55,23 +56,24 @@ CASES = [  # editor, L, dtype, use_mask, tolerance on the edited latent (rel L2)
 ]
 
 
-@pytest.mark.parametrize("editor,L,dtype,use_mask,tol", CASES)
-def test_edit_vs_oracle(setup, editor, L, dtype, use_mask, tol):
-    from oracle import loop as oloop, ptp as optp
-    from etainv.pipeline import EtaLoop, PtpTables, noise_table
-    unet, get_engine = setup
-    eng = get_engine(L, dtype)
+def _edit_setup(editor, L):
     pairs, z0, ctx_src, ctx_tgt = _inputs(L)
     replace = editor == "ptp_replace"
     if replace:
         editor = "ptp"
         pairs = [pairs[0], pairs[0]]     # AttentionReplace needs prompts of equal length (seq_aligner.py:161-163)
     eta = [[0.6, 0], [1, 0.7]] if editor == "ptp" else (0.0, 0.4)
+    return editor, replace, pairs, z0, ctx_src, ctx_tgt, eta, [1, 1]
+
+
+@oracle_leg(cases=sorted({(c[0], c[1], c[3]) for c in CASES}))
+def leg_edit(editor, L, use_mask):
+    """the fp32 oracle, one pair at a time"""
+    from oracle import loop as oloop, ptp as optp
+    editor, replace, pairs, z0, ctx_src, ctx_tgt, eta, edit_word = _edit_setup(editor, L)
     tok = optp.WordTokenizer()
     noise = oloop.noise_table(S, 10, L, seed=0)
-    edit_word = [1, 1]
-
-    # ---------------- oracle, one pair at a time
+    unet = oracle_unet()
     ref_inv, ref_out, ref_maps = [], [], []
     with torch.no_grad():
         for i, (src, tgt) in enumerate(pairs):
@@ -92,6 +94,20 @@ def test_edit_vs_oracle(setup, editor, L, dtype, use_mask, tol):
             ref_out.append(z)
     ref_inv = torch.stack(ref_inv, 1)                     # (S+1, B, 4, L, L)
     ref_out = torch.cat([torch.stack([r[0] for r in ref_out]), torch.stack([r[1] for r in ref_out])])   # [src.., tgt..]
+    return {"inv": ref_inv, "out": ref_out, "maps": torch.stack(ref_maps) if use_mask else None}
+
+
+@pytest.mark.parametrize("editor,L,dtype,use_mask,tol", CASES)
+def test_edit_vs_oracle(setup, editor, L, dtype, use_mask, tol):
+    from oracle import loop as oloop, ptp as optp
+    from etainv.pipeline import EtaLoop, PtpTables, noise_table
+    _, get_engine = setup
+    eng = get_engine(L, dtype)
+    R = leg_edit(editor, L, use_mask)
+    ref_inv, ref_out, ref_maps = R["inv"], R["out"], R["maps"]
+    editor, replace, pairs, z0, ctx_src, ctx_tgt, eta, edit_word = _edit_setup(editor, L)
+    tok = optp.WordTokenizer()
+    noise = oloop.noise_table(S, 10, L, seed=0)
 
     # ---------------- native
     W = max(len(s.split(" ")) for s, _ in pairs)
@@ -125,7 +141,7 @@ def test_edit_vs_oracle(setup, editor, L, dtype, use_mask, tol):
     torch.cuda.synchronize()
 
     e_inv = relerr(inv["latents"].cpu(), ref_inv)
-    e_map = relerr(torch.stack([inv["maps_mean"][i, edit_word[i]] for i in range(B)]).cpu(), torch.stack(ref_maps)[:, 0]) if use_mask else 0.0
+    e_map = relerr(torch.stack([inv["maps_mean"][i, edit_word[i]] for i in range(B)]).cpu(), ref_maps[:, 0]) if use_mask else 0.0
     e_src = relerr(out[:B].cpu(), ref_out[:B])
     e_tgt = relerr(out[B:].cpu(), ref_out[B:])
     print(f"{editor} L={L} {dtype} mask={use_mask} replace={replace}: inversion traj {e_inv:.2e}, word map {e_map:.2e}, latent_inv {e_src:.2e}, latent {e_tgt:.2e}")
@@ -136,7 +152,28 @@ def test_edit_vs_oracle(setup, editor, L, dtype, use_mask, tol):
     assert e_tgt < tol
 
 
-@pytest.mark.parametrize("mode", [dict(mask_eta="fwd", thres=0.2), dict(mask_eta="fwd_mean", thres=None, pow=2.0), dict(mask_eta="gt", thres=0.5)])
+MASK_MODES = [dict(mask_eta="fwd", thres=0.2), dict(mask_eta="fwd_mean", thres=None, pow=2.0), dict(mask_eta="gt", thres=0.5)]
+
+
+@oracle_leg(cases=[(m,) for m in MASK_MODES])
+def leg_mask_modes(mode):
+    from oracle import loop as oloop
+    L = 16
+    pairs, z0, ctx_src, ctx_tgt = _inputs(L)
+    noise = oloop.noise_table(S, 10, L, seed=0)
+    gt = torch.rand(B, L, L, generator=torch.Generator().manual_seed(9))
+    unet = oracle_unet()
+    ref = []
+    with torch.no_grad():
+        for i, (src, tgt) in enumerate(pairs):
+            o = oloop.EtaInversionOracle(unet, S=S, eta=(0.0, 0.4), L=L, use_mask=True, thres=mode.get("thres", 0.2), mask_eta=mode["mask_eta"],
+                                         mask_pow=mode.get("pow"))
+            inv = o.invert(z0[i:i + 1], ctx_src[i], src)
+            ref.append(o.sample(inv, ctx_src[i], ctx_tgt[i], noise, edit_word_idx=(1, 1), gt_mask=gt[i:i + 1]))
+    return {"ref": torch.cat([torch.stack([r[0] for r in ref]), torch.stack([r[1] for r in ref])])}
+
+
+@pytest.mark.parametrize("mode", MASK_MODES)
 def test_mask_modes_vs_oracle(setup, mode):
     """non-default eta-mask sources / shapes end to end (etainv + simple): per-timestep forward maps, soft mask with pow, given mask"""
     from oracle import loop as oloop
@@ -147,14 +184,7 @@ def test_mask_modes_vs_oracle(setup, mode):
     pairs, z0, ctx_src, ctx_tgt = _inputs(L)
     noise = oloop.noise_table(S, 10, L, seed=0)
     gt = torch.rand(B, L, L, generator=torch.Generator().manual_seed(9))
-    ref = []
-    with torch.no_grad():
-        for i, (src, tgt) in enumerate(pairs):
-            o = oloop.EtaInversionOracle(unet, S=S, eta=(0.0, 0.4), L=L, use_mask=True, thres=mode.get("thres", 0.2), mask_eta=mode["mask_eta"],
-                                         mask_pow=mode.get("pow"))
-            inv = o.invert(z0[i:i + 1], ctx_src[i], src)
-            ref.append(o.sample(inv, ctx_src[i], ctx_tgt[i], noise, edit_word_idx=(1, 1), gt_mask=gt[i:i + 1]))
-    ref = torch.cat([torch.stack([r[0] for r in ref]), torch.stack([r[1] for r in ref])])
+    ref = leg_mask_modes(mode)["ref"]
     W = max(len(s.split(" ")) for s, _ in pairs)
     tokens = torch.ones(B, W, dtype=torch.int32)
     for i, (src, _) in enumerate(pairs):
@@ -167,7 +197,30 @@ def test_mask_modes_vs_oracle(setup, mode):
     assert relerr(out[:B].cpu(), ref[:B]) < 1e-6 and relerr(out[B:].cpu(), ref[B:]) < 1.9e-2     # measured 8.5e-3 ... 9.6e-3 (round 3); bound at 2x
 
 
-@pytest.mark.parametrize("mode", ["bwd_source", "bwd_target", "bwd_source_target"])
+BWD_MODES = ["bwd_source", "bwd_target", "bwd_source_target"]
+
+
+@oracle_leg(cases=[(m,) for m in BWD_MODES])
+def leg_bwd_mask(mode):
+    from oracle import loop as oloop, ptp as optp
+    L, eta = 16, (0.3, 0.6)
+    pairs, z0, ctx_src, ctx_tgt = _inputs(L)
+    tok = optp.WordTokenizer()
+    noise = oloop.noise_table(S, 10, L, seed=0)
+    unet = oracle_unet()
+    ref = []
+    with torch.no_grad():
+        for i, (src, tgt) in enumerate(pairs):
+            o = oloop.EtaInversionOracle(unet, S=S, eta=eta, L=L, use_mask=True, thres=0.15, mask_eta=mode)
+            inv = o.invert(z0[i:i + 1], ctx_src[i], src)
+            bw, tw = src.split(" ")[1], tgt.split(" ")[1]
+            controller = optp.make_edit_controller(src, tgt, S, tok, blend_words=((bw,), (tw,)), equilizer_params={"words": (tw,), "values": (2,)},
+                                                   res=L // 4, thres_n=(L // 2) ** 2, **PTP_CFG)
+            ref.append(o.sample(inv, ctx_src[i], ctx_tgt[i], noise, edit_word_idx=(1, 1), controller=controller))
+    return {"ref": torch.cat([torch.stack([r[0] for r in ref]), torch.stack([r[1] for r in ref])])}
+
+
+@pytest.mark.parametrize("mode", BWD_MODES)
 def test_bwd_mask_sources_vs_oracle(setup, mode):
     """eta mask from the backward-pass prompt-to-prompt store (running average over the steps done), etainv + ptp"""
     from oracle import loop as oloop, ptp as optp
@@ -179,16 +232,7 @@ def test_bwd_mask_sources_vs_oracle(setup, mode):
     tok = optp.WordTokenizer()
     noise = oloop.noise_table(S, 10, L, seed=0)
     eta = (0.3, 0.6)
-    ref = []
-    with torch.no_grad():
-        for i, (src, tgt) in enumerate(pairs):
-            o = oloop.EtaInversionOracle(unet, S=S, eta=eta, L=L, use_mask=True, thres=0.15, mask_eta=mode)
-            inv = o.invert(z0[i:i + 1], ctx_src[i], src)
-            bw, tw = src.split(" ")[1], tgt.split(" ")[1]
-            controller = optp.make_edit_controller(src, tgt, S, tok, blend_words=((bw,), (tw,)), equilizer_params={"words": (tw,), "values": (2,)},
-                                                   res=L // 4, thres_n=(L // 2) ** 2, **PTP_CFG)
-            ref.append(o.sample(inv, ctx_src[i], ctx_tgt[i], noise, edit_word_idx=(1, 1), controller=controller))
-    ref = torch.cat([torch.stack([r[0] for r in ref]), torch.stack([r[1] for r in ref])])
+    ref = leg_bwd_mask(mode)["ref"]
     W = max(len(s.split(" ")) for s, _ in pairs)
     tokens = torch.ones(B, W, dtype=torch.int32)
     mp, al, eq, ba, ca = [], [], [], [], []
@@ -210,7 +254,28 @@ def test_bwd_mask_sources_vs_oracle(setup, mode):
     assert relerr(out[:B].cpu(), ref[:B]) < 1e-6 and relerr(out[B:].cpu(), ref[B:]) < 1.9e-2     # measured 8.5e-3 ... 9.6e-3 (round 3); bound at 2x
 
 
-@pytest.mark.parametrize("mask_eta,mask_dirinv", [("fwd_mean", "fwd_mean"), ("fwd_mean", "gt"), ("gt", "fwd")])
+DIRINV = [("fwd_mean", "fwd_mean"), ("fwd_mean", "gt"), ("gt", "fwd")]
+
+
+@oracle_leg(cases=DIRINV)
+def leg_target_dirinv(mask_eta, mask_dirinv):
+    from oracle import loop as oloop
+    L = 16
+    pairs, z0, ctx_src, ctx_tgt = _inputs(L)
+    noise = oloop.noise_table(S, 10, L, seed=0)
+    gt = torch.rand(B, L, L, generator=torch.Generator().manual_seed(19))
+    kw = dict(thres=0.3, mask_eta=mask_eta, target_dirinv=0.6, mask_dirinv=mask_dirinv)
+    unet = oracle_unet()
+    ref = []
+    with torch.no_grad():
+        for i, (src, tgt) in enumerate(pairs):
+            o = oloop.EtaInversionOracle(unet, S=S, eta=(0.0, 0.4), L=L, use_mask=True, **kw)
+            inv = o.invert(z0[i:i + 1], ctx_src[i], src)
+            ref.append(o.sample(inv, ctx_src[i], ctx_tgt[i], noise, edit_word_idx=(1, 1), gt_mask=gt[i:i + 1]))
+    return {"ref": torch.cat([torch.stack([r[0] for r in ref]), torch.stack([r[1] for r in ref])])}
+
+
+@pytest.mark.parametrize("mask_eta,mask_dirinv", DIRINV)
 def test_target_dirinv_vs_oracle(setup, mask_eta, mask_dirinv):
     """target_dirinv with a mask_dirinv (eta_inversion.py:234-256) end to end, etainv + simple; mask_dirinv may name a different map
     source than mask_eta"""
@@ -222,14 +287,7 @@ def test_target_dirinv_vs_oracle(setup, mask_eta, mask_dirinv):
     pairs, z0, ctx_src, ctx_tgt = _inputs(L)
     noise = oloop.noise_table(S, 10, L, seed=0)
     gt = torch.rand(B, L, L, generator=torch.Generator().manual_seed(19))
-    kw = dict(thres=0.3, mask_eta=mask_eta, target_dirinv=0.6, mask_dirinv=mask_dirinv)
-    ref = []
-    with torch.no_grad():
-        for i, (src, tgt) in enumerate(pairs):
-            o = oloop.EtaInversionOracle(unet, S=S, eta=(0.0, 0.4), L=L, use_mask=True, **kw)
-            inv = o.invert(z0[i:i + 1], ctx_src[i], src)
-            ref.append(o.sample(inv, ctx_src[i], ctx_tgt[i], noise, edit_word_idx=(1, 1), gt_mask=gt[i:i + 1]))
-    ref = torch.cat([torch.stack([r[0] for r in ref]), torch.stack([r[1] for r in ref])])
+    ref = leg_target_dirinv(mask_eta, mask_dirinv)["ref"]
     W = max(len(s.split(" ")) for s, _ in pairs)
     tokens = torch.ones(B, W, dtype=torch.int32)
     for i, (src, _) in enumerate(pairs):
@@ -242,6 +300,17 @@ def test_target_dirinv_vs_oracle(setup, mask_eta, mask_dirinv):
     assert relerr(out[:B].cpu(), ref[:B]) < 1e-6 and relerr(out[B:].cpu(), ref[B:]) < 1.9e-2     # measured 8.5e-3 ... 9.6e-3 (round 3); bound at 2x
 
 
+@oracle_leg()
+def leg_forward_guidance_table():
+    from oracle import loop as oloop
+    L = 16
+    pairs, z0, ctx_src, ctx_tgt = _inputs(L)
+    unet = oracle_unet()
+    with torch.no_grad():
+        return {"ref": torch.stack([torch.cat(oloop.EtaInversionOracle(unet, S=S, L=L, use_mask=False, guidance_scale_fwd=(1.0, 3.0))
+                                              .invert(z0[i:i + 1], ctx_src[i], pairs[i][0])["latents"]) for i in range(B)], 1)}
+
+
 def test_forward_guidance_table_vs_oracle(setup):
     """guidance_scale_fwd = (start, end): per-timestep CFG in the inversion pass (eta_inversion.py:108-110,325-326) -- the uncond half is run"""
     from oracle import loop as oloop
@@ -251,9 +320,7 @@ def test_forward_guidance_table_vs_oracle(setup):
     eng = get_engine(L, torch.float16)
     pairs, z0, ctx_src, ctx_tgt = _inputs(L)
     tokens = torch.ones(B, 8, dtype=torch.int32)
-    with torch.no_grad():
-        ref = torch.stack([torch.cat(oloop.EtaInversionOracle(unet, S=S, L=L, use_mask=False, guidance_scale_fwd=(1.0, 3.0)).invert(z0[i:i + 1], ctx_src[i], pairs[i][0])["latents"])
-                           for i in range(B)], 1)
+    ref = leg_forward_guidance_table()["ref"]
     loop = EtaLoop(eng, S=S, use_mask=False, guidance_scale_fwd=(1.0, 3.0))
     assert not loop.skip_uncond_fwd
     inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
@@ -347,7 +414,7 @@ def test_cond_source_rows_exit_early_not_changed(setup):
     dead = [i for i, t in enumerate(loop.t_bwd) if loop.etas[int(t)] == 0.0 and not ptp.cross_active[i]]
     n12 = sum(1 for i in dead if ptp.self_lo <= i < ptp.self_hi)
     n_exit = len(dead) - n12
-    assert (n_exit, n12) == (4, 2) and abs((rows[1] - rows[0]) - B * (n_exit * (1 - EtaLoop.SRC_EXIT_SHARE) + n12 * (1 - EtaLoop.SRC_EXIT_SHARE_12))) < 1e-6
+    assert (n_exit, n12) == (4, 2) and abs((rows[1] - rows[0]) - B * (n_exit * (1 - loop.SRC_EXIT_SHARE) + n12 * (1 - loop.SRC_EXIT_SHARE_12))) < 1e-6
     e_src, e_tgt = relerr(outs[0][:B], outs[1][:B]), relerr(outs[0][B:], outs[1][B:])
     print(f"cond source rows exit after block 9 in {n_exit} steps, after block 12 in {n12}: source row {e_src:.2e}, edited latent {e_tgt:.2e}; UNet row-equivalents {rows[0]:.1f} vs {rows[1]:.1f}")
     assert e_src == 0.0 and e_tgt < 2e-3

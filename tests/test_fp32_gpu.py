@@ -63,26 +63,43 @@ def test_cross_attention_ptp_edit_and_store_f32(capi, n, d):
 
 
 # ------------------------------------------------------------------------------------------------ whole UNet
-@pytest.fixture(scope="module")
-def oracle_unet():
-    from oracle.unet import build_unet
-    return build_unet(0)
+from tests.oracle_cache import oracle_leg, oracle_unet  # noqa: E402
+
+_u64 = []
+
+
+def oracle_unet_fp64():
+    if not _u64:
+        import copy
+        _u64.append(copy.deepcopy(oracle_unet()).double())
+    return _u64[0]
 
 
 def relerr(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm()).item()
 
 
+def _unet_inputs(L, rows):
+    g = torch.Generator().manual_seed(5)
+    return torch.randn(rows, 4, L, L, generator=g), torch.randn(rows, 77, 768, generator=g)
+
+
+@oracle_leg(cases=[(16, 4, torch.float32), (64, 2, torch.float32), (16, 4, torch.float64)])
+def leg_unet(L, rows, dtype):
+    """one UNet call of the fp32 oracle (or of its float64 copy: the arithmetic truth of test_fp32_noise_floor_against_fp64)"""
+    x, c = _unet_inputs(L, rows)
+    u = oracle_unet() if dtype == torch.float32 else oracle_unet_fp64()
+    return {"out": u(x.to(dtype), 481, encoder_hidden_states=c.to(dtype))["sample"]}
+
+
 @pytest.mark.parametrize("L,rows", [(16, 4), (64, 2)])
-def test_unet_f32_vs_oracle(oracle_unet, L, rows):
+def test_unet_f32_vs_oracle(L, rows):
     from etainv.engine import Engine
     e = Engine(dtype=F32, max_unet_batch=rows, latent_size=L, max_img=1)
     e.load_synthetic(0)
-    g = torch.Generator().manual_seed(5)
-    x, c = torch.randn(rows, 4, L, L, generator=g), torch.randn(rows, 77, 768, generator=g)
+    x, c = _unet_inputs(L, rows)
     out = e.unet(x.cuda(), 481, c.cuda()).cpu()
-    with torch.no_grad():
-        ref = oracle_unet(x, 481, encoder_hidden_states=c)["sample"]
+    ref = leg_unet(L, rows, torch.float32)["out"]
     err = relerr(out, ref)
     print(f"fp32 UNet L={L} rows={rows}: rel L2 {err:.2e}, max abs {float((out - ref).abs().max()):.2e} (|ref| max {float(ref.abs().max()):.2f})")
     e.close()
@@ -94,22 +111,32 @@ def test_unet_f32_vs_oracle(oracle_unet, L, rows):
 PTP_CFG = dict(is_replace_controller=False, cross_replace_steps={"default_": .4}, self_replace_steps=.6)
 
 
-def _run_pair(oracle_unet, editor, L, S, eta, native=True, dtype=torch.float32):
-    from oracle import loop as oloop, ptp as optp
-    from etainv.engine import Engine
-    from etainv.pipeline import EtaLoop, PtpTables
+def _pair_inputs(L, S):
+    from oracle import loop as oloop
     pairs = json.load(open(__file__.rsplit("/", 1)[0] + "/golden/prompt_pairs.json"))
     src, tgt = pairs[0]
     g = torch.Generator().manual_seed(321)
     z0 = 0.8 * torch.randn(1, 4, L, L, generator=g)
     ctx_s, ctx_t = torch.randn(2, 77, 768, generator=g), torch.randn(2, 77, 768, generator=g)
     ctx_t[0] = ctx_s[0]
-    noise = oloop.noise_table(S, 10, L, seed=0)
+    return src, tgt, z0, ctx_s, ctx_t, oloop.noise_table(S, 10, L, seed=0)
+
+
+ETA_F32 = (0.2, 0.7)
+LOOP_CASES = [("ptp", 16, 6), ("masactrl", 16, 6), ("simple", 16, 6), ("ptp", 64, 3)]
+
+
+@oracle_leg(cases=[(*c, torch.float32) for c in LOOP_CASES] + [("ptp", 16, 6, torch.float64)])
+def leg_pair(editor, L, S, dtype):
+    """free-running etainv + editor of the oracle on one pair (dtype float64: the arithmetic truth)"""
+    from oracle import loop as oloop, ptp as optp
+    src, tgt, z0, ctx_s, ctx_t, noise = _pair_inputs(L, S)
     z0_o, ctx_s_o, ctx_t_o = z0.to(dtype), ctx_s.to(dtype), ctx_t.to(dtype)
     tok = optp.WordTokenizer()
     bw, tw = src.split(" ")[1], tgt.split(" ")[1]
+    unet = oracle_unet() if dtype == torch.float32 else oracle_unet_fp64()
     with torch.no_grad():
-        o = oloop.EtaInversionOracle(oracle_unet, S=S, eta=eta, L=L, use_mask=True)
+        o = oloop.EtaInversionOracle(unet, S=S, eta=ETA_F32, L=L, use_mask=True)
         inv_o = o.invert(z0_o, ctx_s_o, src)
         controller = masa_o = None
         if editor == "ptp":
@@ -118,11 +145,21 @@ def _run_pair(oracle_unet, editor, L, S, eta, native=True, dtype=torch.float32):
         elif editor == "masactrl":
             masa_o = oloop.MasaCtrl(start_step=1, start_layer=10)
         ref = o.sample(inv_o, ctx_s_o, ctx_t_o, noise, edit_word_idx=(1, 1), controller=controller, masactrl=masa_o)
-    if not native:
-        return None, torch.cat(inv_o["latents"]), None, ref
+    return {"inv": torch.cat(inv_o["latents"]), "out": ref}
+
+
+def _run_pair(editor, L, S):
+    """the native fp32-operand loop and the fp32 oracle's cached result: (native trajectory, oracle trajectory, native latents, oracle latents)"""
+    from oracle import ptp as optp
+    from etainv.engine import Engine
+    from etainv.pipeline import EtaLoop, PtpTables
+    src, tgt, z0, ctx_s, ctx_t, noise = _pair_inputs(L, S)
+    tok = optp.WordTokenizer()
+    bw, tw = src.split(" ")[1], tgt.split(" ")[1]
+    R = leg_pair(editor, L, S, torch.float32)
     eng = Engine(dtype=F32, max_unet_batch=4, latent_size=L, max_img=1)
     eng.load_synthetic(0)
-    loop = EtaLoop(eng, S=S, eta=eta, use_mask=True)
+    loop = EtaLoop(eng, S=S, eta=ETA_F32, use_mask=True)
     ws = src.split(" ")
     tokens = torch.tensor([[ws.index(w) + 1 for w in ws]], dtype=torch.int32).cuda()
     inv = loop.invert(z0.cuda(), ctx_s[None].cuda(), tokens)
@@ -136,7 +173,7 @@ def _run_pair(oracle_unet, editor, L, S, eta, native=True, dtype=torch.float32):
     out = loop.sample(inv, ctx_s[None].cuda(), ctx_t[None].cuda(), noise.reshape(S, 10, 4, L, L).cuda(), edit_word=torch.tensor([1]), ptp=ptp, masactrl=masa)
     torch.cuda.synchronize()
     eng.close()
-    return inv["latents"][:, 0].cpu(), torch.cat(inv_o["latents"]), out.cpu(), ref
+    return inv["latents"][:, 0].cpu(), R["inv"], out.cpu(), R["out"]
 
 
 def within_tol(a, b):
@@ -144,14 +181,14 @@ def within_tol(a, b):
     return float(((a.double() - b.double()).abs() <= 1e-4 + 1e-3 * b.double().abs()).double().mean())
 
 
-@pytest.mark.parametrize("editor,L,S", [("ptp", 16, 6), ("masactrl", 16, 6), ("simple", 16, 6), ("ptp", 64, 3)])
-def test_etainv_f32_meets_north_star_tolerance(oracle_unet, editor, L, S):
+@pytest.mark.parametrize("editor,L,S", LOOP_CASES)
+def test_etainv_f32_meets_north_star_tolerance(editor, L, S):
     """free-running etainv + editor in the fp32-operand mode vs the fp32 oracle: north_star's tolerance AS WRITTEN -- torch.allclose(rtol 1e-3, atol 1e-4)
     on the edited latents, the source row and the whole inversion trajectory, and latent L2 <= 1e-3.  Measured on MI355X (round 3, after the two-level
     accumulation of csrc/f32path.hip): edited latent rel L2 7e-6 ... 9e-6, max abs 6e-5 ... 1.6e-4 on values up to 4, inversion trajectory 4e-7 ... 6e-7.
     What is left is fp32 summation-order noise of two fp32 implementations through the 7.5 x CFG amplification (next test: both against float64).
     eta (0.2, 0.7) keeps the best-of-n choice live at every step."""
-    inv_n, inv_r, out, ref = _run_pair(oracle_unet, editor, L, S, (0.2, 0.7))
+    inv_n, inv_r, out, ref = _run_pair(editor, L, S)
     e_inv, e_src, e_tgt = relerr(inv_n, inv_r), relerr(out[0], ref[0]), relerr(out[1], ref[1])
     frac = within_tol(out[1], ref[1])
     print(f"fp32 etainv+{editor} L={L} S={S}: inversion trajectory rel L2 {e_inv:.2e}, latent_inv {e_src:.2e}, edited latent {e_tgt:.2e}, "
@@ -162,21 +199,16 @@ def test_etainv_f32_meets_north_star_tolerance(oracle_unet, editor, L, S):
     assert torch.allclose(out[1], ref[1], rtol=1e-3, atol=1e-4), f"share inside the tolerance {frac:.5f}"   # the edited latent: as written
 
 
-def test_fp32_noise_floor_against_fp64(oracle_unet):
+def test_fp32_noise_floor_against_fp64():
     """What elementwise agreement between two fp32 executions of this graph CAN be: the oracle run in float64 is the arithmetic truth; the fp32
     oracle (PyTorch-CPU kernels) and the fp32-operand engine (k-ordered fmaf chains of the f32 MFMA) are two fp32 implementations of it.  The
     engine's error against the truth must be of the oracle's order (<= 3 x: the matrix instruction accumulates K sequentially, blocked CPU kernels
     reduce in a tree -- which is why f32path.hip closes its accumulation chain every 64 k: 2.2e-6 -> 6.5e-7 per UNet call, the oracle's 8.9e-7),
     per UNet call and for the free-running edited latent."""
-    import copy
     from etainv.engine import Engine
     L, rows = 16, 4
-    u64 = copy.deepcopy(oracle_unet).double()
-    g = torch.Generator().manual_seed(5)
-    x, c = torch.randn(rows, 4, L, L, generator=g), torch.randn(rows, 77, 768, generator=g)
-    with torch.no_grad():
-        truth = u64(x.double(), 481, encoder_hidden_states=c.double())["sample"]
-        ref = oracle_unet(x, 481, encoder_hidden_states=c)["sample"]
+    x, c = _unet_inputs(L, rows)
+    truth, ref = leg_unet(L, rows, torch.float64)["out"], leg_unet(L, rows, torch.float32)["out"]
     e = Engine(dtype=F32, max_unet_batch=rows, latent_size=L, max_img=1)
     e.load_synthetic(0)
     out = e.unet(x.cuda(), 481, c.cuda()).cpu()
@@ -186,8 +218,8 @@ def test_fp32_noise_floor_against_fp64(oracle_unet):
           f"PyTorch-CPU fp32 oracle {e_ora:.2e} max abs {float((ref - truth).abs().max()):.2e}")
     assert e_nat < 2 * e_ora and e_nat < 2e-6                                       # measured 6.5e-7 vs 8.9e-7
     # free-running loop: the fp64 oracle as truth
-    inv_n, inv_r, out_n, ref_l = _run_pair(oracle_unet, "ptp", L, 6, (0.2, 0.7))
-    _, _, _, truth_l = _run_pair(u64, "ptp", L, 6, (0.2, 0.7), native=False, dtype=torch.float64)
+    inv_n, inv_r, out_n, ref_l = _run_pair("ptp", L, 6)
+    truth_l = leg_pair("ptp", L, 6, torch.float64)["out"]
     d_nat, d_ora = float((out_n[1] - truth_l[1]).abs().max()), float((ref_l[1] - truth_l[1]).abs().max())
     print(f"free-running etainv+ptp S=6 vs fp64 truth: edited latent max abs engine {d_nat:.2e} (rel L2 {relerr(out_n[1], truth_l[1]):.2e}, within tol "
           f"{within_tol(out_n[1], truth_l[1]):.5f}); fp32 oracle {d_ora:.2e} (rel L2 {relerr(ref_l[1], truth_l[1]):.2e}, within tol {within_tol(ref_l[1], truth_l[1]):.5f})")
@@ -195,9 +227,10 @@ def test_fp32_noise_floor_against_fp64(oracle_unet):
 
 
 def test_load_diffusion_model_fp32_variant():
-    """`--prec fp32` (the reference's default) builds the fp32-operand engine and the fp32 VAE / text encoder instead of raising"""
+    """no `--prec` / `variant=None` means fp32 like the reference (modules/models/__init__.py:104-138): the fp32-operand engine and the fp32
+    VAE / text encoder"""
     import modules
-    p, (pre, post) = modules.load_diffusion_model("sd15", "cuda", variant="fp32", latent_size=16)
+    p, (pre, post) = modules.load_diffusion_model("sd15", "cuda", variant=None, latent_size=16)
     assert p.engine.dtype == torch.float32
     g = torch.Generator().manual_seed(3)
     img = (torch.rand(1, 3, 128, 128, generator=g) * 2 - 1).cuda()
@@ -208,23 +241,33 @@ def test_load_diffusion_model_fp32_variant():
 
 
 # ------------------------------------------------------------------------------------------------ the third-party networks in fp32
-def test_vae_and_clip_f32_vs_oracle():
-    """`--prec fp32` also runs the VAE and the text encoder on the fp32-operand kernels: 1e-4 against the CPU oracle (fp16: 5e-3)"""
-    from oracle.vae import build_vae
-    from oracle.clip import build_clip
-    from etainv.nets import NativeVAE, NativeCLIPText
-    rel = lambda a, b: ((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm()).item()
-    ref, nat = build_vae(0), NativeVAE(None, F32, 0)
+def _nets_inputs():
     g = torch.Generator().manual_seed(64)
     img, z = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1, torch.randn(2, 4, 8, 8, generator=g)
-    with torch.no_grad():
-        want_e, want_d = ref.encode_mean(img), ref.decode(z)
-    e_enc, e_dec = rel(nat.encode(img.cuda())["latent_dist"].mean, want_e), rel(nat.decode(z.cuda())["sample"], want_d)
-    clip_r, clip_n = build_clip(0), NativeCLIPText(None, F32, 0)
     ids = torch.randint(0, 49408, (2, 77), generator=g)
     ids[:, 0], ids[:, 20:] = 49406, 49407
-    with torch.no_grad():
-        want_c = clip_r(ids)[0]
+    return img, z, ids
+
+
+@oracle_leg()
+def leg_vae_clip():
+    from oracle.vae import build_vae
+    from oracle.clip import build_clip
+    img, z, ids = _nets_inputs()
+    ref = build_vae(0)
+    return {"enc": ref.encode_mean(img), "dec": ref.decode(z), "clip": build_clip(0)(ids)[0]}
+
+
+def test_vae_and_clip_f32_vs_oracle():
+    """`--prec fp32` also runs the VAE and the text encoder on the fp32-operand kernels: 1e-4 against the CPU oracle (fp16: 5e-3)"""
+    from etainv.nets import NativeVAE, NativeCLIPText
+    rel = lambda a, b: ((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm()).item()
+    nat = NativeVAE(None, F32, 0)
+    img, z, ids = _nets_inputs()
+    R = leg_vae_clip()
+    want_e, want_d, want_c = R["enc"], R["dec"], R["clip"]
+    e_enc, e_dec = rel(nat.encode(img.cuda())["latent_dist"].mean, want_e), rel(nat.decode(z.cuda())["sample"], want_d)
+    clip_n = NativeCLIPText(None, F32, 0)
     e_clip = rel(clip_n(ids.cuda())[0], want_c)
     print(f"fp32 nets vs oracle: VAE encode {e_enc:.2e}, decode {e_dec:.2e}, CLIP {e_clip:.2e}")
     assert e_enc < 1e-4 and e_dec < 1e-4 and e_clip < 1e-4

@@ -328,8 +328,12 @@ def test_backward_loop_row_economy_host_logic(monkeypatch):
     assert all(c["edit"] and c["first_row"] == 0 and c["exit"] == 0 and c["n_lat"] == 2 * B for c in calls[:20])
     assert all(not c["edit"] and c["first_row"] == B and c["exit"] == 12 and c["self_on"] and c["n_lat"] == 3 * B for c in calls[20:30])
     assert all(not c["edit"] and c["first_row"] == B and c["exit"] == 9 and not c["self_on"] for c in calls[30:])
-    want = B * (20 * 4 + 10 * (2 + EtaLoop.SRC_EXIT_SHARE_12) + 20 * (2 + EtaLoop.SRC_EXIT_SHARE))
-    assert abs(loop.rows_executed - want) < 1e-9 and abs(50 + want / B - 207.34) < 0.01       # + the S cond rows of the forward pass
+    want = B * (20 * 4 + 10 * (2 + loop.SRC_EXIT_SHARE_12) + 20 * (2 + loop.SRC_EXIT_SHARE))
+    assert abs(loop.rows_executed - want) < 1e-9
+    from etainv.flops import exit_share, unet_macs                                              # the shares follow the latent size (layer walk)
+    assert abs(unet_macs(64) / 1e9 - 401.64) < 0.01 and abs(unet_macs(96) / 1e9 - 1074.06) < 0.01
+    assert abs(50 + 20 * 4 + 10 * (2 + exit_share(64, 12)) + 20 * (2 + exit_share(64, 9)) - 207.34) < 0.01   # per image at L = 64, + the S cond rows of the forward pass
+    assert exit_share(96, 9) < exit_share(64, 9) and (loop.SRC_EXIT_SHARE, loop.SRC_EXIT_SHARE_12) == (exit_share(L, 9), exit_share(L, 12))
     calls, _ = run()                                                                            # no attention coupling (simple editor)
     assert [c["rows"] for c in calls] == [4 * B] * 20 + [2 * B] * 30 and all(c["n_lat"] == B for c in calls[20:])
     calls, _ = run(masactrl=(4, 10))                                                            # MasaCtrl couples u_t to u_s

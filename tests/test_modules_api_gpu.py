@@ -179,7 +179,7 @@ def test_dirinv_plugin_vs_oracle():
     (reference modules/inversion/direct_inversion.py:17-58)."""
     from modules import load_diffusion_model, load_inverter, load_editor, get_inversion_methods
     from oracle import loop as oloop
-    from oracle.unet import build_unet
+    from tests.oracle_cache import oracle_unet      # one fp32 oracle UNet per session
     assert "dirinv" in get_inversion_methods()
     S, L = 4, 16
     pipe, _ = load_diffusion_model("CompVis/stable-diffusion-v1-4", "cuda", variant="fp16", latent_size=L, max_img=1)
@@ -192,7 +192,7 @@ def test_dirinv_plugin_vs_oracle():
     res = ed.edit(z0, src, tgt, inv_cfg=dict(edit_word_idx=(1, 1)))
     ctx_s, ctx_t = inv.create_context(src).cpu(), inv.create_context(tgt).cpu()
     with torch.no_grad():
-        o = oloop.EtaInversionOracle(build_unet(0), S=S, eta=(0.0, 0.0), noise_sample_count=1, use_mask=False, L=L)
+        o = oloop.EtaInversionOracle(oracle_unet(), S=S, eta=(0.0, 0.0), noise_sample_count=1, use_mask=False, L=L)
         oinv = o.invert(z0, ctx_s, src)
         z = o.sample(oinv, ctx_s, ctx_t, oloop.noise_table(S, 1, L, seed=0), edit_word_idx=(1, 1))
     rel = lambda a, b: ((a.float().cpu() - b).norm() / b.norm()).item()
@@ -200,7 +200,7 @@ def test_dirinv_plugin_vs_oracle():
     # DirectInversion.invert honours the per-call guidance_scale_fwd (direct_inversion.py:60-62): CFG 3 in the inversion pass
     inv_res = inv.invert(z0, prompt=src, context=inv.create_context(src), guidance_scale_fwd=3.0)
     with torch.no_grad():
-        o3 = oloop.EtaInversionOracle(build_unet(0), S=S, eta=(0.0, 0.0), noise_sample_count=1, use_mask=False, L=L, guidance_scale_fwd=3.0)
+        o3 = oloop.EtaInversionOracle(oracle_unet(), S=S, eta=(0.0, 0.0), noise_sample_count=1, use_mask=False, L=L, guidance_scale_fwd=3.0)
         ref3 = torch.cat(o3.invert(z0, ctx_s, src)["latents"])
     assert rel(torch.cat(inv_res["latents"]), ref3) < 5e-3
     assert rel(torch.cat(inv_res["latents"]), torch.cat(oinv["latents"])) > 1e-2      # and it really differs from the scale-1 trajectory
@@ -212,7 +212,7 @@ def test_diffinv_plugin_vs_oracle(no_source_backward):
     vs the CPU oracle's restatement of the reference loops (diffusion_inversion.py:388-436, pinned by tests/golden/e2e_diffinv.npz)."""
     from modules import load_diffusion_model, load_inverter, load_editor
     from oracle import loop as oloop
-    from oracle.unet import build_unet
+    from tests.oracle_cache import oracle_unet      # one fp32 oracle UNet per session
     S, L = 4, 16
     pipe, _ = load_diffusion_model("CompVis/stable-diffusion-v1-4", "cuda", variant="fp16", latent_size=L, max_img=1)
     inv = load_inverter(type="diffinv", model=pipe, scheduler="ddim", num_inference_steps=S)
@@ -223,7 +223,7 @@ def test_diffinv_plugin_vs_oracle(no_source_backward):
     res = ed.edit(z0, src, tgt)
     ctx_s, ctx_t = inv.create_context(src).cpu(), inv.create_context(tgt).cpu()
     with torch.no_grad():
-        o = oloop.DiffusionInversionOracle(build_unet(0), S=S)
+        o = oloop.DiffusionInversionOracle(oracle_unet(), S=S)
         z = o.sample(o.invert(z0, ctx_s), [ctx_t] if no_source_backward else [ctx_s, ctx_t])
     rel = lambda a, b: ((a.float().cpu() - b).norm() / b.norm()).item()
     if no_source_backward:
@@ -287,7 +287,7 @@ def test_diffinv_dpm_plugin_vs_oracle():
     """`diffinv --scheduler dpm` + simple editor through the plugin API vs the oracle loop driven by the oracle's DPM steppers"""
     from modules import load_diffusion_model, load_inverter, load_editor
     from oracle import loop as oloop, schedule as sch
-    from oracle.unet import build_unet
+    from tests.oracle_cache import oracle_unet      # one fp32 oracle UNet per session
     S, L = 4, 16
     pipe, _ = load_diffusion_model("CompVis/stable-diffusion-v1-4", "cuda", variant="fp16", latent_size=L, max_img=1)
     inv = load_inverter(type="diffinv", model=pipe, scheduler="dpm", num_inference_steps=S)
@@ -303,7 +303,7 @@ def test_diffinv_dpm_plugin_vs_oracle():
     tf, tb = sch.dpm_timesteps_forward(S), sch.dpm_timesteps_backward(S)
     sf, sb = sch.DpmStepper(ac, tf, 999), sch.DpmStepper(ac, tb, 0)
     with torch.no_grad():
-        o = oloop.DiffusionInversionOracle(build_unet(0), S=S, step_fwd=sf.step, step_bwd=sb.step)
+        o = oloop.DiffusionInversionOracle(oracle_unet(), S=S, step_fwd=sf.step, step_bwd=sb.step)
         o.t_fwd, o.t_bwd = tf, tb
         z = o.sample(o.invert(z0, ctx_s), [ctx_s, ctx_t])
     rel = lambda a, b: ((a.float().cpu() - b.float()).norm() / b.float().norm()).item()

@@ -33,44 +33,43 @@ def maxabs(a, b):
     return float((a.float() - b.float()).abs().max())
 
 
-@pytest.fixture(scope="module")
-def oracle_unet():
-    from oracle.unet import build_unet
-    return build_unet(0)
+from tests.oracle_cache import oracle_leg, oracle_unet, lowprec_unet  # noqa: E402
+
+
+def _rows16_inputs():
+    g = torch.Generator().manual_seed(5)
+    return torch.randn(16, 4, L, L, generator=g), torch.randn(16, 77, 768, generator=g)
 
 
 # ------------------------------------------------------------------------------------------------ whole UNet, bench tile dispatch
-@pytest.fixture(scope="module")
-def lowprec_unets():
-    """the oracle with the reference's 16-bit execution emulated, one per dtype (built on first use; 3.4 GB each)"""
-    from oracle.unet import build_unet
-    from oracle.lowprec import LowPrecisionUNet
-    made = {}
+@oracle_leg()
+def leg_unet_rows16_ref():
+    """fp32 oracle on rows 0 and 15 of the 16-row batch"""
+    x, c = _rows16_inputs()
+    return {"ref": oracle_unet()(x[[0, 15]], 481, encoder_hidden_states=c[[0, 15]])["sample"]}
 
-    def get(dtype):
-        if dtype not in made:
-            made[dtype] = LowPrecisionUNet(build_unet(0), dtype)
-        return made[dtype]
-    return get
+
+@oracle_leg(cases=[(torch.float16,), (torch.bfloat16,)])
+def leg_unet_rows16_low(dtype):
+    """the same rows through the oracle with the reference's 16-bit execution emulated"""
+    x, c = _rows16_inputs()
+    return {"low": lowprec_unet(dtype)(x[[0, 15]], 481, encoder_hidden_states=c[[0, 15]])["sample"]}
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 2.2e-3), (torch.bfloat16, 1.8e-2)])     # measured 1.1e-3 / 9.2e-3
-def test_unet_L64_rows16_vs_oracle(oracle_unet, lowprec_unets, dtype, tol):
+def test_unet_L64_rows16_vs_oracle(dtype, tol):
     """16 DIFFERENT rows through the persistent ring kernels: the first and the last are checked against the CPU oracle, all of them
     through batch invariance (the same samples in reversed row order must give bit-identical rows)."""
     from etainv.engine import Engine
     e = Engine(dtype=dtype, max_unet_batch=16, latent_size=L, max_img=4)
     e.load_synthetic(0)
-    g = torch.Generator().manual_seed(5)
-    x, c = torch.randn(16, 4, L, L, generator=g), torch.randn(16, 77, 768, generator=g)
+    x, c = _rows16_inputs()
     out = e.unet(x.cuda(), 481, c.cuda())
     perm = torch.arange(15, -1, -1)
     out_p = e.unet(x[perm].cuda().contiguous(), 481, c[perm].cuda().contiguous())
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), out_p.cpu()[perm]), "a row's result depends on its position in the batch"
-    with torch.no_grad():
-        ref = oracle_unet(x[[0, 15]], 481, encoder_hidden_states=c[[0, 15]])["sample"]
-        low = lowprec_unets(dtype)(x[[0, 15]], 481, encoder_hidden_states=c[[0, 15]])["sample"]
+    ref, low = leg_unet_rows16_ref()["ref"], leg_unet_rows16_low(dtype)["low"]
     err, floor = relerr(out[[0, 15]].cpu(), ref), relerr(low, ref)
     print(f"UNet L=64 rows=16 {dtype}: rel L2 {err:.2e}, max abs {maxabs(out[[0, 15]].cpu(), ref):.2e} (|ref| max {float(ref.abs().max()):.2f}); "
           f"reference-precision floor (oracle with {dtype} execution emulated vs fp32) {floor:.2e} -> ratio {err / floor:.2f}")
@@ -91,8 +90,8 @@ def _inputs():
     return two, z0, ctx_src, ctx_tgt
 
 
-@pytest.fixture(scope="module")
-def oracle_run(oracle_unet):
+@oracle_leg()
+def leg_oracle_run():
     """The oracle's etainv + ptp on 2 distinct pairs (the native batch holds each twice), with the per-step trace."""
     from oracle import loop as oloop, ptp as optp
     pairs, z0, ctx_src, ctx_tgt = _inputs()
@@ -101,7 +100,7 @@ def oracle_run(oracle_unet):
     runs = []
     with torch.no_grad():
         for i, (src, tgt) in enumerate(pairs):
-            o = oloop.EtaInversionOracle(oracle_unet, S=S, eta=ETA, L=L, use_mask=True)
+            o = oloop.EtaInversionOracle(oracle_unet(), S=S, eta=ETA, L=L, use_mask=True)
             inv = o.invert(z0[i:i + 1], ctx_src[i], src)
             bw, tw = src.split(" ")[1], tgt.split(" ")[1]
             controller = optp.make_edit_controller(src, tgt, S, tok, blend_words=((bw,), (tw,)), equilizer_params={"words": (tw,), "values": (2,)},
@@ -109,16 +108,23 @@ def oracle_run(oracle_unet):
             trace = []
             z = o.sample(inv, ctx_src[i], ctx_tgt[i], noise, edit_word_idx=(1, 1), controller=controller, trace=trace)
             runs.append({"inv": torch.cat(inv["latents"]), "maps": torch.stack(inv["attn_maps_mean"])[:, 0], "trace": trace, "out": z})
-    return pairs, z0, ctx_src, ctx_tgt, noise, runs
+    return {"runs": runs}
 
 
-def floor_run(oracle_run, low_unet):
+def oracle_run():
+    from oracle import loop as oloop
+    return (*_inputs(), oloop.noise_table(S, 10, L, seed=0), leg_oracle_run()["runs"])
+
+
+@oracle_leg(cases=[(torch.float16,), (torch.bfloat16,)])
+def leg_floor_run(dtype):
     """The same two pairs through the oracle loop with the reference's 16-bit UNet execution emulated, TEACHER-FORCED on the fp32 oracle's
     latents (every step on identical inputs, like the native teacher-forced run): per-step errors of the reference's own precision."""
     from oracle import loop as oloop, ptp as optp
-    pairs, z0, ctx_src, ctx_tgt, noise, runs = oracle_run
+    pairs, z0, ctx_src, ctx_tgt, noise, runs = oracle_run()
     tok = optp.WordTokenizer()
     out = []
+    low_unet = lowprec_unet(dtype)
     with torch.no_grad():
         for i, (src, tgt) in enumerate(pairs):
             o = oloop.EtaInversionOracle(low_unet, S=S, eta=ETA, L=L, use_mask=True)
@@ -140,14 +146,14 @@ def floor_run(oracle_run, low_unet):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_etainv_ptp_L64_teacher_forced(oracle_run, lowprec_unets, dtype):
+def test_etainv_ptp_L64_teacher_forced(dtype):
     from oracle import ptp as optp
     from etainv.engine import Engine
     from etainv.pipeline import EtaLoop, PtpTables
-    pairs, z0, ctx_src, ctx_tgt, noise, runs = oracle_run
+    pairs, z0, ctx_src, ctx_tgt, noise, runs = oracle_run()
     bf = dtype == torch.bfloat16
     fails = []                                                        # every bound is checked (and printed) before the test fails
-    floor = floor_run(oracle_run, lowprec_unets(dtype))
+    floor = leg_floor_run(dtype)
     print(f"[{dtype}] reference-precision floor per teacher-forced step: fwd latent {['%.2e' % v for v in floor['fwd']]}, guided eps "
           f"{['%.2e' % v for v in floor['eps']]}, target latent {['%.2e' % v for v in floor['tgt']]}")
 
@@ -263,21 +269,33 @@ def test_etainv_ptp_L64_teacher_forced(oracle_run, lowprec_unets, dtype):
 
 
 # ------------------------------------------------------------------------------------------------ 768^2: N = 9216 self-attention + MasaCtrl
-def test_unet_L96_masactrl_vs_oracle(oracle_unet):
-    from oracle import loop as oloop
-    from etainv import _capi
-    from etainv.engine import Engine, AttnControl
-    L96 = 96
+L96 = 96
+
+
+def _l96_inputs():
     g = torch.Generator().manual_seed(96)
     lat = torch.randn(2, 4, L96, L96, generator=g)                    # [source, target] latents; UNet rows [u_s,u_t,c_s,c_t] read row r % 2
-    ctx = torch.randn(4, 77, 768, generator=g)
-    masa = oloop.MasaCtrl(start_step=0, start_layer=10)
-    oracle_unet.set_ctrl(masa)
+    return lat, torch.randn(4, 77, 768, generator=g)
+
+
+@oracle_leg()
+def leg_unet_L96_masactrl():
+    from oracle import loop as oloop
+    lat, ctx = _l96_inputs()
+    unet = oracle_unet()
+    unet.set_ctrl(oloop.MasaCtrl(start_step=0, start_layer=10))
     try:
         with torch.no_grad():
-            ref = oracle_unet(torch.cat([lat, lat]), 601, encoder_hidden_states=ctx)["sample"]
+            return {"ref": unet(torch.cat([lat, lat]), 601, encoder_hidden_states=ctx)["sample"]}
     finally:
-        oracle_unet.set_ctrl(None)
+        unet.set_ctrl(None)
+
+
+def test_unet_L96_masactrl_vs_oracle():
+    from etainv import _capi
+    from etainv.engine import Engine, AttnControl
+    lat, ctx = _l96_inputs()
+    ref = leg_unet_L96_masactrl()["ref"]
     e = Engine(dtype=torch.float16, max_unet_batch=4, latent_size=L96, max_img=1)
     e.load_synthetic(0)
     out = e.unet(lat.cuda(), 601, ctx.cuda(), AttnControl(mode=_capi.ATTN_MASA, n_img=1, masa_active=True, masa_first_block=10))

@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 def _write_snapshot(root: Path):
     from safetensors.torch import save_file
     from oracle.clip import build_clip
-    from oracle.unet import build_unet
+    from tests.oracle_cache import oracle_unet      # one fp32 oracle UNet per session
     from oracle.vae import build_vae
-    for sub, sd, fname in (("unet", build_unet(0).state_dict(), "diffusion_pytorch_model.fp16.safetensors"),
+    for sub, sd, fname in (("unet", oracle_unet().state_dict(), "diffusion_pytorch_model.fp16.safetensors"),
                            ("text_encoder", build_clip(0).state_dict(), "model.fp16.safetensors")):
         (root / sub).mkdir(parents=True)
         save_file({k: v.half().contiguous() for k, v in sd.items()}, str(root / sub / fname))

@@ -7,10 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def oracle_unet():
-    from oracle.unet import build_unet
-    return build_unet(0)
+from tests.oracle_cache import oracle_leg, oracle_unet  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -34,10 +31,12 @@ def relerr(a, b):
     return ((a.float() - b.float()).norm() / b.float().norm()).item()
 
 
-def test_weight_names_match_oracle(engines, oracle_unet):
+def test_weight_names_match_oracle(engines):
+    from oracle.unet import UNet2DConditionModel
     e = engines(torch.float16, 16)
     specs = dict(e.weight_specs())
-    sd = oracle_unet.state_dict()
+    with torch.device("meta"):                       # names and shapes only (the values are compared below, tensor by tensor)
+        sd = UNet2DConditionModel().state_dict()
     assert set(specs) == set(sd.keys())
     for k, v in sd.items():
         assert tuple(v.shape) == specs[k], k
@@ -47,15 +46,32 @@ def test_weight_names_match_oracle(engines, oracle_unet):
         assert torch.equal(synthetic_tensor(name, specs[name], 0), oracle_syn(name, specs[name], 0))
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
-@pytest.mark.parametrize("L,rows,t", [(16, 2, 500), (32, 4, 981), (16, 4, 0)])
-def test_unet_forward_vs_oracle(engines, oracle_unet, dtype, tol, L, rows, t):
+FWD_CASES = [(16, 2, 500), (32, 4, 981), (16, 4, 0)]
+
+
+def _fwd_inputs(L, rows):
     g = torch.Generator().manual_seed(L * 100 + rows)
-    n_lat = rows // 2
-    latent = torch.randn(n_lat, 4, L, L, generator=g)
-    ctx = torch.randn(rows, 77, 768, generator=g)
-    with torch.no_grad():
-        ref = oracle_unet(torch.cat([latent] * 2), torch.tensor(t), encoder_hidden_states=ctx)["sample"]
+    return torch.randn(rows // 2, 4, L, L, generator=g), torch.randn(rows, 77, 768, generator=g)
+
+
+@oracle_leg(cases=FWD_CASES)
+def leg_unet_forward(L, rows, t):
+    latent, ctx = _fwd_inputs(L, rows)
+    return {"ref": oracle_unet()(torch.cat([latent] * 2), torch.tensor(t), encoder_hidden_states=ctx)["sample"]}
+
+
+@oracle_leg()
+def leg_unet_bench_shape():
+    g = torch.Generator().manual_seed(1)
+    x1, c1 = torch.randn(1, 4, 64, 64, generator=g), torch.randn(1, 77, 768, generator=g)
+    return {"ref": oracle_unet()(x1, 500, encoder_hidden_states=c1)["sample"][0]}
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("L,rows,t", FWD_CASES)
+def test_unet_forward_vs_oracle(engines, dtype, tol, L, rows, t):
+    latent, ctx = _fwd_inputs(L, rows)
+    ref = leg_unet_forward(L, rows, t)["ref"]
     e = engines(dtype, L)
     out = e.unet(latent.cuda(), t, ctx.cuda())
     torch.cuda.synchronize()
@@ -64,7 +80,7 @@ def test_unet_forward_vs_oracle(engines, oracle_unet, dtype, tol, L, rows, t):
     assert err < tol
 
 
-def test_unet_bench_shape_class_vs_oracle(oracle_unet):
+def test_unet_bench_shape_class_vs_oracle():
     """L = 64 with 16 UNet rows: the tile dispatch of the bench configuration (256 x 160 / 256 x 128 persistent ring kernels,
     several tiles per block, two-slot kernels for the fused-upsample convs), which small-L tests never reach.  The same sample in
     every row, so one CPU-oracle forward checks all rows; rows must also agree bit for bit with each other."""
@@ -73,8 +89,7 @@ def test_unet_bench_shape_class_vs_oracle(oracle_unet):
     e.load_synthetic(0)
     g = torch.Generator().manual_seed(1)
     x1, c1 = torch.randn(1, 4, 64, 64, generator=g), torch.randn(1, 77, 768, generator=g)
-    with torch.no_grad():
-        ref = oracle_unet(x1, 500, encoder_hidden_states=c1)["sample"][0]
+    ref = leg_unet_bench_shape()["ref"]
     for rows in (1, 4, 16):
         out = torch.empty(rows, 4, 64, 64, device="cuda")
         e.unet(x1.repeat(rows, 1, 1, 1).cuda().contiguous(), 500, c1.repeat(rows, 1, 1).cuda().contiguous(), None, out=out)
