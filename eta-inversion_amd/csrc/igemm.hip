@@ -1231,6 +1231,10 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   ETAINV_CHECK(!p.ln_stat || (p.ln_s && p.bias && p.taps == 1 && !p.a2), "folded LayerNorm: s / c vectors, plain GEMM");
   ETAINV_CHECK(!p.ln_stat || (!p.residual && !p.rowvec && !p.stat_out), "folded LayerNorm: no residual / row vector / statistics output on the consumer");
   ETAINV_CHECK(!p.ln_stat || (!p.out_f32 && !p.out_nchw), "folded LayerNorm: the consumer stores the compute dtype, row-major (the fp32 / NCHW epilogues do not apply mean / rstd)");
+  if (xs_gemm_applicable(p, dtype)) {   // K = 320 LayerNorm consumers with many rows: stationary activation tile, epilogue under the other wave group's MFMAs
+    ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)p.c1, s, igemm_algo_bytes(p));
+    return launch_xs_gemm(p, dtype, s);
+  }
   // tile choice: big tiles when they still fill the 256 CUs, else 64x64 (GEGLU pairing is per wave tile,
   // so the packing of a GEGLU weight fixes its tile: always 128 wide)
   const int64_t big_tiles = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128);

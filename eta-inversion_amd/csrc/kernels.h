@@ -55,6 +55,11 @@ struct IGemmParams {
 // stat_P (optional): receives the number of partials per row written to p.stat_out (0: none written)
 int launch_igemm(const IGemmParams& p, int dtype, hipStream_t s, int* stat_P = nullptr);
 
+// ---- xsgemm.hip: K = 320 LayerNorm-consumer projections (GEGLU, fused QKV) of the L^2-token blocks on a stationary activation tile with two wave
+// groups in anti-phase; launch_igemm routes to it when xs_gemm_applicable (bit-identical results)
+bool xs_gemm_applicable(const IGemmParams& p, int dtype);
+int launch_xs_gemm(const IGemmParams& p, int dtype, hipStream_t s);
+
 // ---- f32path.hip: the fp32-operand execution (dtype == ETAINV_F32 routes here from the launchers of igemm / norm / attention)
 int launch_igemm_f32(const IGemmParams& p, hipStream_t s);
 int launch_groupnorm_f32(const void* x1, const void* x2, int c1, int c2, const float* gamma, const float* beta, void* out, int b, int hw, int groups,

@@ -309,6 +309,43 @@ def test_gemm_layernorm_fold(capi, dtype, m, c, n_out, geglu, expect_p):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m_tiles,n_out,geglu", [(256, 2560, 1), (700, 2560, 1), (256, 960, 0), (513, 960, 0), (1024, 1920, 0)])
+def test_xsgemm_equals_ring_kernel(capi, dtype, monkeypatch, m_tiles, n_out, geglu):
+    """csrc/xsgemm.hip (opt-in experiment, ETAINV_XSGEMM=1: K = 320 LayerNorm consumers with many rows on a stationary activation tile, two wave
+    groups in anti-phase) accumulates in the ring kernel's K order and runs its epilogue arithmetic: the two must give EQUAL values.  Row counts that give the 256 persistent blocks 1, 2-3
+    (uneven) and 4 M tiles each; GEGLU (128-column N tiles) and plain (96-column) epilogues."""
+    lib = capi.load()
+    dt = capi.dtype_code(dtype)
+    m, c = 128 * m_tiles, 320
+    x = rnd(m, c, seed=11, scale=1.5, dtype=dtype) + 0.3
+    xf = x.float()
+    stat = torch.stack([xf.mean(-1), (xf.var(-1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous()
+    w = rnd(n_out, c, seed=5, scale=c ** -0.5)
+    gamma, beta, bias = 1.0 + 0.3 * rnd(c, seed=6), 0.2 * rnd(c, seed=7), rnd(n_out, seed=8)
+    wp = torch.empty(n_out, c, dtype=dtype, device="cuda")
+    s_vec, c_vec = torch.empty(n_out, device="cuda"), torch.empty(n_out, device="cuda")
+    capi.check(lib.etainv_op_ln_fold(capi.ptr(w), capi.ptr(gamma), capi.ptr(beta), capi.ptr(bias), n_out, c, geglu, 1.0, capi.ptr(wp), capi.ptr(s_vec),
+                                     capi.ptr(c_vec), dt, capi.stream_ptr()))
+    n_store = n_out // 2 if geglu else n_out
+    outs = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("ETAINV_XSGEMM", on)
+        out = torch.full((m, n_store), float("nan"), dtype=dtype, device="cuda")
+        capi.check(lib.etainv_op_gemm_ln(capi.ptr(x), capi.ptr(wp), capi.ptr(c_vec), capi.ptr(s_vec), capi.ptr(stat), None, capi.ptr(out), None, None,
+                                         m, n_out, c, geglu, dt, capi.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(out)
+    h = F.layer_norm(xf, (c,), gamma, beta, 1e-5) @ w.t() + bias
+    ref = h[:, :n_out // 2] * F.gelu(h[:, n_out // 2:]) if geglu else h
+    assert relerr(outs[0], ref) < TOL[dtype] and relerr(outs[1], ref) < TOL[dtype]
+    # same MFMA accumulation order, same epilogue expressions: equal values (as numbers: a product that underflows to zero may come out as -0 in one
+    # kernel and +0 in the other, depending on where the compiler contracts a * b + c into an fma)
+    a, b = outs[0].float(), outs[1].float()
+    neq = a != b
+    assert not bool(neq.any()), f"{int(neq.sum())} of {neq.numel()} elements differ, max abs {float((a - b).abs().max()):.3e}; rows {neq.any(1).nonzero().flatten()[:8].tolist()}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_layernorm_fold_ragged(capi, dtype):
     """row counts that are not a multiple of the wave tile: general epilogue on the consumer, fallback statistics pass on the producer"""
     assert _ln_pair(capi, dtype, 4096, 320, 960, 0, ragged=24) == 0
