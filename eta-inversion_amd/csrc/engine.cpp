@@ -145,6 +145,21 @@ struct etainv_engine {
   bool ln_folded = false;   // the gamma-scaled consumer weights are packed (redone after any set_weight)
   std::vector<hipStream_t> upload_streams;   // streams weights were uploaded on since the last fold (the fold waits for each that is not the forward's)
   uint64_t ctx_gen = 0, ctx_gen_cached = 0;  // caller's generation of the context buffer (etainv_engine_context_generation)
+
+  // ---- hipGraph replay of small UNet calls (batch 1: ~330 dependent launches of 5 - 30 us).  OPT-IN: the GPU, not the host, paces these calls -- the
+  // gap between two dependent kernels (~1.5 us) is the same inside a replayed graph as between eager launches (MI355X_MICROARCH.md, "boundary" row),
+  // and the measurement agrees: BASELINE config 2 runs 1.456 images/s with replays and 1.458 without (profiles/r04_cfg2_graph_ab.json).  One captured graph
+  // per call signature (rows, latents, io dtype, shared prefix, K / V reuse, attention-control flags); everything that changes from call to call
+  // sits behind a FIXED device address: latent / context / output staged through engine-owned buffers, the timesteps in a device vector that a
+  // by-value kernel fills in front of the replay.  Calls whose attention control carries per-step device tables (prompt-to-prompt edits) run
+  // eagerly, as do calls above ETAINV_GRAPH_MAX_ROWS rows (launch overhead is hidden there) and everything while the event profiler is on.
+  void *g_lat = nullptr, *g_ctx = nullptr, *g_out = nullptr;
+  float* g_t = nullptr;
+  struct GraphEntry { int calls = 0; bool failed = false; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+  std::unordered_map<std::string, GraphEntry> graphs;
+  hipStream_t cap_stream = nullptr;   // capture happens on a stream of the engine's own (the caller's is usually the legacy default stream, which cannot capture)
+  int graph_max_rows = 0;             // OFF by default: measured on MI355X at batch 1 (config 2) a replay is exactly as fast as the eager launches (1.456 vs 1.458 images/s)
+  int64_t graph_replays = 0, graph_captures = 0;
 };
 
 namespace {
@@ -413,6 +428,10 @@ int build_workspace(etainv_engine* e) {
   const size_t res = L / 4;
   e->maps_bytes = (size_t)5 * e->max_img * 2 * etainv_engine::kHeads * res * res * 77 * 4;
   want(reinterpret_cast<void**>(&e->maps_acc), e->maps_bytes);
+  want(&e->g_lat, B * 4 * L * L * 4);                                   // graph staging (fp32-sized: the boundary dtype may be fp32)
+  want(&e->g_out, B * 4 * L * L * 4);
+  want(&e->g_ctx, B * 77 * 768 * 4);
+  want(reinterpret_cast<void**>(&e->g_t), B * 4);
   e->wsbytes = plan.off;
   ETAINV_HIP(hipMalloc(reinterpret_cast<void**>(&e->wsarena), e->wsbytes));
   for (auto& f : fix) f(e->wsarena);
@@ -691,6 +710,8 @@ extern "C" int etainv_engine_create(const etainv_engine_config* cfg, etainv_engi
   e->ln_fused = !getenv("ETAINV_LN_UNFUSED") && e->dt != ETAINV_F32;
   e->gn_fused = !getenv("ETAINV_GN_UNFUSED") && e->dt != ETAINV_F32;
   e->gn_fold = e->gn_fused && getenv("ETAINV_GN_FOLD") != nullptr;
+  // hipGraph replay of small calls: opt-in, ETAINV_GRAPH_MAX_ROWS=<rows> (calls of at most that many UNet rows are captured and replayed)
+  if (const char* gm = getenv("ETAINV_GRAPH_MAX_ROWS")) e->graph_max_rows = atoi(gm);
   if (build_model(e) || build_workspace(e)) {
     etainv_engine_destroy(e);
     return 1;
@@ -701,6 +722,11 @@ extern "C" int etainv_engine_create(const etainv_engine_config* cfg, etainv_engi
 
 extern "C" int etainv_engine_destroy(etainv_engine_t* e) {
   if (!e) return 0;
+  for (auto& kv : e->graphs) {
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+  }
+  if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
   if (e->warena) (void)hipFree(e->warena);
   if (e->wsarena) (void)hipFree(e->wsarena);
   delete e;
@@ -780,11 +806,60 @@ extern "C" int64_t etainv_engine_workspace_bytes(etainv_engine_t* e) { return e 
 extern "C" int64_t etainv_engine_weight_bytes(etainv_engine_t* e) { return e ? (int64_t)e->wbytes : 0; }
 
 static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const int64_t* t_host, const void* ctx, int n_rows,
-                     const etainv_attn_ctrl* ctrl, void* out, int io_dtype, void* stream);
+                     const etainv_attn_ctrl* ctrl, void* out, int io_dtype, void* stream, const float* t_dev, int kv_reuse_forced);
+
+static size_t io_size(int dt) { return dt == ETAINV_F32 ? 4 : 2; }
+
+// Replay of a captured call (see etainv_engine::graphs).  Returns 0 = replayed, 1 = error (message set), 2 = not taken: run the call eagerly.
+static int unet_graph(etainv_engine_t* e, const void* latent, int n_lat, const int64_t* t_host, const void* ctx, int n_rows, const etainv_attn_ctrl* ctrl,
+                      void* out, int io_dtype, void* stream) {
+  if (e->graph_max_rows <= 0 || n_rows > e->graph_max_rows || prof_enabled()) return 2;
+  if (ctrl && (ctrl->mapper || ctrl->alphas || ctrl->replace_mat || ctrl->equalizer || ctrl->cross_alpha)) return 2;   // per-step device tables
+  hipStream_t s = (hipStream_t)stream;
+  if (e->ln_fused && !e->ln_folded && fold_layernorms(e, s)) return 1;   // (host work with stream synchronisation: never inside a capture)
+  bool t_pairs = n_rows > n_lat && n_rows <= 2 * n_lat;                   // what unet_body's shared-prefix decision reads from the timesteps
+  for (int r = n_lat; t_pairs && r < n_rows; ++r) t_pairs = t_host[r] == t_host[r - n_lat];
+  const bool reuse = e->ctx_cache_on && e->ctx_cached == ctx && e->ctx_rows == n_rows && e->ctx_io == io_dtype && e->ctx_gen_cached == e->ctx_gen;
+  char key[160];
+  snprintf(key, sizeof key, "%d.%d.%d.%d.%d|%d.%d.%d.%d.%d.%d.%d.%d.%d", n_rows, n_lat, io_dtype, (int)t_pairs, (int)reuse, ctrl ? ctrl->mode : -1,
+           ctrl ? ctrl->n_img : 0, ctrl ? ctrl->store_maps : 0, ctrl ? ctrl->self_replace_active : 0, ctrl ? ctrl->self_max_tokens : 0,
+           ctrl ? ctrl->masa_active : 0, ctrl ? ctrl->masa_first_block : 0, ctrl ? ctrl->first_row : 0, ctrl ? ctrl->src_exit_block : 0);
+  auto& ge = e->graphs[key];
+  // the first call of a signature runs eagerly: one-time allocations, function attributes and the LayerNorm fold happen outside any capture
+  if (ge.failed || ++ge.calls < 2) return 2;
+  const size_t lat_bytes = (size_t)n_lat * 4 * e->L * e->L * io_size(io_dtype), out_bytes = (size_t)n_rows * 4 * e->L * e->L * io_size(io_dtype);
+  ETAINV_HIP(hipMemcpyAsync(e->g_lat, latent, lat_bytes, hipMemcpyDeviceToDevice, s));
+  if (!reuse) ETAINV_HIP(hipMemcpyAsync(e->g_ctx, ctx, (size_t)n_rows * etainv_engine::kCtx * etainv_engine::kCtxDim * io_size(io_dtype), hipMemcpyDeviceToDevice, s));
+  if (launch_set_timesteps(t_host, n_rows, e->g_t, s)) return 1;
+  if (!ge.exec) {
+    if (!e->cap_stream) ETAINV_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+    ETAINV_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
+    const int rc = unet_body(e, e->g_lat, n_lat, t_host, e->g_ctx, n_rows, ctrl, e->g_out, io_dtype, (void*)e->cap_stream, e->g_t, reuse ? 1 : 0);
+    hipGraph_t g = nullptr;
+    const hipError_t ec = hipStreamEndCapture(e->cap_stream, &g);
+    if (rc || ec != hipSuccess || !g || hipGraphInstantiate(&ge.exec, g, nullptr, nullptr, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      if (g) (void)hipGraphDestroy(g);
+      ge.exec = nullptr;
+      ge.failed = true;                    // this signature stays on the eager path (the staged inputs are untouched copies)
+      return 2;
+    }
+    ge.graph = g;
+    ++e->graph_captures;
+  }
+  ETAINV_HIP(hipGraphLaunch(ge.exec, s));
+  ETAINV_HIP(hipMemcpyAsync(out, e->g_out, out_bytes, hipMemcpyDeviceToDevice, s));
+  ++e->graph_replays;
+  return 0;
+}
 
 extern "C" int etainv_unet_forward(etainv_engine_t* e, const void* latent, int n_lat, const int64_t* t_host, const void* ctx, int n_rows,
                                    const etainv_attn_ctrl* ctrl, void* out, int io_dtype, void* stream) {
-  if (unet_body(e, latent, n_lat, t_host, ctx, n_rows, ctrl, out, io_dtype, stream)) return 1;
+  int rc = 2;
+  if (e && latent && t_host && ctx && out && n_rows >= 1 && n_rows <= e->maxB && n_lat >= 1 && n_lat <= n_rows && etainv_engine_weights_ready(e))
+    rc = unet_graph(e, latent, n_lat, t_host, ctx, n_rows, ctrl, out, io_dtype, stream);
+  if (rc == 1) return 1;
+  if (rc == 2 && unet_body(e, latent, n_lat, t_host, ctx, n_rows, ctrl, out, io_dtype, stream, nullptr, -1)) return 1;
   if (e->ctx_cache_on) {
     e->ctx_cached = ctx;
     e->ctx_rows = n_rows;
@@ -794,8 +869,16 @@ extern "C" int etainv_unet_forward(etainv_engine_t* e, const void* latent, int n
   return 0;
 }
 
+/* hipGraph path of small calls: captures / replays since the engine was created (tests, benchmarks) */
+extern "C" int etainv_engine_graph_stats(etainv_engine_t* e, int64_t* captures, int64_t* replays) {
+  ETAINV_CHECK(e && captures && replays, "null argument");
+  *captures = e->graph_captures;
+  *replays = e->graph_replays;
+  return 0;
+}
+
 static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const int64_t* t_host, const void* ctx, int n_rows,
-                     const etainv_attn_ctrl* ctrl, void* out, int io_dtype, void* stream) {
+                     const etainv_attn_ctrl* ctrl, void* out, int io_dtype, void* stream, const float* t_dev, int kv_reuse_forced) {
   ETAINV_CHECK(e && latent && t_host && ctx && out, "null argument");
   ETAINV_CHECK(n_rows >= 1 && n_rows <= e->maxB, "n_rows exceeds max_unet_batch");
   ETAINV_CHECK(n_lat >= 1 && n_lat <= n_rows, "1 <= n_lat <= n_rows (UNet row r reads latent r % n_lat)");
@@ -819,7 +902,9 @@ static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const in
   f.ctx_rows = n_rows;
 
   // timesteps (by value in the kernel arguments: no host buffer outlives this call) -> embedding, MLP, all 22 projections in one GEMM
-  if (launch_time_embedding(t_host, n_rows, etainv_engine::kCh0, e->tembuf, e->dt, s)) return 1;
+  // (t_dev: the graph path -- the timesteps of a replay are whatever launch_set_timesteps wrote to the device vector in front of it)
+  if (t_dev ? launch_time_embedding_dev(t_dev, n_rows, etainv_engine::kCh0, e->tembuf, e->dt, s)
+            : launch_time_embedding(t_host, n_rows, etainv_engine::kCh0, e->tembuf, e->dt, s)) return 1;
   if (f.gemm(e->tembuf, e->time1, e->temb1, n_rows)) return 1;
   if (launch_silu(e->temb1, e->temb1, (int64_t)n_rows * etainv_engine::kTemb, e->dt, s)) return 1;
   if (f.gemm(e->temb1, e->time2, e->temb2, n_rows)) return 1;
@@ -839,7 +924,8 @@ static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const in
     p.rows_per_batch = n_rows;
     if (launch_igemm(p, e->dt, s)) return 1;
   }
-  f.kv_reuse = e->ctx_cache_on && e->ctx_cached == ctx && e->ctx_rows == n_rows && e->ctx_io == io_dtype && e->ctx_gen_cached == e->ctx_gen;
+  f.kv_reuse = kv_reuse_forced >= 0 ? kv_reuse_forced != 0
+                                    : e->ctx_cache_on && e->ctx_cached == ctx && e->ctx_rows == n_rows && e->ctx_io == io_dtype && e->ctx_gen_cached == e->ctx_gen;
   // the cache entry becomes valid only when this forward has enqueued every projection (set at the end of unet_body): an error half-way
   // leaves it invalid, so the next call projects again
   e->ctx_cached = nullptr;

@@ -134,6 +134,9 @@ int launch_conv_out(const void* x, int rows, int L, int cin, const void* w, cons
                     hipStream_t s);
 // sinusoidal timestep embedding (flip_sin_to_cos, freq_shift 0): t_host [rows] (HOST array, passed by value in the kernel arguments) -> [rows][dim] T
 int launch_time_embedding(const int64_t* t_host, int rows, int dim, void* out, int dtype, hipStream_t s);
+// the same from DEVICE timesteps t_dev [rows] floats (written by launch_set_timesteps): replayable inside a captured hipGraph
+int launch_set_timesteps(const int64_t* t_host, int rows, float* t_dev, hipStream_t s);
+int launch_time_embedding_dev(const float* t_dev, int rows, int dim, void* out, int dtype, hipStream_t s);
 // y = silu(x) elementwise on T
 int launch_silu(const void* x, void* out, int64_t n, int dtype, hipStream_t s);
 // cast fp32 -> T with optional row permutation (weights)

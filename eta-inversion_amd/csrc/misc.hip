@@ -262,6 +262,40 @@ int launch_time_embedding(const int64_t* t_host, int rows, int dim, void* out, i
   return 0;
 }
 
+// the same embedding with the timesteps read from DEVICE memory (t_dev [rows] floats): the form a captured hipGraph can replay with new timesteps.
+// launch_set_timesteps (kernel arguments by value, like above) fills t_dev in front of it.
+template <typename T>
+__global__ void time_embedding_dev_kernel(const float* __restrict__ t_dev, int rows, int dim, T* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * dim) return;
+  const int r = i / dim, c = i - r * dim, half = dim / 2;
+  const int k = c < half ? c : c - half;
+  const float freq = expf(-9.210340371976184f * (float)k / (float)half);  // ln(10000)
+  const float a = t_dev[r] * freq;
+  out[i] = from_f32<T>(c < half ? cosf(a) : sinf(a));
+}
+__global__ void set_timesteps_kernel(TimeVec tv, int row0, int n, float* __restrict__ t_dev) {
+  const int i = threadIdx.x;
+  if (i < n) t_dev[row0 + i] = tv.t[i];
+}
+int launch_set_timesteps(const int64_t* t_host, int rows, float* t_dev, hipStream_t s) {
+  ETAINV_CHECK(t_host && t_dev && rows > 0, "bad arguments");
+  for (int r0 = 0; r0 < rows; r0 += 64) {
+    const int n = std::min(64, rows - r0);
+    TimeVec tv;
+    for (int i = 0; i < n; ++i) tv.t[i] = (float)t_host[r0 + i];
+    hipLaunchKernelGGL(set_timesteps_kernel, dim3(1), dim3(64), 0, s, tv, r0, n, t_dev);
+  }
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+int launch_time_embedding_dev(const float* t_dev, int rows, int dim, void* out, int dtype, hipStream_t s) {
+  ETAINV_CHECK(t_dev && out && dim % 2 == 0 && rows > 0, "bad arguments");
+  ETAINV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(time_embedding_dev_kernel<T>, dim3(cdiv(rows * dim, 256)), dim3(256), 0, s, t_dev, rows, dim, (T*)out));
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_silu(const void* x, void* out, int64_t n, int dtype, hipStream_t s) {
   ETAINV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(silu_kernel<T>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const T*)x, (T*)out, n));
   ETAINV_LAUNCH_CHECK();

@@ -50,6 +50,7 @@ SIGNATURES = {
     "etainv_maps_word_maps": [_p, _i, _p, _i, _i, _p, _i, _f, _p],
     "etainv_maps_word_maps_role": [_p, _i, _p, _i, _i, _i, _p, _i, _f, _p],
     "etainv_local_blend": [_p, _p, _i, _p, _f, _p],
+    "etainv_engine_graph_stats": [_p, C.POINTER(_i64), C.POINTER(_i64)],
     "etainv_engine_workspace_bytes": [_p],
     "etainv_engine_weight_bytes": [_p],
     "etainv_prof_enable": [_i],

@@ -148,6 +148,13 @@ class Engine:
         return x
 
     @property
+    def graph_stats(self):
+        """(captures, replays) of the hipGraph path of small UNet calls since the engine was created"""
+        cap, rep = C.c_int64(), C.c_int64()
+        _capi.check(self.lib.etainv_engine_graph_stats(self.h, C.byref(cap), C.byref(rep)))
+        return cap.value, rep.value
+
+    @property
     def workspace_bytes(self):
         return self.lib.etainv_engine_workspace_bytes(self.h)
 

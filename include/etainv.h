@@ -194,6 +194,12 @@ int etainv_engine_cache_context(etainv_engine_t* e, int enable);
  * that rewrites the context tensor IN PLACE between two calls (same pointer, rows, dtype) bumps it; the built-in loops pass a fresh value per
  * loop.  The cache entry is recorded only after a forward has succeeded: an error half-way never leaves stale K / V behind. */
 int etainv_engine_context_generation(etainv_engine_t* e, uint64_t generation);
+/* hipGraph replay of small UNet calls (opt-in: ETAINV_GRAPH_MAX_ROWS=<rows>, read at engine creation; measured no faster than the eager launches
+ * at batch 1 -- the dependent-kernel gap is the same inside a graph): from its
+ * second occurrence on, a call signature (rows, latents, dtype, attention-control flags without per-step device tables) is captured once and replayed
+ * -- latent / context / output staged through engine-owned buffers, the timesteps through a device vector.  Same results as the eager launches
+ * (the replay IS those launches); captures / replays counted since engine creation. */
+int etainv_engine_graph_stats(etainv_engine_t* e, int64_t* captures, int64_t* replays);
 int64_t etainv_engine_workspace_bytes(etainv_engine_t* e);
 int64_t etainv_engine_weight_bytes(etainv_engine_t* e);
 
