@@ -81,8 +81,17 @@ __device__ __forceinline__ float row_sum16(float x) {
 // LN: the folded-LayerNorm role of the launch as a compile-time constant -- the ring kernels sit exactly at 256 VGPRs, and a role read at
 // run time makes the register allocator keep all three epilogues' values apart (0 = none, 1 = producer: row statistics from the epilogue,
 // 2 = consumer: rstd (acc - mean s) + c, 3 = GroupNorm producer: per-channel (sum, sum of squares) of the stored values over the rows of each wave tile)
-template <typename T, int BM, int BN, int WAVES_M, int STAGES, bool UPS = false, int LN = 0>
+// PATCH (256 x 160 ring, conv3x3 stride 1 on H, W multiples of 16 only): an M tile is a 16 x 16 PIXEL PATCH of one image and the K loop runs channel
+// chunk major, the nine taps inside: the activations of a chunk are brought to LDS ONCE as the halo'd 18 x 18 patch (41 DMA pieces of 1 KiB instead of
+// 9 x 32) and the nine taps read it at shifted rows; the halo outside the image comes from the zero page.  Measured motivation: profiles/
+// r04_conv_traffic_ablation.log (activation pieces for one tap in nine: conv3x3 -9 ... -15 %).
+template <typename T, int BM, int BN, int WAVES_M, int STAGES, bool UPS = false, int LN = 0, bool PATCH = false>
 __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) {
+  static_assert(!PATCH || (STAGES == 3 && BM == 256 && WAVES_M == 4 && !UPS && (LN == 0 || LN == 3)), "patch mode: the 256-row ring, plain or GroupNorm-producer epilogue");
+  constexpr int PW = 18;                                   // patch pitch (16 + halo)
+  constexpr int PROWS = 328;                               // 18 x 18 = 324 patch rows, rounded up to whole 8-row DMA pieces
+  constexpr int PPIECES = PROWS / 8;                       // 41
+  constexpr int A_REGION = PATCH ? 2 * PROWS * 64 : STAGES * BM * 64;   // elements: two patch slots / the A ring
   constexpr bool ln_emit = LN == 1;
   constexpr bool ln_use = LN == 2;
   constexpr bool gn_emit = LN == 3;
@@ -96,11 +105,11 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   typedef typename Mfma<T>::frag frag;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* sA = reinterpret_cast<T*>(smem);                       // [STAGES][BM*BK]
-  T* sB = reinterpret_cast<T*>(smem) + STAGES * BM * BK;    // [STAGES][BN*BK]
+  T* sA = reinterpret_cast<T*>(smem);                       // [STAGES][BM*BK]   (PATCH: [2][PROWS*BK])
+  T* sB = reinterpret_cast<T*>(smem) + A_REGION;            // [STAGES][BN*BK]
   // bias of the tiles in flight: filled by LDS-DMA together with a tile's first K step, read by its epilogue (a global bias
   // load in the epilogue waits behind every queued DMA: ~1.5 us per tile with the matrix pipe idle)
-  float* sBias = reinterpret_cast<float*>(smem + (size_t)STAGES * (BM + BN) * BK * sizeof(T));   // [4][BN]
+  float* sBias = reinterpret_cast<float*>(smem + ((size_t)A_REGION + (size_t)STAGES * BN * BK) * sizeof(T));   // [4][BN]
   // LayerNorm consumer on the 256 x 128 ring (the GEGLU projection; 13 KB of LDS to spare): the s vector and the (mean, rstd) rows of the tiles in
   // flight arrive by DMA with the bias -- read from global memory at the start of the epilogue they cost one exposed memory latency per tile
   // (measured +1.5 us on a 7.4 us tile), and the 256 x 160 ring has neither the LDS nor the registers to fetch them early
@@ -184,7 +193,9 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       it_ky = it_tap / 3;
       it_kx = it_tap - it_ky * 3;
     }
-    if (p.taps == 1) {
+    if constexpr (PATCH) {
+      // (the activation side of a patch tile has no per-row state: issue_a derives the halo'd patch of a chunk from the tile index)
+    } else if (p.taps == 1) {
       // 1x1 / Linear: the source row IS the output row -- no (image, y, x) decomposition, no halo mask (a K = 320 tile is
       // only five K steps long, so the ~500 VALU instructions of the general setup were ~20 % of its main loop)
 #pragma unroll
@@ -379,6 +390,15 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       if (p.debug & 8) mw &= 255;   // ablation: all tiles store into the same cache-resident rows
       const bool wide = (n0 + BN <= p.N) && (p.N % 16) == 0 && !(p.debug & 32);
       const float* tile_bias = sBias + (tile & 3) * BN;   // whole tile inside N: 16-byte stores after a lane swap
+      // memory row of this lane's 16-row group i.  PATCH: the group is patch row wm * 4 + i of a 16 x 16 pixel patch, lane fr its column (mw stays the
+      // VIRTUAL row index, patches enumerated image-major: `batch` and the GroupNorm row-block index derived from it are unchanged)
+      int pm0 = 0;
+      if constexpr (PATCH) {
+        const int mt = m0 / BM, tpr = p.W / 16, tpi = (p.H / 16) * tpr;
+        const int b_ = mt / tpi, r_ = mt - b_ * tpi, ty_ = r_ / tpr;
+        pm0 = (b_ * p.H + ty_ * 16 + wm * 4) * p.W + (r_ - ty_ * tpr) * 16;
+      }
+      auto row_m = [&](int i) __attribute__((always_inline)) { return PATCH ? pm0 + i * p.W + fr : mw + i * 16 + fr; };
       const bool ln = ln_use;   // folded LayerNorm: v = rstd[m] * (acc - mean[m] * s[n]) + c[n]  (c arrives as the bias)
       float ln_mean[MT], ln_rstd[MT];
       if (!p.geglu) {
@@ -430,7 +450,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         if (res) {
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
-            const int m = mw + i * 16 + fr;
+            const int m = row_m(i);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
               const int n = n0 + wn * WN + j * 16 + fq * 4;
@@ -445,7 +465,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         u32x2 po[MT][NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          const int m = mw + i * 16 + fr;
+          const int m = row_m(i);
 #if !ETAINV_RES_PREFETCH
           u32x2 rvi[NT];
           if (res) {
@@ -793,14 +813,24 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     static_assert(STAGES == 3, "ring");
     constexpr int B_PASSES = (BN + RP - 1) / RP;
     constexpr int N1 = A_LOADS + B_PASSES;   // DMA pieces per wave and step
-    T* const dummy = reinterpret_cast<T*>(smem + (size_t)STAGES * (BM + BN) * BK * sizeof(T) + 4 * BN * sizeof(float));
-    auto read_frags = [&](int st, int kk, u32x4 (&fa)[MT], u32x4 (&fb)[NT]) __attribute__((always_inline)) {
+    T* const dummy = reinterpret_cast<T*>(smem + ((size_t)A_REGION + (size_t)STAGES * BN * BK) * sizeof(T) + 4 * BN * sizeof(float));
+    int ct_tap = 0, ct_gq = 0;   // PATCH: tap / running chunk count of the K tile being computed
+    // (PATCH: pgq / ptap = patch slot parity and tap of the K tile the fragments belong to; wave row group i = patch row wm * 4 + i, lane fr = patch column)
+    auto read_frags = [&](int st, int kk, u32x4 (&fa)[MT], u32x4 (&fb)[NT], int pgq = 0, int ptap = 0) __attribute__((always_inline)) {
       const T* tA = sA + st * BM * BK;
       const T* tB = sB + st * BN * BK;
+      if constexpr (PATCH) {
+        const int ky = ptap / 3, kx = ptap - ky * 3;
+        const int col = fr + kx;
+        const T* tP = sA + (pgq & 1) * (PROWS * BK) + ((wm * 4 + ky) * PW + col) * BK + (((kk * 4 + fq) ^ (col & 7)) << 3);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const u32x4*>(tP + i * (PW * BK));
+      } else {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         int row = wm * WM + i * 16 + fr;
         fa[i] = *reinterpret_cast<const u32x4*>(tA + row * BK + (((kk * 4 + fq) ^ (row & 7)) << 3));
+      }
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -823,7 +853,52 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     // window 2 of step s, the weight pieces in window 1 of step s+1.  The CU's vector-memory path moves 64 B/clk, i.e. 16 clocks
     // per 1-KiB piece: all 56 pieces of a K tile right after the barrier are a 900-clock burst during which window 2 (640
     // clocks of matrix work) waits on its own last piece (in-kernel stamps: window 1 338 clocks, window 2 1154).
+    // ---- PATCH mode issue state: the chunk stream (tile, channel chunk) -> two patch slots alternately.  Every step issues exactly ONE patch piece
+    // per wave, branch-free (the windows must stay single basic blocks and the counted waits uniform): pieces of the NEXT chunk of the stream from tap 2 on
+    // (its slot's previous patch is read until the rendezvous of compute step (chunk - 2, tap 8) = issue position (chunk - 1, tap 2) of the 3-step
+    // run-ahead), a piece aimed at the dummy area otherwise (taps 0, 1; ids past the patch; no next tile).
+    int it_q = 0, it_gq = 0;                 // chunk index inside the tile / running chunk count (patch slot = count & 1) of the issue position
+    int pt_e0 = 0, pt_y0 = 0, pt_x0 = 0;     // patch being issued: element offset of its pixel (-1, -1) at its channel chunk, its image origin
+    bool pt_ok = false;
+    auto patch_target = [&](int tile, int q) __attribute__((always_inline)) {   // scalar work, once per chunk (advance_ring: off the windows)
+      pt_ok = tile < my_tiles;
+      int m0, n0;
+      tile_origin(pt_ok ? tile : 0, m0, n0);
+      const int mt = m0 / BM, tpr = p.W / 16, tpi = (p.H / 16) * tpr;
+      const int b = mt / tpi, r = mt - b * tpi, ty = r / tpr;
+      pt_y0 = ty * 16;
+      pt_x0 = (r - ty * tpr) * 16;
+      pt_e0 = ((b * p.H + pt_y0 - 1) * p.W + pt_x0 - 1) * p.c1 + q * BK;
+    };
+    const int lrow8 = lane >> 3;
+    // piece `id` (rows id * 8 .. + 7 of the 18 x 18 patch, row-major incl. halo) of the target patch -> slot `ps`; !real: a dummy piece
+    // (LDS image of a patch: row = patch pixel (pr, pc) row-major at pitch 18, physical 16-byte chunk = logical chunk ^ (pc & 7).  The key is the patch
+    // COLUMN, not the row as in the tile image: rows that a fragment read touches are 16 consecutive columns of one patch row, so (row parity, key)
+    // relate exactly as in the tile image -- conflict-free ds_read_b128 -- while the key of a read depends on the tap's kx only, not on ky or the row group)
+    // !real: the piece goes to the dummy area from the zero page -- every wave issues exactly one piece per step INSIDE the MFMA cluster of window 2,
+    // no branch (a piece issued behind the cluster cost ~170 cycles per step on the critical path: profiles/r04_conv_patch_stamps.log), uniform counts
+    auto issue_patch_piece = [&](int ps, int id, bool real) __attribute__((always_inline)) {
+      const int prow = id * 8 + lrow8;
+      const int pr = (prow * 3641) >> 16, pc = prow - pr * PW;     // prow / 18 for prow < 1024
+      const int y = pt_y0 - 1 + pr, x = pt_x0 - 1 + pc;
+      const bool ok = real & (prow < PW * PW) & (y >= 0) & (y < p.H) & (x >= 0) & (x < p.W);
+      const T* src = reinterpret_cast<const T*>(p.a1);
+      const unsigned elem = ok ? (unsigned)(pt_e0 + (pr * p.W + pc) * p.c1 + (((lane & 7) ^ (pc & 7)) << 3)) : 0u;   // (halo lanes: offset 0 of the zero page)
+      const T* g = (ok ? src : zero_page) + elem;
+      T* dst = real ? sA + ps * (PROWS * BK) + id * 8 * BK : dummy;   // wave-uniform
+#ifdef ETAINV_ABL_PATCH_ZERO   // timing experiment only (wrong results): every piece reads the zero page
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)zero_page, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      return;
+#endif
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    const int kcq = cin / BK;                // channel chunks per tile (PATCH: K tile kt = q * 9 + tap)
     auto issue_a = [&](int buf) __attribute__((always_inline)) {
+      if constexpr (PATCH) {
+        const int id = (it_tap - 2) * 8 + __builtin_amdgcn_readfirstlane(wid);
+        issue_patch_piece((it_gq + 1) & 1, id & 63, (it_tap >= 2) & (id < PPIECES) & pt_ok);
+        return;
+      }
       const bool second = it_c0 >= p.c1;
       const T* src = reinterpret_cast<const T*>(second ? p.a2 : p.a1);
       const int cs = second ? p.c2 : p.c1;
@@ -847,10 +922,11 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     };
     auto issue_b = [&](int buf) __attribute__((always_inline)) {
       T* dB = sB + buf * BN * BK;
+      const int koff = PATCH ? it_tap * cin + it_q * BK : it_kt * BK;   // (PATCH: weights [N][tap][cin], K tile = (chunk q, tap))
 #pragma unroll
       for (int i = 0; i < B_PASSES; ++i) {
         T* dst = (BN % RP == 0 || wrow0 + RP * i < BN) ? dB + (wrow0 + RP * i) * BK : dummy;   // wave-uniform select
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_row[i] + it_kt * BK),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_row[i] + koff),
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       }
     };
@@ -875,18 +951,35 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       }
     };
     auto advance_ring = [&]() __attribute__((always_inline)) {
-      it_c0 += BK;
-      if (it_c0 == cin) {
-        it_c0 = 0;
-        ++it_tap;
-        if (++it_kx == 3) { it_kx = 0; ++it_ky; }
+      bool chunk_changed = false;
+      if constexpr (PATCH) {                 // chunk major: nine taps, then the next channel chunk
+        if (++it_tap == 9) {
+          it_tap = 0;
+          ++it_q;
+          ++it_gq;
+          chunk_changed = true;
+        }
+      } else {
+        it_c0 += BK;
+        if (it_c0 == cin) {
+          it_c0 = 0;
+          ++it_tap;
+          if (++it_kx == 3) { it_kx = 0; ++it_ky; }
+        }
       }
       if (++it_kt == nk) {
         it_kt = 0;
         it_tap = it_ky = it_kx = 0;
+        it_q = 0;
         if (++it_tile < my_tiles) {
           setup_issue(it_tile);
           bias_dma();
+        }
+      }
+      if constexpr (PATCH) {
+        if (chunk_changed) {                 // the patch issued while the issue position walks chunk it_q is the one of the chunk AFTER it in the stream
+          const bool last_q = it_q + 1 == kcq;
+          patch_target(last_q ? it_tile + 1 : it_tile, last_q ? 0 : it_q + 1);
         }
       }
     };
@@ -899,6 +992,11 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     // (A bias DMA issued at a tile switch is younger still: it only makes the wait cover one more piece of the newest slot.)
     auto wait_one_slot_in_flight = [&](int young = 0) {
       constexpr int S1 = MT * ((NT + 1) / 2), S2 = MT * ((NT / 2 + 1) / 2);
+      if constexpr (PATCH) {   // pieces per wave of the K tile in flight: its weight pieces + the one patch (or dummy) piece of the last issue_a
+        constexpr int NP_ = B_PASSES + 1;
+        if (young == 1) ETAINV_VMCNT(NP_ + S1); else if (young == 4) ETAINV_VMCNT(NP_ + S1 + 2 * NT); else ETAINV_VMCNT(NP_);
+        return;
+      }
       if (young == 1) ETAINV_VMCNT(N1 + S1);
       else if (young == 3) ETAINV_VMCNT(N1 + S1 + MT);   // + the row-statistics stores of a LayerNorm producer
       else if (young == 4) ETAINV_VMCNT(N1 + S1 + 2 * NT);   // + the channel-statistics stores of a GroupNorm producer
@@ -907,14 +1005,24 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     };
     // prologue: K tiles 0 and 1 whole, of K tile 2 only the activation pieces (its weight pieces go out in step 0's window 1)
     bias_dma();
+    if constexpr (PATCH) {   // the whole patch of the first chunk up front (41 pieces over the 8 waves), then the target moves to the second chunk
+      patch_target(0, 0);
+      for (int id = __builtin_amdgcn_readfirstlane(wid); id < PPIECES; id += 8) issue_patch_piece(0, id, true);
+      patch_target(kcq > 1 ? 0 : 1, kcq > 1 ? 1 : 0);
+    }
     issue_a(0);
     issue_b(0);
     if (total_steps > 1) { advance_ring(); issue_a(1); issue_b(1); }
     if (total_steps > 2) { advance_ring(); issue_a(2); }
     // (tile switches inside this prologue put bias pieces between the slots: the counts below then over-wait, never under-wait)
+    if constexpr (PATCH) {   // K tile 1's pieces (weights + 1) and the piece of K tile 2's issue may stay in flight (nk >= 9: no tile switch in here)
+      if (total_steps > 2) ETAINV_VMCNT(B_PASSES + 2);
+      else ETAINV_VMCNT(0);
+    } else {
     if (total_steps > 2) ETAINV_VMCNT(N1 + A_LOADS);
     else if (total_steps > 1) ETAINV_VMCNT(N1);
     else ETAINV_VMCNT(0);
+    }
     __builtin_amdgcn_s_barrier();
     u32x4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
     read_frags(0, 0, fa0, fb0);
@@ -945,7 +1053,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
 #endif
       constexpr int NA = (!HAS_NEXT || !ETAINV_RING_EARLY_SYNC) ? MT * NT
                          : (ETAINV_RING_NA_BASE + (HAS_PB ? B_PASSES : 0) + 2 < MT * NT ? ETAINV_RING_NA_BASE + (HAS_PB ? B_PASSES : 0) + 2 : MT * NT);
-      read_frags(slot, 1, fa1, fb1);
+      read_frags(slot, 1, fa1, fb1, ct_gq, ct_tap);
       if constexpr (HAS_PB) issue_b(pslot);
       mfma_range(fa0, fb0, std::integral_constant<int, 0>{}, std::integral_constant<int, NA>{});
 #ifndef ETAINV_W1_READS1
@@ -1001,7 +1109,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         // ---- window 1b + 2: the rest of the F0 cluster, then the F1 cluster with the F0 reads of the next step and the
         // activation pieces of step s+3
         mfma_range(fa0, fb0, std::integral_constant<int, NA>{}, std::integral_constant<int, MT * NT>{});
-        read_frags(nslot, 0, fa0, fb0);
+        read_frags(nslot, 0, fa0, fb0, ct_tap == 8 ? ct_gq + 1 : ct_gq, ct_tap == 8 ? 0 : ct_tap + 1);
         if constexpr (HAS_ISSUE) issue_a(slot);
       }
       mfma_all(fa1, fb1);
@@ -1014,13 +1122,13 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         }
         if constexpr (HAS_ISSUE) {
 #pragma unroll
-          for (int q = 0; q < A_LOADS; ++q) {
+          for (int q = 0; q < (PATCH ? 1 : A_LOADS); ++q) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
             __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // 1 DMA piece
           }
         }
-        if constexpr (MT * NT - (MT + NT) - (HAS_ISSUE ? A_LOADS : 0) > 0)
-          __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT) - (HAS_ISSUE ? A_LOADS : 0), 0);
+        if constexpr (MT * NT - (MT + NT) - (HAS_ISSUE ? (PATCH ? 1 : A_LOADS) : 0) > 0)
+          __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT) - (HAS_ISSUE ? (PATCH ? 1 : A_LOADS) : 0), 0);
       }
       __builtin_amdgcn_sched_barrier(0);
 #ifdef ETAINV_IGEMM_STAMPS
@@ -1028,6 +1136,9 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       st_w1 += t1 - t0; st_wait += t2 - t1; st_bar += t3 - t2; st_w2 += t4 - t3;
 #endif
       // ---- step end
+      if constexpr (PATCH) {
+        if (++ct_tap == 9) { ct_tap = 0; ++ct_gq; }
+      }
       if (++ct_kt == nk) {
         int m0, n0;
         tile_origin(ct_tile, m0, n0);
@@ -1112,7 +1223,7 @@ static int pick_xcd_gn(const IGemmParams& p, int BM, int BN, int grid, int tiles
   return forced > 1 ? 1 : best;
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int STAGES = 2, bool UPS = false, int LN = 0>
+template <typename T, int BM, int BN, int WAVES_M, int STAGES = 2, bool UPS = false, int LN = 0, bool PATCH = false>
 static int launch_igemm_t(const IGemmParams& p_in, hipStream_t s, int* stat_P = nullptr) {
   IGemmParams p = p_in;
   // Statistics producers: the fast epilogue (whole wave tiles inside one image and inside N) writes, for a LayerNorm (stat_kind 0), one (mean, M2)
@@ -1130,20 +1241,21 @@ static int launch_igemm_t(const IGemmParams& p_in, hipStream_t s, int* stat_P = 
   ETAINV_CHECK(!p.w_batch_stride || (p.rows_per_batch % BM == 0 && !p.geglu && p.taps == 1), "per-image weights: every M tile inside one image, plain 1x1");
   if constexpr (LN == 0) {   // one instantiation per role (the 256 x 128 ring only runs GEGLU: never a producer; fused upsample: GroupNorm producer only)
     if constexpr (!(STAGES == 3 && BN == 128)) {
-      if constexpr (!UPS)
-        if (p.stat_out && p.stat_kind == 0) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 1>(p, s, nullptr);
-      if (p.stat_out && p.stat_kind == 1) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 3>(p, s, nullptr);
+      if constexpr (!UPS && !PATCH)
+        if (p.stat_out && p.stat_kind == 0) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 1, PATCH>(p, s, nullptr);
+      if (p.stat_out && p.stat_kind == 1) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 3, PATCH>(p, s, nullptr);
     }
-    if constexpr (!UPS)
-      if (p.ln_stat) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 2>(p, s, nullptr);
+    if constexpr (!UPS && !PATCH)
+      if (p.ln_stat) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 2, PATCH>(p, s, nullptr);
   }
+  if constexpr (PATCH) p.stat_kind = p.stat_out ? 1 : 0;   // (a conv never emits LayerNorm row statistics)
   const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN) * (STAGES != 3 && p.ksplit > 1 ? p.ksplit : 1);   // virtual tiles with split-K
-  const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(T) + 4 * BN * sizeof(float) + (STAGES == 3 ? 1024 : 0) +
+  const size_t lds = (PATCH ? (size_t)(2 * 328 * 64 + STAGES * BN * BK) : (size_t)STAGES * (BM + BN) * BK) * sizeof(T) + 4 * BN * sizeof(float) + (STAGES == 3 ? 1024 : 0) +
                      (LN == 2 && STAGES == 3 && BN == 128 ? (size_t)4 * (BN + 2 * BM) * sizeof(float) : 0);   // staged s vectors and (mean, rstd) rows
   static bool attr_set[kMaxDevices] = {};   // per device: function attributes and the allocations below belong to the current device
   const int dev = current_device();
   if (!attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS, LN, PATCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set[dev] = true;
   }
   // persistent grid: as many blocks as are resident at once (LDS-limited: 160 KiB / lds per CU, 256 CUs), a multiple of 8
@@ -1157,7 +1269,7 @@ static int launch_igemm_t(const IGemmParams& p_in, hipStream_t s, int* stat_P = 
     (void)hipMemsetAsync(d_stamps, 0, 2048 * 8 * 8 * sizeof(uint64_t), s);
     ps.stamps = d_stamps;
   }
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS, LN>), dim3(grid), dim3(WAVES_M * 128), lds, s, ps);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS, LN, PATCH>), dim3(grid), dim3(WAVES_M * 128), lds, s, ps);
   if (ps.stamps) {
     (void)hipStreamSynchronize(s);
     std::vector<uint64_t> h((size_t)grid * 8 * 8);
@@ -1179,7 +1291,7 @@ static int launch_igemm_t(const IGemmParams& p_in, hipStream_t s, int* stat_P = 
 #endif
   p.xcd_gn = STAGES == 3 ? pick_xcd_gn(p, BM, BN, grid, tiles) : 1;
   ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.taps * (p.c1 + p.c2)), s, igemm_algo_bytes(p));
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS, LN>), dim3(grid), dim3(WAVES_M * 128), lds, s, p);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS, LN, PATCH>), dim3(grid), dim3(WAVES_M * 128), lds, s, p);
   ETAINV_LAUNCH_CHECK();
   return 0;
 }
@@ -1257,6 +1369,12 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   if (!p.geglu && p.ups && p.N % 160 == 0 && huge_tiles >= ring_min && !getenv("ETAINV_NO_RING")) {
     // the ring's issue is branch-free, so the fused-upsample addressing is its own instantiation
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, true, 0>(p, s, stat_P)));
+  } else if (!p.geglu && p.taps == 9 && p.stride == 1 && !p.ups && !p.a2 && !p.pad0 && p.H % 16 == 0 && p.W % 16 == 0 && p.H == p.Ho && p.W == p.Wo &&
+             p.N % 160 == 0 && huge_tiles >= ring_min && !p.ln_stat && !p.out_nchw && !p.out_f32 && !p.w_batch_stride &&
+             (!p.stat_out || p.stat_kind == 1) && !(getenv("ETAINV_PATCHCONV") && atoi(getenv("ETAINV_PATCHCONV")) == 0) && !getenv("ETAINV_NO_RING")) {
+    // conv3x3 stride 1 on 16-pixel-aligned images: 16 x 16 pixel patches, the halo'd activation patch of a channel chunk loaded once for all nine taps
+    // (same-box A/B, 128 rows: -1 ... -5 % per launch from the 16 x 16 level up, +1 % on the benchmark step; ETAINV_PATCHCONV=0 keeps the tap-major tiles)
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, false, 0, true>(p, s, stat_P)));
   } else if (!p.geglu && p.N % 160 == 0 && huge_tiles >= ring_min && ln_ring_ok && !getenv("ETAINV_NO_RING")) {
     // experimental (opt-in): 256 x 160 x 64 tile, 8 waves, one resident block per CU (26 % fewer L2 -> LDS bytes per
     // FLOP).  Measured equal to 128 x 160 with two resident blocks (1026 vs 1033 TFLOP/s on conv 1280->1280 @16x16)
