@@ -882,10 +882,17 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       const int pr = (prow * 3641) >> 16, pc = prow - pr * PW;     // prow / 18 for prow < 1024
       const int y = pt_y0 - 1 + pr, x = pt_x0 - 1 + pc;
       const bool ok = real & (prow < PW * PW) & (y >= 0) & (y < p.H) & (x >= 0) & (x < p.W);
-      const T* src = reinterpret_cast<const T*>(p.a1);
-      const unsigned elem = ok ? (unsigned)(pt_e0 + (pr * p.W + pc) * p.c1 + (((lane & 7) ^ (pc & 7)) << 3)) : 0u;   // (halo lanes: offset 0 of the zero page)
-      const T* g = (ok ? src : zero_page) + elem;
-      T* dst = real ? sA + ps * (PROWS * BK) + id * 8 * BK : dummy;   // wave-uniform
+      // source = zero page + (ok ? (activations - zero page) + element offset : 0), computed for EVERY lane and masked: a conditional expression here
+      // is compiled into a divergent branch, which cuts window 2 in two (9 fragment reads and ~50 address instructions between 6 and 20 MFMAs with the
+      // matrix pipe idle: +200 cycles per step in the stamps)
+      const uint64_t zp = reinterpret_cast<uint64_t>(zero_page);
+      const uint64_t raw = (reinterpret_cast<uint64_t>(p.a1) - zp) +
+                           (uint64_t)(unsigned)(pt_e0 + (pr * p.W + pc) * p.c1 + (((lane & 7) ^ (pc & 7)) << 3)) * sizeof(T);
+      const uint64_t keep = ok ? ~0ull : 0ull;
+      const T* g = reinterpret_cast<const T*>(zp + (raw & keep));
+      // (wave-uniform, masked like the source: a select would become a scalar branch in the middle of the window)
+      const int dummy_el = (int)(dummy - sA), real_el = ps * (PROWS * BK) + id * 8 * BK;
+      T* dst = sA + __builtin_amdgcn_readfirstlane(dummy_el + ((real_el - dummy_el) & -(int)real));
 #ifdef ETAINV_ABL_PATCH_ZERO   // timing experiment only (wrong results): every piece reads the zero page
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)zero_page, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       return;

@@ -1,8 +1,8 @@
 mkdir -p gpurun_out/r04
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for i in 1 2; do
-ETAINV_PATCHCONV=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r04/n_bench_patch_$i.json 2> gpurun_out/r04/n_bench_patch_$i.err
-python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r04/n_bench_ring_$i.json 2> gpurun_out/r04/n_bench_ring_$i.err
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r04/n_bench_patch_$i.json 2> gpurun_out/r04/n_bench_patch_$i.err
+ETAINV_PATCHCONV=0 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r04/n_bench_ring_$i.json 2> gpurun_out/r04/n_bench_ring_$i.err
 done
 for f in gpurun_out/r04/n_bench_*.json; do python -c "
 import json
