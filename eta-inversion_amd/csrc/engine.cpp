@@ -121,6 +121,11 @@ struct etainv_engine {
        *ffbuf = nullptr, *ctxT = nullptr, *tembuf = nullptr, *temb1 = nullptr, *temb2 = nullptr;
   float *tprojbuf = nullptr, *gn_scratch = nullptr, *maps_acc = nullptr, *lnstat = nullptr, *lnfinal = nullptr;
   size_t maps_bytes = 0;
+  // which cross layers the store keeps (etainv_maps_configure): map_div 4 = the five (L/4)^2 layers (default; what LocalBlend and the default eta mask
+  // read), 2 = the five (L/2)^2 layers (own lazily allocated buffer, 4x the size), 8 = the mid block's (L/8)^2 layer.  maps_cur = the buffer in use
+  int map_div = 4, map_layers = 5;
+  float *maps_alt = nullptr, *maps_cur = nullptr;
+  size_t maps_alt_bytes = 0, maps_cur_bytes = 0;
   // norm1/2/3 of the transformer blocks folded into the GEMMs around them (no LayerNorm pass over HBM); ETAINV_LN_UNFUSED=1 keeps the
   // standalone LayerNorm kernel (A/B switch, read at engine creation)
   // GroupNorm statistics from the epilogue of the GEMM / conv that wrote the tensor (per-channel partials per wave-tile row block, one buffer per
@@ -439,6 +444,8 @@ int build_workspace(etainv_engine* e) {
   for (int i = 0; i < 3; ++i) e->gn_bufs[12 + i] = e->tmp[i];
   e->gn_bufs[15] = e->h1;
   ETAINV_HIP(hipMemset(e->maps_acc, 0, e->maps_bytes));
+  e->maps_cur = e->maps_acc;
+  e->maps_cur_bytes = e->maps_bytes;
   return 0;
 }
 
@@ -644,7 +651,7 @@ struct Fwd {
     cp.scale_log2 = (1.0f / std::sqrt((float)d)) * 1.4426950408889634f;
     cp.rows = rows;
     cp.n_img_cap = e->max_img;
-    cp.maps_acc = e->maps_acc;
+    cp.maps_acc = e->maps_cur;
     if (ctrl && (ctrl->mode == ETAINV_ATTN_PTP || ctrl->mode == ETAINV_ATTN_STORE)) {
       cp.n_img = ctrl->n_img;
       cp.layout = ctrl->mode == ETAINV_ATTN_PTP ? (ctrl->src_exit_block ? 3 : 2) : 1;   // 3: rows [u_t, c_t, c_s] (cond source rows leave early)
@@ -657,11 +664,13 @@ struct Fwd {
         cp.equalizer = ctrl->equalizer;
         cp.cross_alpha = ctrl->cross_alpha;
       }
-      const int res = e->L / 4;
+      const int res = e->L / e->map_div;
       if (ctrl->store_maps && hw == res * res) {
-        // the five (L/4)^2-token cross layers: transformer blocks 4,5 (down) and 7,8,9 (up)
-        static const int layer_of_block[16] = {-1, -1, -1, -1, 0, 1, -1, 2, 3, 4, -1, -1, -1, -1, -1, -1};
-        cp.map_layer = layer_of_block[blk];
+        // the five (L/4)^2-token cross layers: transformer blocks 4,5 (down) and 7,8,9 (up); (L/2)^2: 2,3 and 10,11,12; (L/8)^2: the mid block 6
+        static const int layer_of_block[3][16] = {{-1, -1, 0, 1, -1, -1, -1, -1, -1, -1, 2, 3, 4, -1, -1, -1},
+                                                  {-1, -1, -1, -1, 0, 1, -1, 2, 3, 4, -1, -1, -1, -1, -1, -1},
+                                                  {-1, -1, -1, -1, -1, -1, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1}};
+        cp.map_layer = layer_of_block[e->map_div == 2 ? 0 : e->map_div == 4 ? 1 : 2][blk];
       }
     }
     if (launch_cross_attention_p(e->qbuf, kvb, e->attnbuf, rows, d, cp, e->dt, s)) return 1;
@@ -728,6 +737,7 @@ extern "C" int etainv_engine_destroy(etainv_engine_t* e) {
   }
   if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
   if (e->warena) (void)hipFree(e->warena);
+  if (e->maps_alt) (void)hipFree(e->maps_alt);
   if (e->wsarena) (void)hipFree(e->wsarena);
   delete e;
   return 0;
@@ -821,7 +831,7 @@ static int unet_graph(etainv_engine_t* e, const void* latent, int n_lat, const i
   for (int r = n_lat; t_pairs && r < n_rows; ++r) t_pairs = t_host[r] == t_host[r - n_lat];
   const bool reuse = e->ctx_cache_on && e->ctx_cached == ctx && e->ctx_rows == n_rows && e->ctx_io == io_dtype && e->ctx_gen_cached == e->ctx_gen;
   char key[160];
-  snprintf(key, sizeof key, "%d.%d.%d.%d.%d|%d.%d.%d.%d.%d.%d.%d.%d.%d", n_rows, n_lat, io_dtype, (int)t_pairs, (int)reuse, ctrl ? ctrl->mode : -1,
+  snprintf(key, sizeof key, "%d.%d.%d.%d.%d.%d|%d.%d.%d.%d.%d.%d.%d.%d.%d", n_rows, n_lat, io_dtype, (int)t_pairs, (int)reuse, e->map_div, ctrl ? ctrl->mode : -1,
            ctrl ? ctrl->n_img : 0, ctrl ? ctrl->store_maps : 0, ctrl ? ctrl->self_replace_active : 0, ctrl ? ctrl->self_max_tokens : 0,
            ctrl ? ctrl->masa_active : 0, ctrl ? ctrl->masa_first_block : 0, ctrl ? ctrl->first_row : 0, ctrl ? ctrl->src_exit_block : 0);
   auto& ge = e->graphs[key];
@@ -1042,26 +1052,62 @@ static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const in
 
 extern "C" int etainv_maps_reset(etainv_engine_t* e, void* stream) {
   ETAINV_CHECK(e, "null engine");
-  ETAINV_HIP(hipMemsetAsync(e->maps_acc, 0, e->maps_bytes, (hipStream_t)stream));
+  ETAINV_HIP(hipMemsetAsync(e->maps_cur, 0, e->maps_cur_bytes, (hipStream_t)stream));
   return 0;
+}
+
+extern "C" int etainv_maps_configure(etainv_engine_t* e, int res_div, void* stream) {
+  ETAINV_CHECK(e, "null engine");
+  ETAINV_CHECK(res_div == 2 || res_div == 4 || res_div == 8, "res_div must be 2, 4 or 8 (the (L/2)^2, (L/4)^2 cross layers or the mid block's (L/8)^2 layer)");
+  ETAINV_CHECK(e->L % res_div == 0, "latent size not divisible by res_div");
+  const int layers = res_div == 8 ? 1 : 5;
+  const size_t res = e->L / res_div;
+  const size_t bytes = (size_t)layers * e->max_img * 2 * etainv_engine::kHeads * res * res * 77 * 4;
+  if (bytes <= e->maps_bytes) {
+    e->maps_cur = e->maps_acc;
+  } else {
+    if (bytes > e->maps_alt_bytes) {   // first use of the (L/2)^2 store: its own allocation (host work, outside any capture)
+      ETAINV_HIP(hipStreamSynchronize((hipStream_t)stream));
+      if (e->maps_alt) ETAINV_HIP(hipFree(e->maps_alt));
+      e->maps_alt = nullptr;
+      e->maps_alt_bytes = 0;
+      ETAINV_HIP(hipMalloc(reinterpret_cast<void**>(&e->maps_alt), bytes));
+      e->maps_alt_bytes = bytes;
+    }
+    e->maps_cur = e->maps_alt;
+  }
+  e->maps_cur_bytes = bytes;
+  e->map_div = res_div;
+  e->map_layers = layers;
+  ETAINV_HIP(hipMemsetAsync(e->maps_cur, 0, e->maps_cur_bytes, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int etainv_maps_word_maps_ex(etainv_engine_t* e, int n_img, const int32_t* tokens, int n_tok, int steps_done, int row_sel, unsigned layer_mask,
+                                        float* out, int accumulate, float scale, void* stream) {
+  ETAINV_CHECK(e && n_img >= 1 && n_img <= e->max_img && (row_sel == 0 || row_sel == 1), "bad arguments");
+  ETAINV_CHECK((layer_mask & ((1u << e->map_layers) - 1u)) != 0, "layer_mask selects none of the stored layers");
+  return launch_word_maps(e->maps_cur, e->map_layers, e->max_img, 2, row_sel, etainv_engine::kHeads, e->L / e->map_div, e->L, n_img, tokens, n_tok,
+                          steps_done, out, accumulate, scale, (hipStream_t)stream, layer_mask);
 }
 
 extern "C" int etainv_maps_word_maps(etainv_engine_t* e, int n_img, const int32_t* tokens, int n_tok, int steps_done, float* out,
                                      int accumulate, float scale, void* stream) {
   ETAINV_CHECK(e && n_img >= 1 && n_img <= e->max_img, "bad arguments");
-  return launch_word_maps(e->maps_acc, 5, e->max_img, 2, 0, etainv_engine::kHeads, e->L / 4, e->L, n_img, tokens, n_tok, steps_done, out,
+  return launch_word_maps(e->maps_cur, e->map_layers, e->max_img, 2, 0, etainv_engine::kHeads, e->L / e->map_div, e->L, n_img, tokens, n_tok, steps_done, out,
                           accumulate, scale, (hipStream_t)stream);
 }
 
 extern "C" int etainv_maps_word_maps_role(etainv_engine_t* e, int n_img, const int32_t* tokens, int n_tok, int steps_done, int row_sel,
                                           float* out, int accumulate, float scale, void* stream) {
   ETAINV_CHECK(e && n_img >= 1 && n_img <= e->max_img && (row_sel == 0 || row_sel == 1), "bad arguments");
-  return launch_word_maps(e->maps_acc, 5, e->max_img, 2, row_sel, etainv_engine::kHeads, e->L / 4, e->L, n_img, tokens, n_tok, steps_done, out,
+  return launch_word_maps(e->maps_cur, e->map_layers, e->max_img, 2, row_sel, etainv_engine::kHeads, e->L / e->map_div, e->L, n_img, tokens, n_tok, steps_done, out,
                           accumulate, scale, (hipStream_t)stream);
 }
 
 extern "C" int etainv_local_blend(etainv_engine_t* e, float* x, int n_img, const float* blend_alpha, float thres, void* stream) {
   ETAINV_CHECK(e && n_img >= 1 && n_img <= e->max_img, "bad arguments");
+  ETAINV_CHECK(e->map_div == 4, "LocalBlend reads the five (L/4)^2 cross layers (ptp.py:37-39): etainv_maps_configure(e, 4, ...) first");
   return launch_local_blend(e->maps_acc, 5, e->max_img, etainv_engine::kHeads, e->L / 4, e->L, x, n_img, blend_alpha, thres,
                             (hipStream_t)stream);
 }

@@ -151,7 +151,7 @@ int launch_cast_f32(const void* src, int src_dtype, void* dst, int dst_dtype, in
 // ---- maps.hip
 int launch_word_maps(const float* maps_acc, int n_layers, int n_img_cap, int rows_per_img, int row_sel, int heads, int res, int L,
                      int n_img, const int32_t* tokens, int n_tok, int steps_done, float* out, int accumulate, float scale,
-                     hipStream_t s);
+                     hipStream_t s, unsigned layer_mask = ~0u);
 int launch_local_blend(const float* maps_acc, int n_layers, int n_img_cap, int heads, int res, int L, float* x, int n_img,
                        const float* blend_alpha, float thres, hipStream_t s);
 

@@ -23,7 +23,7 @@ __device__ __forceinline__ void cubic_coeffs(float t, float (&w)[4]) {
 // grid (n_tok, n_img), 256 threads.  out [n_img][n_tok][L][L]
 __global__ void __launch_bounds__(256) word_maps_kernel(const float* __restrict__ acc, int n_layers, int n_img_cap, int row_sel,
                                                         int heads, int res, int L, const int32_t* __restrict__ tokens, int n_tok,
-                                                        float inv_steps, float* __restrict__ out, int accumulate, float scale) {
+                                                        float inv_steps, float* __restrict__ out, int accumulate, float scale, unsigned layer_mask) {
   extern __shared__ float sm[];  // [res*res] aggregated map, then sm[res*res .. +4] reduction scratch
   const int img = blockIdx.y, ti = blockIdx.x;
   const int tok = tokens[img * n_tok + ti];
@@ -37,9 +37,10 @@ __global__ void __launch_bounds__(256) word_maps_kernel(const float* __restrict_
   for (int pix = threadIdx.x; pix < RR; pix += blockDim.x) {
     float s = 0.f;
     for (int l = 0; l < n_layers; ++l)
-      for (int h = 0; h < heads; ++h)
-        s += acc[(((((int64_t)l * n_img_cap + img) * 2 + row_sel) * heads + h) * RR + pix) * 77 + tok] * inv_steps;
-    s /= (float)(n_layers * heads);
+      if ((layer_mask >> l) & 1u)      // `from_where` of aggregate_attention (ptp.py:296-300): layers 0,1 = down, 2.. = up
+        for (int h = 0; h < heads; ++h)
+          s += acc[(((((int64_t)l * n_img_cap + img) * 2 + row_sel) * heads + h) * RR + pix) * 77 + tok] * inv_steps;
+    s /= (float)(__builtin_popcount(layer_mask & ((1u << n_layers) - 1u)) * heads);
     sm[pix] = s;
     lmax = fmaxf(lmax, s);
   }
@@ -155,12 +156,13 @@ __global__ void __launch_bounds__(256) local_blend_kernel(const float* __restric
 
 int launch_word_maps(const float* maps_acc, int n_layers, int n_img_cap, int rows_per_img, int row_sel, int heads, int res, int L,
                      int n_img, const int32_t* tokens, int n_tok, int steps_done, float* out, int accumulate, float scale,
-                     hipStream_t s) {
+                     hipStream_t s, unsigned layer_mask) {
   (void)rows_per_img;
   ETAINV_CHECK(maps_acc && tokens && out && n_img > 0 && n_tok > 0 && steps_done > 0, "bad arguments");
+  ETAINV_CHECK(n_layers >= 1 && n_layers <= 31 && (layer_mask & ((1u << n_layers) - 1u)) != 0, "no layer selected");
   const size_t lds = (size_t)(res * res + 8) * sizeof(float);
   hipLaunchKernelGGL(word_maps_kernel, dim3(n_tok, n_img), dim3(256), lds, s, maps_acc, n_layers, n_img_cap, row_sel, heads, res, L,
-                     tokens, n_tok, 1.0f / (float)steps_done, out, accumulate, scale);
+                     tokens, n_tok, 1.0f / (float)steps_done, out, accumulate, scale, layer_mask);
   ETAINV_LAUNCH_CHECK();
   return 0;
 }

@@ -49,6 +49,8 @@ SIGNATURES = {
     "etainv_maps_reset": [_p, _p],
     "etainv_maps_word_maps": [_p, _i, _p, _i, _i, _p, _i, _f, _p],
     "etainv_maps_word_maps_role": [_p, _i, _p, _i, _i, _i, _p, _i, _f, _p],
+    "etainv_maps_configure": [_p, _i, _p],
+    "etainv_maps_word_maps_ex": [_p, _i, _p, _i, _i, _i, C.c_uint, _p, _i, _f, _p],
     "etainv_local_blend": [_p, _p, _i, _p, _f, _p],
     "etainv_engine_graph_stats": [_p, C.POINTER(_i64), C.POINTER(_i64)],
     "etainv_engine_workspace_bytes": [_p],

@@ -40,6 +40,7 @@ class Engine:
         h = C.c_void_p()
         _capi.check(self.lib.etainv_engine_create(C.byref(cfg), C.byref(h)))
         self.h = h
+        self.map_div = 4
 
     def close(self):
         if getattr(self, "h", None):
@@ -124,6 +125,17 @@ class Engine:
         """maps of one role of the backward-pass store (0 source, 1 target cond row), averaged over `steps_done` steps"""
         _capi.check(self.lib.etainv_maps_word_maps_role(self.h, n_img, _capi.ptr(tokens), tokens.shape[1], steps_done, row_sel, _capi.ptr(out),
                                                         0, 1.0, _capi.stream_ptr()))
+        return out
+
+    def maps_configure(self, res_div=4):
+        """which cross layers the attention-map store keeps: 4 = the five (L/4)^2 layers (default), 2 = the (L/2)^2 layers, 8 = the mid block's; clears the store"""
+        _capi.check(self.lib.etainv_maps_configure(self.h, int(res_div), _capi.stream_ptr()))
+        self.map_div = int(res_div)
+
+    def word_maps_ex(self, n_img, tokens, steps_done, row_sel, layer_mask, out, accumulate=False, scale=1.0):
+        """word maps over the layers selected by `layer_mask` (bits: down 0x03, up 0x1c; res_div 8: mid 0x01)"""
+        _capi.check(self.lib.etainv_maps_word_maps_ex(self.h, n_img, _capi.ptr(tokens), tokens.shape[1], steps_done, int(row_sel), int(layer_mask),
+                                                      _capi.ptr(out), int(accumulate), float(scale), _capi.stream_ptr()))
         return out
 
     def cache_context(self, enable):

@@ -48,12 +48,34 @@ def _env_on(name):
     return os.environ.get(name, "0") not in ("", "0")
 
 
+def attn_layer_selection(L, attn_res=None, attn_from_where=("up", "down")):
+    """(res_div, layer mask) of etainv_maps_configure / etainv_maps_word_maps_ex for the reference's (attn_res, attn_from_where)"""
+    attn_res = L // 4 if attn_res is None else int(attn_res)
+    if attn_res <= 0 or L % attn_res or L // attn_res not in (2, 4, 8):
+        raise NotImplementedError(f"attn_res must be L/2, L/4 or L/8 (cross layers exist at those sizes only), got {attn_res} at L = {L}")
+    div = L // attn_res
+    if div == 8:                                                # ptp.py:293-294 (`res == 8` at the reference's 64 x 64 latents)
+        return div, 0x01
+    where = set(attn_from_where)
+    if not where <= {"up", "down", "mid"}:
+        raise ValueError(f"attn_from_where entries must be 'up', 'down' or 'mid', got {sorted(where)}")
+    mask = (0x03 if "down" in where else 0) | (0x1c if "up" in where else 0)
+    if mask == 0:
+        raise ValueError(f"attn_from_where {sorted(where)} has no cross layer with {attn_res}^2 tokens (the reference fails in torch.cat, ptp.py:301)")
+    return div, mask
+
+
 class EtaLoop:
 
     def __init__(self, engine, S=50, guidance_scale_bwd=7.5, guidance_scale_fwd=1.0, eta=(0.0, 0.4), noise_sample_count=10,
                  use_mask=True, mask_thres=0.2, skip_uncond_fwd=True, steps_offset=0, mask_eta="fwd_mean", mask_pow=None, target_dirinv=None,
-                 mask_dirinv=None, skip_dead_source_rows=True):
+                 mask_dirinv=None, skip_dead_source_rows=True, attn_res=None, attn_from_where=("up", "down")):
         self.e, self.S, self.L = engine, S, engine.L
+        # which cross layers the eta mask's word maps average (mask_mode_cfg attn_res / attn_from_where, eta_inversion.py:161-162; aggregate_attention
+        # ptp.py:288-303: the layers with res^2 tokens of the named locations, `res == 8` -> the mid block whatever from_where says)
+        self.attn_div, self.attn_layer_mask = attn_layer_selection(self.L, attn_res, attn_from_where)
+        if use_mask and self.attn_div != 4 and any(str(m).startswith("bwd") for m in (mask_eta, mask_dirinv)):
+            raise NotImplementedError("bwd_* mask sources with attn_res != L/4: the backward pass keeps the (L/4)^2 store LocalBlend reads")
         # guidance_scale_fwd may be a (start, end) pair: linspace over the 1000 training timesteps, indexed by t (eta_inversion.py:108-110,325-326)
         self.g_fwd_table = np.linspace(guidance_scale_fwd[0], guidance_scale_fwd[1], NUM_TRAIN) if isinstance(guidance_scale_fwd, (tuple, list)) else None
         self.g_bwd, self.g_fwd = float(guidance_scale_bwd), (1.0 if self.g_fwd_table is not None else float(guidance_scale_fwd))
@@ -121,7 +143,10 @@ class EtaLoop:
             if "fwd" in (self.mask_eta, self.mask_dirinv):                        # per-step maps, keyed by step (eta_inversion.py:44-49,168)
                 maps_steps = torch.zeros(S, B, tokens.shape[1], L, L, dtype=torch.float32, device=dev)
             ctrl = AttnControl(mode=_capi.ATTN_STORE, n_img=B, store_maps=True)
-            e.maps_reset()
+            if e.map_div != self.attn_div:
+                e.maps_configure(self.attn_div)                                   # (clears the store)
+            else:
+                e.maps_reset()
         n = B * 4 * L * L
         st = _capi.stream_ptr()
         with e.cached_context():                               # one unchanged context tensor for all S calls
@@ -136,9 +161,9 @@ class EtaLoop:
                 a_from, a_to = self._alpha(int(t) - self.delta), self._alpha(int(t))   # "sameshift" (scheduling_ddim_inverse.py:127-131)
                 _capi.check(self.lib.etainv_ddim_step(_capi.ptr(x_in), _capi.ptr(eps), a_from, a_to, _capi.ptr(lat[j + 1]), n, _capi.F32, st))
                 if self.use_mask:
-                    e.word_maps(B, tokens, j + 1, maps_mean, accumulate=True, scale=1.0 / S)
+                    e.word_maps_ex(B, tokens, j + 1, 0, self.attn_layer_mask, maps_mean, accumulate=True, scale=1.0 / S)
                     if maps_steps is not None:
-                        e.word_maps(B, tokens, j + 1, maps_steps[j], accumulate=False, scale=1.0)
+                        e.word_maps_ex(B, tokens, j + 1, 0, self.attn_layer_mask, maps_steps[j], accumulate=False, scale=1.0)
         return {"latents": lat, "maps_mean": maps_mean, "maps_steps": maps_steps}
 
     # ---------------------------------------------------------------- backward / eta sampling
@@ -191,13 +216,16 @@ class EtaLoop:
                 if name == "fwd":                                                   # map of THIS timestep (t_bwd[i] == t_fwd[S-1-i])
                     return inv["maps_steps"][S - 1 - i].gather(1, idx).reshape(B, L, L)
                 if name != "bwd_target":                                            # average over the i+1 backward steps done, this one included
-                    e.word_maps_role(B, tok_s, i + 1, 0, map_s)
+                    e.word_maps_ex(B, tok_s, i + 1, 0, self.attn_layer_mask, map_s)
                 if name != "bwd_source":
-                    e.word_maps_role(B, tok_t, i + 1, 1, map_t)
+                    e.word_maps_ex(B, tok_t, i + 1, 1, self.attn_layer_mask, map_t)
                 m = map_s if name == "bwd_source" else map_t if name == "bwd_target" else torch.maximum(map_s, map_t)
                 return m.reshape(B, L, L)
         if ptp is not None:
-            e.maps_reset()
+            if e.map_div != 4:
+                e.maps_configure(4)                                                  # LocalBlend and the bwd_* sources read the (L/4)^2 layers
+            else:
+                e.maps_reset()
         ctx3 = eps3 = ctx3x = eps3x = None
         eps_t = torch.empty(B, 4, L, L, dtype=torch.float32, device=dev)
         st = _capi.stream_ptr()

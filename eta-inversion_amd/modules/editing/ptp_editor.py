@@ -19,7 +19,8 @@ class PromptToPromptControllerBase(ControllerBase):
 
     def begin(self) -> None:
         self.step_idx = 0
-        self.model.engine.maps_reset()                 # AttentionStore.reset (ptp.py:169-172)
+        e = self.model.engine                          # AttentionStore.reset (ptp.py:169-172); the backward-pass store keeps the (L/4)^2 layers (LocalBlend)
+        e.maps_configure(4) if e.map_div != 4 else e.maps_reset()
 
     def end(self) -> None:
         self.model.unet.attn_ctrl = None
@@ -56,11 +57,14 @@ class PromptToPromptControllerBase(ControllerBase):
         """word map of one prompt from the backward-pass store, averaged over the steps done (ptp_editor.py:43-85): (1, L, L)"""
         import torch
         e = self.model.engine
-        assert num_prompts == 2 and (res is None or res == e.L // 4) and (resize is None or resize == e.L), "store holds the five (L/4)^2 cross layers"
-        assert from_where is None or sorted(from_where) == ["down", "up"]
+        from etainv.pipeline import attn_layer_selection
+        assert num_prompts == 2 and (resize is None or resize == e.L)
+        div, mask = attn_layer_selection(e.L, res, from_where if from_where is not None else ("up", "down"))
+        if div != e.map_div:
+            raise NotImplementedError(f"the backward-pass store holds the (L/{e.map_div})^2 cross layers (LocalBlend reads those), not res = {res}")
         tok = torch.tensor([[mask_idx + 1]], dtype=torch.int32, device=self.model.device)
         out = torch.empty(1, 1, e.L, e.L, dtype=torch.float32, device=self.model.device)
-        e.word_maps_role(1, tok, self.step_idx + 1, prompt_idx, out)
+        e.word_maps_ex(1, tok, self.step_idx + 1, prompt_idx, mask, out)
         return out[0]
 
 

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from etainv import _capi
-from etainv.pipeline import EtaLoop, PtpTables, eta_table
+from etainv.pipeline import EtaLoop, PtpTables, attn_layer_selection, eta_table
 from ..editing.controller import ControllerEmpty
 from .diffusion_inversion import DiffusionInversion
 
@@ -27,10 +27,9 @@ class EtaInversion(DiffusionInversion):
             srcs = ("fwd_mean", "fwd", "gt", "bwd_source", "bwd_target", "bwd_source_target")
             if mask_mode_cfg["mask_eta"] not in srcs + (None,) or mask_mode_cfg["mask_dirinv"] not in srcs + (None,):
                 raise ValueError(f"mask_eta / mask_dirinv must be one of {srcs} or None (reference eta_inversion.py:164-187)")
-            # the engine stores and aggregates exactly what the reference's defaults read: the five (L/4)^2 up + down cross layers
-            if mask_mode_cfg["attn_res"] != model.engine.L // 4 or sorted(mask_mode_cfg["attn_from_where"]) != ["down", "up"]:
-                raise NotImplementedError(f"attn_res must be L/4 = {model.engine.L // 4} and attn_from_where ['up', 'down']: the native attention-map "
-                                          "store only keeps those layers")
+            # the engine's store keeps the cross layers of ONE resolution per pass (etainv_maps_configure): L/4 (default), L/2 or L/8 for the forward-pass
+            # sources; the backward pass always keeps L/4 (LocalBlend), so bwd_* sources take `attn_from_where` subsets at L/4 only
+            attn_layer_selection(model.engine.L, mask_mode_cfg["attn_res"], mask_mode_cfg["attn_from_where"])   # raises on what cannot be served
         else:
             mask_mode_cfg = None
         self.mask_mode_cfg = mask_mode_cfg
@@ -56,7 +55,8 @@ class EtaInversion(DiffusionInversion):
                              guidance_scale_fwd=self._g_fwd_pair or self.guidance_scale_fwd, eta=eta, noise_sample_count=noise_sample_count,
                              use_mask=use_mask and mask_mode_cfg["mask_eta"] is not None, mask_thres=(mask_mode_cfg or {}).get("thres", 0.2),
                              mask_eta=(mask_mode_cfg or {}).get("mask_eta", "fwd_mean"), mask_pow=(mask_mode_cfg or {}).get("pow"),
-                             target_dirinv=(mask_mode_cfg or {}).get("target_dirinv"), mask_dirinv=(mask_mode_cfg or {}).get("mask_dirinv"))
+                             target_dirinv=(mask_mode_cfg or {}).get("target_dirinv"), mask_dirinv=(mask_mode_cfg or {}).get("mask_dirinv"),
+                             attn_res=(mask_mode_cfg or {}).get("attn_res"), attn_from_where=(mask_mode_cfg or {}).get("attn_from_where", ("up", "down")))
 
     # ------------------------------------------------------------------ noise / mask
     def sample_variance_noise(self, n: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:

@@ -180,6 +180,17 @@ int etainv_maps_word_maps(etainv_engine_t* e, int n_img, const int32_t* tokens, 
 int etainv_maps_word_maps_role(etainv_engine_t* e, int n_img, const int32_t* tokens, int n_tok, int steps_done, int row_sel, float* out,
                                int accumulate, float scale, void* stream);
 
+/* Which cross-attention layers the store keeps: res_div 4 (default) = the five (L/4)^2 layers [down, down, up, up, up]; 2 = the five (L/2)^2 layers
+ * (same order; allocated on first use, 4x the default store); 8 = the mid block's (L/8)^2 layer.  Non-default `attn_res` of the eta mask
+ * (modules/inversion/eta_inversion.py:161; aggregate_attention keeps the layers whose token count is res^2, modules/utils/ptp.py:288-303).  Clears the
+ * store.  LocalBlend needs res_div 4. */
+int etainv_maps_configure(etainv_engine_t* e, int res_div, void* stream);
+/* etainv_maps_word_maps_role with `attn_from_where` (eta_inversion.py:162) as a mask over the stored layers: bit l = layer l of the order above
+ * ("down" = 0x03, "up" = 0x1c, both = 0x1f; res_div 8: bit 0 = "mid").  A mask that selects no stored layer is an error (the reference fails in
+ * torch.cat of an empty list, ptp.py:301). */
+int etainv_maps_word_maps_ex(etainv_engine_t* e, int n_img, const int32_t* tokens, int n_tok, int steps_done, int row_sel, unsigned layer_mask,
+                             float* out, int accumulate, float scale, void* stream);
+
 /* LocalBlend (modules/utils/ptp.py:18-47) on the backward latents x [2*n_img][4][L][L] (in place, fp32):
  * blend_alpha [n_img][2][77] selects the blend-word tokens of (source, target) prompt. */
 int etainv_local_blend(etainv_engine_t* e, float* x, int n_img, const float* blend_alpha, float thres, void* stream);

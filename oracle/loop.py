@@ -94,7 +94,8 @@ class MasaCtrl:
 # --------------------------------------------------------------------------- the loops
 class EtaInversionOracle:
     def __init__(self, unet, S=50, guidance_scale_bwd=7.5, guidance_scale_fwd=1, eta=(0.0, 0.4),
-                 noise_sample_count=10, use_mask=True, thres=0.2, L=64, dtype=torch.float32, mask_eta="fwd_mean", mask_pow=None, target_dirinv=None, mask_dirinv=None):
+                 noise_sample_count=10, use_mask=True, thres=0.2, L=64, dtype=torch.float32, mask_eta="fwd_mean", mask_pow=None, target_dirinv=None, mask_dirinv=None,
+                 attn_res=None, attn_from_where=("up", "down")):
         self.unet, self.S, self.L, self.dtype = unet, S, L, dtype
         self.g_bwd, self.g_fwd = guidance_scale_bwd, guidance_scale_fwd
         if isinstance(guidance_scale_fwd, (tuple, list)):                     # per-timestep table, eta_inversion.py:108-110,325-326
@@ -106,7 +107,8 @@ class EtaInversionOracle:
         self.use_mask, self.thres = use_mask, thres
         self.mask_eta, self.mask_pow = mask_eta, mask_pow     # eta_inversion.py:164-201 (gt / fwd / fwd_mean; thres None; pow)
         self.target_dirinv, self.mask_dirinv = target_dirinv, mask_dirinv   # eta_inversion.py:251-256
-        self.attn_res = L // 4                  # 16 at L=64 (eta_inversion.py:90)
+        self.attn_res = attn_res if attn_res is not None else L // 4     # 16 at L=64 (eta_inversion.py:90); mask_mode_cfg["attn_res"] (:161)
+        self.attn_from_where = tuple(attn_from_where)                      # mask_mode_cfg["attn_from_where"] (:162)
         self.thres_n = (L // 2) ** 2            # 32^2 at L=64 (ptp.py:153,226)
 
     # eta_inversion.py:319-328
@@ -139,7 +141,7 @@ class EtaInversionOracle:
                 latent = sch.ddim_step(latent, eps, a_from, a_to)
                 if store is not None:                                     # eta_inversion.py:44-49
                     maps_per_t[int(t)] = [
-                        optp.attention_map(store, ti, res=self.attn_res, from_where=("up", "down"), resize=self.L)
+                        optp.attention_map(store, ti, res=self.attn_res, from_where=self.attn_from_where, resize=self.L)
                         for ti in tok_idx]
                 noise_preds.append(eps)
                 latents.append(latent)
@@ -173,7 +175,7 @@ class EtaInversionOracle:
         if source == "fwd_mean":
             return inv["attn_maps_mean"][ew[0]]                               # eta_inversion.py:171
         # eta_inversion.py:176-183: maps of the backward-pass controller, averaged over the steps done so far (this one included)
-        amap = lambda word, sel: optp.attention_map(controller, word + 1, res=self.attn_res, from_where=("up", "down"), resize=self.L,
+        amap = lambda word, sel: optp.attention_map(controller, word + 1, res=self.attn_res, from_where=self.attn_from_where, resize=self.L,
                                                     num_prompts=2, select=sel)
         if source == "bwd_source":
             return amap(ew[0], 0)

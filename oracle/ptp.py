@@ -272,7 +272,8 @@ def aggregate_attention(store: AttentionStore, res: int, from_where, num_prompts
 
 def attention_map(store, token_idx: int, res=16, from_where=("up", "down"), resize=64, num_prompts=1, select=0):
     """ptp_editor.py:43-85: per-token map / max, bicubic -> (1,resize,resize), clamp [0,1]."""
-    m = aggregate_attention(store, res, from_where, num_prompts, select, mid_res=res // 2)[:, :, token_idx][None]
+    # (`res == 8` in the reference = the mid block's side at its 64 x 64 latents: resize / 8 here; a caller without `resize` keeps the default pairing)
+    m = aggregate_attention(store, res, from_where, num_prompts, select, mid_res=resize // 8 if resize else res // 2)[:, :, token_idx][None]
     m = m / m.max()
     if resize is not None and m.shape[-2:] != (resize, resize):
         m = F.interpolate(m[None], (resize, resize), mode="bicubic")[0].clamp(0, 1)

@@ -614,6 +614,32 @@ def gen_e2e_bwdmask(S=2):
     save("e2e_bwdmask", **out)
 
 
+ATTNRES_CASES = {"res32": dict(attn_res=32), "up_only": dict(attn_from_where=["up"]), "mid8": dict(attn_res=8),
+                 "down_bwd": dict(attn_from_where=["down"], mask_eta="bwd_source_target", thres=0.15)}
+
+
+def gen_e2e_attnres(S=2):
+    """EtaInversion with non-default `attn_res` / `attn_from_where` of the eta mask (eta_inversion.py:161-162: the (L/2)^2 cross layers, the up or
+    the down blocks only, the mid block's 8 x 8 map; forward-pass and backward-pass sources) + ptp editor on the toy UNet."""
+    from modules.inversion.eta_inversion import EtaInversion
+    from modules.editing.ptp_editor import PromptToPromptEditor
+    src, tgt = PROMPT_PAIRS[0]
+    unet = toy_unet(0)
+    z0 = 0.8 * torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(2027))
+    ptp_cfg = dict(is_replace_controller=False, prompts=[src, tgt], cross_replace_steps={"default_": .4},
+                   self_replace_steps=0.6, blend_words=(("cat",), ("tiger",)),
+                   equilizer_params={"words": ("tiger",), "values": (2,)})
+    out = {"z0": z0, "S": np.array(S)}
+    for name, mm in ATTNRES_CASES.items():
+        pipe = make_pipe(unet)
+        inv = EtaInversion(pipe, scheduler="ddim", num_inference_steps=S, eta=(0.3, 0.6), noise_sample_count=10, seed=0, mask_mode_cfg=dict(mm))
+        res = PromptToPromptEditor(inv).edit(z0 / 0.18215, src, tgt, cfg={**ptp_cfg}, inv_cfg=dict(edit_word_idx=(1, 1)))
+        out[f"{name}/maps_mean"] = torch.stack(inv.attn_maps_forward["mean"])
+        out[f"{name}/latent_inv"] = res["latent_inv"]
+        out[f"{name}/latent"] = res["latent"]
+    save("e2e_attnres", **out)
+
+
 def gen_pie_bench():
     """reference dataset/pie_bench_data.py on a synthetic mapping_file.json (the real PIE-Bench is not in the container):
     records, edit_word_idx and decoded RLE masks"""
@@ -716,7 +742,7 @@ def gen_dpm_inverse():
 
 
 GENS = {"schedule": gen_schedule, "ddim_inverse": gen_ddim_inverse, "eta_step": gen_eta_step, "eta_step_modes": gen_eta_step_modes, "eta_step_dirinv": gen_eta_step_dirinv,
-        "ptp_tables": gen_ptp_tables, "ptp_algebra": gen_ptp_algebra, "masactrl": gen_masactrl, "e2e": gen_e2e, "e2e_dirinv": gen_e2e_dirinv, "e2e_bwdmask": gen_e2e_bwdmask, "pie_bench": gen_pie_bench,
+        "ptp_tables": gen_ptp_tables, "ptp_algebra": gen_ptp_algebra, "masactrl": gen_masactrl, "e2e": gen_e2e, "e2e_dirinv": gen_e2e_dirinv, "e2e_bwdmask": gen_e2e_bwdmask, "e2e_attnres": gen_e2e_attnres, "pie_bench": gen_pie_bench,
         "resnet_block": gen_resnet_block, "e2e_diffinv": gen_e2e_diffinv, "dpm_inverse": gen_dpm_inverse}
 
 

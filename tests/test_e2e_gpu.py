@@ -254,6 +254,98 @@ def test_bwd_mask_sources_vs_oracle(setup, mode):
     assert relerr(out[:B].cpu(), ref[:B]) < 1e-6 and relerr(out[B:].cpu(), ref[B:]) < 1.9e-2     # measured 8.5e-3 ... 9.6e-3 (round 3); bound at 2x
 
 
+# (name, attn_res as a divisor of L, attn_from_where, mask_eta): the (L/2)^2 layers, the up / the down blocks only, the mid block's map (attn_res = L/8
+# turns from_where into ["mid"], ptp.py:293-294), a from_where subset read from the backward-pass store
+ATTN_LAYER_CASES = [("half", 2, ("up", "down"), "fwd_mean"), ("up", 4, ("up",), "fwd_mean"), ("mid", 8, ("up", "down"), "fwd_mean"),
+                    ("down_bwd", 4, ("down",), "bwd_source_target")]
+
+
+@oracle_leg(cases=[(c[0],) for c in ATTN_LAYER_CASES])
+def leg_attn_layers(name):
+    from oracle import loop as oloop, ptp as optp
+    _, div, where, mask_eta = next(c for c in ATTN_LAYER_CASES if c[0] == name)
+    L, eta = 16, (0.3, 0.6)
+    pairs, z0, ctx_src, ctx_tgt = _inputs(L)
+    tok = optp.WordTokenizer()
+    noise = oloop.noise_table(S, 10, L, seed=0)
+    unet = oracle_unet()
+    ref, maps = [], []
+    with torch.no_grad():
+        for i, (src, tgt) in enumerate(pairs):
+            o = oloop.EtaInversionOracle(unet, S=S, eta=eta, L=L, use_mask=True, thres=None, mask_eta=mask_eta, attn_res=L // div, attn_from_where=where)   # soft mask: the map VALUES reach the latents
+            inv = o.invert(z0[i:i + 1], ctx_src[i], src)
+            maps.append(inv["attn_maps_mean"][1])
+            bw, tw = src.split(" ")[1], tgt.split(" ")[1]
+            controller = optp.make_edit_controller(src, tgt, S, tok, blend_words=((bw,), (tw,)), equilizer_params={"words": (tw,), "values": (2,)},
+                                                   res=L // 4, thres_n=(L // 2) ** 2, **PTP_CFG)
+            ref.append(o.sample(inv, ctx_src[i], ctx_tgt[i], noise, edit_word_idx=(1, 1), controller=controller))
+    return {"ref": torch.cat([torch.stack([r[0] for r in ref]), torch.stack([r[1] for r in ref])]), "maps": torch.cat(maps)}
+
+
+@pytest.mark.parametrize("case", ATTN_LAYER_CASES, ids=[c[0] for c in ATTN_LAYER_CASES])
+def test_attn_res_and_from_where_vs_oracle(setup, case):
+    """non-default `attn_res` / `attn_from_where` of the eta mask (eta_inversion.py:161-162): etainv_maps_configure + the layer mask of
+    etainv_maps_word_maps_ex; the oracle side is pinned by the reference itself (tests/golden/e2e_attnres.npz)"""
+    from oracle import loop as oloop, ptp as optp
+    from etainv.pipeline import EtaLoop, PtpTables
+    name, div, where, mask_eta = case
+    unet, get_engine = setup
+    L = 16
+    eng = get_engine(L, torch.float16)
+    pairs, z0, ctx_src, ctx_tgt = _inputs(L)
+    tok = optp.WordTokenizer()
+    noise = oloop.noise_table(S, 10, L, seed=0)
+    leg = leg_attn_layers(name)
+    ref = leg["ref"]
+    W = max(len(s.split(" ")) for s, _ in pairs)
+    tokens = torch.ones(B, W, dtype=torch.int32)
+    mp, al, eq, ba, ca = [], [], [], [], []
+    for i, (src, tgt) in enumerate(pairs):
+        ws = src.split(" ")
+        tokens[i, :len(ws)] = torch.tensor([ws.index(w) + 1 for w in ws], dtype=torch.int32)
+        bw, tw = src.split(" ")[1], tgt.split(" ")[1]
+        m, a = optp.refinement_mapper(src, tgt, tok)
+        mp.append(m); al.append(a)
+        eq.append(optp.equalizer(tgt, (tw,), (2,), tok))
+        ba.append(optp.blend_alpha_layers([src, tgt], ((bw,), (tw,)), tok))
+        ca.append(optp.time_words_alpha([src, tgt], S, {"default_": .4}, tok)[:, 0])
+    ptp = PtpTables(np.stack(mp), np.stack(al), np.stack(ca, 1), 0.6, S, equalizer=np.stack(eq), blend_alpha=np.stack(ba))
+    loop = EtaLoop(eng, S=S, eta=(0.3, 0.6), use_mask=True, mask_thres=None, mask_eta=mask_eta, attn_res=L // div, attn_from_where=where)
+    try:
+        inv = loop.invert(z0.cuda(), ctx_src.cuda(), tokens.cuda())
+        assert eng.map_div == div
+        m_err = relerr(inv["maps_mean"][:, 1].cpu(), leg["maps"])
+        out = loop.sample(inv, ctx_src.cuda(), ctx_tgt.cuda(), noise.reshape(S, 10, 4, L, L).cuda(), edit_word=torch.tensor([1, 1]), ptp=ptp,
+                          edit_word_tgt=torch.tensor([1, 1]))
+        assert eng.map_div == 4                      # the backward pass went back to the (L/4)^2 store (LocalBlend)
+    finally:
+        eng.maps_configure(4)                        # (the engine is shared by the tests of this file)
+    print(f"{name}: edit-word map {m_err:.2e}, source row {relerr(out[:B].cpu(), ref[:B]):.2e}, edited latent {relerr(out[B:].cpu(), ref[B:]):.2e}")
+    assert m_err < 5e-3
+    assert relerr(out[:B].cpu(), ref[:B]) < 1e-6 and relerr(out[B:].cpu(), ref[B:]) < 2e-2
+
+
+def test_attn_layer_selection_errors(setup):
+    """what the store cannot serve fails loudly, like the reference's own failure modes"""
+    from etainv.pipeline import EtaLoop
+    unet, get_engine = setup
+    eng = get_engine(16, torch.float16)
+    with pytest.raises(NotImplementedError):
+        EtaLoop(eng, S=S, attn_res=16)                                                         # L itself: no cross layer has L^2 ... only L/2, L/4, L/8
+    with pytest.raises(ValueError):
+        EtaLoop(eng, S=S, attn_res=4, attn_from_where=("mid",))                                # the reference fails in torch.cat([])
+    with pytest.raises(NotImplementedError):
+        EtaLoop(eng, S=S, attn_res=8, mask_eta="bwd_source")                                   # backward store is (L/4)^2
+    eng.maps_configure(2)
+    x = torch.zeros(2, 4, 16, 16, device="cuda")
+    with pytest.raises(Exception, match="LocalBlend"):
+        eng.local_blend(x, 1, torch.zeros(1, 2, 77, device="cuda"))
+    eng.maps_configure(4)
+    tok = torch.ones(1, 1, dtype=torch.int32, device="cuda")
+    with pytest.raises(Exception, match="layer_mask"):
+        eng.word_maps_ex(1, tok, 1, 0, 0x20, torch.zeros(1, 1, 16, 16, device="cuda"))
+
+
 DIRINV = [("fwd_mean", "fwd_mean"), ("fwd_mean", "gt"), ("gt", "fwd")]
 
 

@@ -281,10 +281,13 @@ def test_backward_loop_row_economy_host_logic(monkeypatch):
             return lambda *a, **k: 0
 
     class FakeEngine:
-        L, lib = 8, FakeLib()
+        L, lib, map_div = 8, FakeLib(), 4
 
         def __init__(self):
             self.calls = []
+
+        def maps_configure(self, div): self.map_div = div
+        def word_maps_ex(self, *a, **k): pass
 
         def unet(self, latent, t, ctx, ctrl=None, out=None):
             c = ctrl.c if ctrl is not None else None

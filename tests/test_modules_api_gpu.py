@@ -99,7 +99,9 @@ def test_per_step_plugin_path_matches_fast_path(pipe):
 
 @pytest.mark.parametrize("editor_name,mask_cfg", [("ptp", None), ("ptp", dict(mask_eta="bwd_source_target", thres=0.15)),
                                                   ("ptp", dict(mask_eta="fwd_mean", mask_dirinv="bwd_target", target_dirinv=0.5, thres=0.25)),
-                                                  ("masactrl", None)])
+                                                  ("masactrl", None),
+                                                  ("ptp", dict(mask_eta="bwd_source_target", thres=0.15, attn_from_where=["down"])),
+                                                  ("ptp", dict(attn_res=8, attn_from_where=["up"]))])   # (L = 16: the (L/2)^2 layers of the up blocks)
 def test_per_step_api_with_builtin_controllers(pipe, editor_name, mask_cfg):
     """The reference-style per-step path (controller.begin_step -> UNet -> get_mask -> eta step -> controller.end_step, one pair at a
     time) with the BUILT-IN prompt-to-prompt / MasaCtrl controllers, including the bwd_* mask sources that read the controller's
@@ -151,10 +153,17 @@ def test_get_eta_variance_noise_reference_signature(pipe):
 def test_mask_cfg_validation(pipe):
     import modules
     p, pre, post = pipe
-    with pytest.raises(NotImplementedError):
-        modules.load_inverter("etainv", model=p, num_inference_steps=4, mask_mode_cfg=dict(attn_res=8))
-    with pytest.raises(NotImplementedError):
-        modules.load_inverter("etainv", model=p, num_inference_steps=4, mask_mode_cfg=dict(attn_from_where=["up"]))
+    L = p.engine.L
+    with pytest.raises(NotImplementedError):                      # cross layers exist at L/2, L/4, L/8 only
+        modules.load_inverter("etainv", model=p, num_inference_steps=4, mask_mode_cfg=dict(attn_res=L))
+    with pytest.raises(NotImplementedError):                      # the backward-pass store keeps the (L/4)^2 layers
+        modules.load_inverter("etainv", model=p, num_inference_steps=4, mask_mode_cfg=dict(attn_res=L // 2, mask_eta="bwd_source"))
+    with pytest.raises(ValueError):                               # no (L/4)^2 layer in the mid block: the reference fails in torch.cat([])
+        modules.load_inverter("etainv", model=p, num_inference_steps=4, mask_mode_cfg=dict(attn_from_where=["mid"]))
+    inv = modules.load_inverter("etainv", model=p, num_inference_steps=4, mask_mode_cfg=dict(attn_res=L // 2, attn_from_where=["up"]))
+    assert (inv._loop.attn_div, inv._loop.attn_layer_mask) == (2, 0x1c)
+    inv = modules.load_inverter("etainv", model=p, num_inference_steps=4, mask_mode_cfg=dict(attn_res=L // 8, attn_from_where=["down"]))
+    assert (inv._loop.attn_div, inv._loop.attn_layer_mask) == (8, 0x01)   # `res == 8` -> mid, whatever from_where says (ptp.py:293-294)
     with pytest.raises(ValueError):
         modules.load_inverter("etainv", model=p, num_inference_steps=4, mask_mode_cfg=dict(mask_eta="nope"))
 

@@ -272,6 +272,30 @@ def test_bwd_mask_sources_vs_reference(golden, toy_unet, mode):
     np.testing.assert_allclose(z[1:].numpy(), g[f"{mode}/latent"], rtol=1e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("case", ["res32", pytest.param("up_only", marks=pytest.mark.slow), "mid8", "down_bwd"])
+def test_attn_res_and_from_where_vs_reference(golden, toy_unet, case):
+    """non-default `attn_res` / `attn_from_where` of the eta mask (eta_inversion.py:161-162; aggregate_attention ptp.py:288-303 incl. its `res == 8 -> mid`
+    rule) through the reference's EtaInversion + ptp editor on the toy UNet (make_golden.gen_e2e_attnres)"""
+    from tests.golden.make_golden import ATTNRES_CASES, text_embed
+    g = golden("e2e_attnres")
+    S = int(g["S"])
+    mm = ATTNRES_CASES[case]
+    src, tgt = json.load(open(f"{GOLDEN_DIR}/prompt_pairs.json"))[0]
+    tok = optp.WordTokenizer()
+    emb = lambda p: text_embed(torch.tensor([tok.pad_ids(p)]))[0]
+    ctx_s, ctx_t = torch.stack([emb(""), emb(src)]), torch.stack([emb(""), emb(tgt)])
+    z0 = torch.from_numpy(g["z0"])
+    with torch.no_grad():
+        o = oloop.EtaInversionOracle(toy_unet, S=S, eta=(0.3, 0.6), use_mask=True, thres=mm.get("thres", 0.2), mask_eta=mm.get("mask_eta", "fwd_mean"),
+                                     attn_res=mm.get("attn_res", 16), attn_from_where=mm.get("attn_from_where", ("up", "down")))
+        inv = o.invert(z0, ctx_s, src)
+        np.testing.assert_allclose(torch.stack(inv["attn_maps_mean"]).numpy(), g[f"{case}/maps_mean"], rtol=1e-3, atol=2e-5)
+        controller = optp.make_edit_controller(src, tgt, S, tok, **PTP_VARIANTS["refine"])
+        z = o.sample(inv, ctx_s, ctx_t, oloop.noise_table(S, 10, 64, seed=0), edit_word_idx=(1, 1), controller=controller)
+    np.testing.assert_allclose(z[:1].numpy(), g[f"{case}/latent_inv"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(z[1:].numpy(), g[f"{case}/latent"], rtol=1e-3, atol=2e-4)
+
+
 def test_clip_oracle_matches_transformers():
     """oracle/clip.py is pinned by the third-party implementation itself where it is importable: transformers'
     CLIPTextModel (ViT-L/14 text config) loaded with the oracle's seeded weights gives the same hidden states."""
