@@ -5,14 +5,19 @@
             and at the full length S = 100, B = 2 the reference's quirk that MutualSelfAttentionControl's `total_steps = 50` is fixed
             (reference modules/utils/masactrl.py:20,36-37): the control is active for backward steps 4..49 only;
   config 2  etainv + simple at 512^2, B = 1, S = 50 in fp16: round trip, determinism, and the editor itself (`modules.load_editor("simple")`)
-            equal to the direct loop.
+            equal to the direct loop;
+  config 4  the PIE sweep's per-rank share at 512^2 through `eval.py` (synthetic PIE-layout tree), batch 4 == batch 1.
 """
 import json
+import sys
+from pathlib import Path
 
+import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
 
 
 def relerr(a, b):
@@ -166,3 +171,38 @@ def test_simple_editor_full_size_b1():
     torch.testing.assert_close(out[:1], z0, rtol=1e-5, atol=1e-5)                                         # round trip
     assert torch.equal(out[1:2], lat) and torch.equal(out[0:1], lat_inv)
     p.engine.close()
+
+
+def test_pie_sweep_rank_share_full_size(tmp_path, monkeypatch):
+    """BASELINE config 4's per-rank share at the real size (etainv+ptp fp16, 512 x 512, PIE-layout tree, B pairs per engine call): `eval.py` end to end
+    -- JPEG decode, resize, VAE encode, text encoder, per-image prompt-to-prompt tables, loop, two VAE decodes, PNG names -- and batch invariance through
+    the whole CLI: the latents of a batch-4 run equal those of a batch-1 run of the same records (reference: one image per call, eval.py:65-106).
+    The 8-rank exchange itself (RCCL all_gather of the latents) is covered on CPU by tests/test_pie_bench.py::test_eval_two_ranks_gloo."""
+    import importlib.util
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location("make_synth_pie", str(ROOT / "tools" / "make_synth_pie.py"))
+    msp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(msp)
+    root = tmp_path / "pie"
+    monkeypatch.setattr(sys, "argv", ["make_synth_pie.py", "--out", str(root), "--n", "4", "--seed", "3"])
+    msp.main()
+    sys.path.insert(0, str(ROOT / "eta-inversion_amd"))
+    import eval as pie_eval
+    lat = {}
+    for batch in (4, 1):
+        out = tmp_path / f"res{batch}"
+        pie_eval.main(["--data_path", str(root), "--output", str(out), "--batch", str(batch), "--steps", "3", "--size", "512", "--prec", "fp16", "--save_latents"])
+        names = sorted(f.name for f in (out / "imgs").glob("*.png"))
+        assert len(names) == 4 and all(n[:4] == f"{i:04d}" for i, n in enumerate(names))
+        assert np.array(Image.open(out / "imgs" / names[0])).shape == (512, 512, 3)
+        lat[batch] = torch.load(str(out / "latents.pt"))
+        imgs = locals().get("imgs", {})
+        imgs[batch] = [np.array(Image.open(out / "imgs" / n)).astype(np.int16) for n in names]
+    assert sorted(lat[4]) == sorted(lat[1]) == [0, 1, 2, 3]
+    for i in range(4):
+        a, b = lat[4][i].float().cpu(), lat[1][i].float().cpu()
+        assert torch.isfinite(a).all() and a.shape[-3:] == (4, 64, 64)
+        assert relerr(a, b) < 2e-2, (i, relerr(a, b))                  # measured 6.9e-3: batch 1 takes the split-K / small-tile kernels (another fp16 summation order,
+                                                                       # x 7.5 CFG over 3 steps) -- the size of the fp16 distance to the oracle itself (8.5e-3); the images are compared below
+    for x, y in zip(imgs[4], imgs[1]):                                   # the decoded 8-bit images: a few grey levels apart at most
+        assert np.abs(x - y).mean() < 1.5, np.abs(x - y).mean()
