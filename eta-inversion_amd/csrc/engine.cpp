@@ -1068,9 +1068,14 @@ extern "C" int etainv_maps_configure(etainv_engine_t* e, int res_div, void* stre
   } else {
     if (bytes > e->maps_alt_bytes) {   // first use of the (L/2)^2 store: its own allocation (host work, outside any capture)
       ETAINV_HIP(hipStreamSynchronize((hipStream_t)stream));
-      if (e->maps_alt) ETAINV_HIP(hipFree(e->maps_alt));
+      e->maps_cur = e->maps_acc;           // (a failure below leaves the engine on its default store, never on a freed one)
+      e->maps_cur_bytes = e->maps_bytes;
+      e->map_div = 4;
+      e->map_layers = 5;
+      float* old = e->maps_alt;
       e->maps_alt = nullptr;
       e->maps_alt_bytes = 0;
+      if (old) ETAINV_HIP(hipFree(old));
       ETAINV_HIP(hipMalloc(reinterpret_cast<void**>(&e->maps_alt), bytes));
       e->maps_alt_bytes = bytes;
     }

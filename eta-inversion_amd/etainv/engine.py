@@ -129,6 +129,7 @@ class Engine:
 
     def maps_configure(self, res_div=4):
         """which cross layers the attention-map store keeps: 4 = the five (L/4)^2 layers (default), 2 = the (L/2)^2 layers, 8 = the mid block's; clears the store"""
+        self.map_div = 4                              # (what the library falls back to when the call fails)
         _capi.check(self.lib.etainv_maps_configure(self.h, int(res_div), _capi.stream_ptr()))
         self.map_div = int(res_div)
 
