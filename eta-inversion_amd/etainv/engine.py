@@ -129,7 +129,9 @@ class Engine:
 
     def maps_configure(self, res_div=4):
         """which cross layers the attention-map store keeps: 4 = the five (L/4)^2 layers (default), 2 = the (L/2)^2 layers, 8 = the mid block's; clears the store"""
-        self.map_div = 4                              # (what the library falls back to when the call fails)
+        if int(res_div) not in (2, 4, 8) or self.L % int(res_div):
+            raise ValueError(f"res_div must be 2, 4 or 8 and divide L = {self.L}, got {res_div}")
+        self.map_div = 4                              # (what the library falls back to when its allocation fails)
         _capi.check(self.lib.etainv_maps_configure(self.h, int(res_div), _capi.stream_ptr()))
         self.map_div = int(res_div)
 
