@@ -858,17 +858,27 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     // (its slot's previous patch is read until the rendezvous of compute step (chunk - 2, tap 8) = issue position (chunk - 1, tap 2) of the 3-step
     // run-ahead), a piece aimed at the dummy area otherwise (taps 0, 1; ids past the patch; no next tile).
     int it_q = 0, it_gq = 0;                 // chunk index inside the tile / running chunk count (patch slot = count & 1) of the issue position
-    int pt_e0 = 0, pt_y0 = 0, pt_x0 = 0;     // patch being issued: element offset of its pixel (-1, -1) at its channel chunk, its image origin
+    int pt_e0 = 0, pt_y0 = 0, pt_x0 = 0, pt_q = 0;   // patch being issued: element offset of its pixel (-1, -1) at its channel chunk q, its image origin
     bool pt_ok = false;
+    // (the divisions -- ~125 cycles on the scalar / VALU path, in-kernel stamps of round 4 -- run once per TILE; a chunk change inside a tile only moves
+    // the channel offset: this code sits between window 1 and the rendezvous of every ninth step)
+    int pt_tile = -1;
     auto patch_target = [&](int tile, int q) __attribute__((always_inline)) {   // scalar work, once per chunk (advance_ring: off the windows)
-      pt_ok = tile < my_tiles;
-      int m0, n0;
-      tile_origin(pt_ok ? tile : 0, m0, n0);
-      const int mt = m0 / BM, tpr = p.W / 16, tpi = (p.H / 16) * tpr;
-      const int b = mt / tpi, r = mt - b * tpi, ty = r / tpr;
-      pt_y0 = ty * 16;
-      pt_x0 = (r - ty * tpr) * 16;
-      pt_e0 = ((b * p.H + pt_y0 - 1) * p.W + pt_x0 - 1) * p.c1 + q * BK;
+      if (tile != pt_tile) {
+        pt_tile = tile;
+        pt_ok = tile < my_tiles;
+        int m0, n0;
+        tile_origin(pt_ok ? tile : 0, m0, n0);
+        const int mt = m0 / BM, tpr = p.W / 16, tpi = (p.H / 16) * tpr;
+        const int b = mt / tpi, r = mt - b * tpi, ty = r / tpr;
+        pt_y0 = ty * 16;
+        pt_x0 = (r - ty * tpr) * 16;
+        pt_e0 = ((b * p.H + pt_y0 - 1) * p.W + pt_x0 - 1) * p.c1 + q * BK;
+        pt_q = q;
+      } else {
+        pt_e0 += (q - pt_q) * BK;
+        pt_q = q;
+      }
     };
     const int lrow8 = lane >> 3;
     // piece `id` (rows id * 8 .. + 7 of the 18 x 18 patch, row-major incl. halo) of the target patch -> slot `ps`; !real: a dummy piece
@@ -1037,6 +1047,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     int young_cls = 0, young_steps = 0;   // stores of the last epilogue that later waits may leave in flight
 #ifdef ETAINV_IGEMM_STAMPS
     uint64_t st_w1 = 0, st_wait = 0, st_bar = 0, st_w2 = 0, st_end = 0;   // diagnostic build only: s_memtime per step segment
+    uint64_t st_adv = 0, st_lgkm = 0;                                     // ... and the parts of `wait`: advance_ring, lgkmcnt(0) (the rest is the counted vmcnt)
     const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();   // in-kernel clock = d(memtime)/d(memrealtime) x 100 MHz
 #endif
     auto step = [&](int sidx, auto has_next_tag, auto has_issue_tag, auto has_pb_tag) __attribute__((always_inline)) {
@@ -1096,8 +1107,15 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       uint64_t t2 = t1, t3 = t1;
 #endif
       if constexpr (HAS_PB) advance_ring();   // that K tile is fully issued: move the issue position (tile switch + bias DMA here)
+#ifdef ETAINV_IGEMM_STAMPS
+      const uint64_t t1a = __builtin_amdgcn_s_memtime();
+      st_adv += t1a - t1;
+#endif
       if constexpr (HAS_NEXT) {
         ETAINV_LGKMCNT0();                   // F1 landed; slot may be recycled after the barrier
+#ifdef ETAINV_IGEMM_STAMPS
+        st_lgkm += __builtin_amdgcn_s_memtime() - t1a;
+#endif
         if constexpr (HAS_ISSUE) {
           wait_one_slot_in_flight(young_steps > 0 ? young_cls : 0);
           --young_steps;
@@ -1166,7 +1184,8 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     step(sidx, std::false_type{}, std::false_type{}, std::false_type{});
 #ifdef ETAINV_IGEMM_STAMPS
     if (p.stamps && lane == 0) {
-      uint64_t* o = p.stamps + ((size_t)blockIdx.x * 8 + wid) * 8;
+      uint64_t* o = p.stamps + ((size_t)blockIdx.x * 8 + wid) * 16;
+      o[8] = st_adv; o[9] = st_lgkm;
       o[0] = st_w1; o[1] = st_wait; o[2] = st_bar; o[3] = st_w2; o[4] = st_end; o[5] = (uint64_t)total_steps;
       o[6] = __builtin_amdgcn_s_memtime() - clk0; o[7] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
@@ -1272,20 +1291,22 @@ static int launch_igemm_t(const IGemmParams& p_in, hipStream_t s, int* stat_P = 
   static uint64_t* d_stamps = nullptr;
   IGemmParams ps = p;
   if (STAGES == 3 && getenv("ETAINV_IGEMM_STAMPS")) {
-    if (!d_stamps) (void)hipMalloc(&d_stamps, 2048 * 8 * 8 * sizeof(uint64_t));
-    (void)hipMemsetAsync(d_stamps, 0, 2048 * 8 * 8 * sizeof(uint64_t), s);
+    if (!d_stamps) (void)hipMalloc(&d_stamps, 2048 * 8 * 16 * sizeof(uint64_t));
+    (void)hipMemsetAsync(d_stamps, 0, 2048 * 8 * 16 * sizeof(uint64_t), s);
     ps.stamps = d_stamps;
   }
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WAVES_M, STAGES, UPS, LN, PATCH>), dim3(grid), dim3(WAVES_M * 128), lds, s, ps);
   if (ps.stamps) {
     (void)hipStreamSynchronize(s);
-    std::vector<uint64_t> h((size_t)grid * 8 * 8);
+    std::vector<uint64_t> h((size_t)grid * 8 * 16);
     (void)hipMemcpy(h.data(), d_stamps, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
-    double sum[5] = {0, 0, 0, 0, 0}, steps = 0, ck = 0, rt = 0;
+    double sum[5] = {0, 0, 0, 0, 0}, steps = 0, ck = 0, rt = 0, adv = 0, lgkm = 0;
     for (int b = 0; b < grid; ++b)
       for (int w = 0; w < 8; ++w) {
-        const uint64_t* o = &h[((size_t)b * 8 + w) * 8];
+        const uint64_t* o = &h[((size_t)b * 8 + w) * 16];
         for (int k = 0; k < 5; ++k) sum[k] += (double)o[k];
+        adv += (double)o[8];
+        lgkm += (double)o[9];
         steps += (double)o[5];
         ck += (double)o[6];
         rt += (double)o[7];
@@ -1293,6 +1314,7 @@ static int launch_igemm_t(const IGemmParams& p_in, hipStream_t s, int* stat_P = 
     fprintf(stderr, "[igemm stamps] in-kernel clock %.3f GHz (s_memtime / s_memrealtime x 100 MHz, mean over waves)\n", rt > 0 ? ck / rt * 0.1 : 0.0);
     fprintf(stderr, "[igemm stamps %dx%d M=%d N=%d K=%d] s_memtime ticks (core clocks) per step and wave: w1 %.2f wait %.2f barrier %.2f w2 %.2f end %.2f\n", BM, BN,
             p.M, p.N, p.taps * (p.c1 + p.c2), sum[0] / steps, sum[1] / steps, sum[2] / steps, sum[3] / steps, sum[4] / steps);
+    fprintf(stderr, "[igemm stamps] of `wait`: advance_ring %.2f, lgkmcnt(0) %.2f, counted vmcnt %.2f\n", adv / steps, lgkm / steps, (sum[1] - adv - lgkm) / steps);
   }
   return 0;
 #endif
