@@ -391,7 +391,8 @@ constexpr float A40_THR = 8.0f;
 
 template <typename T, int D, bool XCD_REMAP, int QB, int OCC>
 __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads,
-                                                               float q_scale, int mode, int n_img, int nqb, int stagger, int first_row) {
+                                                               float q_scale, int mode, int n_img, int nqb, int stagger, int first_row, int hm_rows) {
+  // hm_rows > 0: qkv holds three head-major planes [q|k|v][hm_rows batch rows][head][token][D] (IGemmParams::hm_*): a 64-key tile is one contiguous block
   typedef typename Frag<T>::v8 v8;
   typedef A32<D> GEO;
   constexpr int KV = GEO::KV, KS = GEO::KS, KROW = GEO::KROW, VROW = GEO::VROW, KBUF = GEO::KBUF, VBUF = GEO::VBUF, DT = GEO::DT, NCH = GEO::NCH,
@@ -463,7 +464,7 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
   for (int qb = 0; qb < QB; ++qb) {
     int query = q_base + qb * 32 + r;
     query = query < N ? query : N - 1;
-    const T* qp = qkv + ((int64_t)bq * N + query) * C3 + hd * D;
+    const T* qp = hm_rows ? qkv + (((int64_t)bq * heads + hd) * N + query) * D : qkv + ((int64_t)bq * N + query) * C3 + hd * D;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int d0 = s * 16 + h * 8;
@@ -480,8 +481,8 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
 
   // ---- K / V staging through registers: 320 16-byte chunks each per tile (64 keys x 5 chunks), 2 per thread (threads >= 64 take one)
   u32x4 rk[NLD], rv[NLD];
-  const T* kbase = qkv + (int64_t)bk * N * C3 + C + hd * D;
-  const T* vbase = qkv + (int64_t)bv * N * C3 + 2 * C + hd * D;
+  const T* kbase = hm_rows ? qkv + ((int64_t)hm_rows * heads + (int64_t)bk * heads + hd) * N * D : qkv + (int64_t)bk * N * C3 + C + hd * D;
+  const T* vbase = hm_rows ? qkv + ((int64_t)2 * hm_rows * heads + (int64_t)bv * heads + hd) * N * D : qkv + (int64_t)bv * N * C3 + 2 * C + hd * D;
   int st_row[NLD], st_ch[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
@@ -494,7 +495,7 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
     for (int i = 0; i < NLD; ++i) {
       u32x4 a = {0u, 0u, 0u, 0u}, c = {0u, 0u, 0u, 0u};
       if (tid + 256 * i < KV * NCH && kv0 + st_row[i] < N) {        // keys past N: zeros (finite), masked in the scores
-        const int64_t off = (int64_t)(kv0 + st_row[i]) * C3 + st_ch[i] * 8;
+        const int64_t off = hm_rows ? ((int64_t)kv0 * NCH + (tid + 256 * i)) * 8 : (int64_t)(kv0 + st_row[i]) * C3 + st_ch[i] * 8;
         a = *reinterpret_cast<const u32x4*>(kbase + off);
         c = *reinterpret_cast<const u32x4*>(vbase + off);
       }
@@ -911,7 +912,8 @@ bool self_attn40_v2_enabled() {
 }
 
 template <typename T, int D, int QB, int OCC>
-static int launch_self40(const void* qkv, void* out, int b, int n, int heads, int mode, int n_img, int q_prescaled, hipStream_t s, int first_row = 0) {
+static int launch_self40(const void* qkv, void* out, int b, int n, int heads, int mode, int n_img, int q_prescaled, hipStream_t s, int first_row = 0, int head_major = 0) {
+  const int hm_rows = head_major ? b : 0;
   const int nqb = cdiv(n, 128 * QB);
   const bool remap = ((b * heads) % 8) == 0;
   const float q_scale = q_prescaled ? 1.0f : (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
@@ -925,15 +927,21 @@ static int launch_self40(const void* qkv, void* out, int b, int n, int heads, in
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn40_kernel<T, D, false, QB, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   if (remap)
-    hipLaunchKernelGGL((self_attn40_kernel<T, D, true, QB, OCC>), dim3(nqb * heads * b), dim3(256), lds, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb, stagger, first_row);
+    hipLaunchKernelGGL((self_attn40_kernel<T, D, true, QB, OCC>), dim3(nqb * heads * b), dim3(256), lds, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb, stagger, first_row, hm_rows);
   else
-    hipLaunchKernelGGL((self_attn40_kernel<T, D, false, QB, OCC>), dim3(nqb, heads, b), dim3(256), lds, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb, stagger, first_row);
+    hipLaunchKernelGGL((self_attn40_kernel<T, D, false, QB, OCC>), dim3(nqb, heads, b), dim3(256), lds, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb, stagger, first_row, hm_rows);
   ETAINV_LAUNCH_CHECK();
   return 0;
 }
 
+bool self_attn_head_major_ok(int d, int dtype) {   // which launches read the head-major QKV planes (the 32x32x16 kernel of head_dim 40 / 80)
+  static const bool v2_80 = getenv("ETAINV_ATT80_OLD") == nullptr;
+  return dtype != ETAINV_F32 && self_attn40_v2_enabled() && (d == 40 || (d == 80 && v2_80));
+}
+
 int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int heads, int d, int mode, int n_img, int dtype,
-                               hipStream_t s, int q_prescaled, int first_row) {
+                               hipStream_t s, int q_prescaled, int first_row, int head_major) {
+  ETAINV_CHECK(!head_major || self_attn_head_major_ok(d, dtype), "head-major QKV planes: head_dim 40 / 80 on the 16-bit kernel only");
   ETAINV_CHECK(qkv && out && b > 0 && n > 0, "bad arguments");
   ETAINV_CHECK(mode == 0 || (n_img > 0 && ((first_row >= 0 && b + first_row == 4 * n_img && (first_row == 0 || (first_row == n_img && mode == 1))) ||
                                            (first_row < 0 && b == 3 * n_img && mode == 1))),
@@ -946,11 +954,11 @@ int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int hea
   ETAINV_CHECK(!q_prescaled || self_attn40_v2_enabled(), "pre-scaled queries need the d = 40 kernel");
   if (d == 40 && self_attn40_v2_enabled()) {
     // two 32-query blocks per wave, 2 waves per SIMD (measured: one block per wave with 3 or 4 waves per SIMD is 10-13 % slower)
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 40, 2, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s, first_row)));
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 40, 2, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s, first_row, head_major)));
   }
   static const bool v2_80 = getenv("ETAINV_ATT80_OLD") == nullptr;   // A/B: head_dim 80 on the 32x32x16 kernel (one 32-query block per wave)
   if (d == 80 && self_attn40_v2_enabled() && v2_80) {
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 80, 1, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s, first_row)));
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 80, 1, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s, first_row, head_major)));
   }
   // (the generic kernel takes pre-scaled queries with scale 1: ETAINV_ATT80_OLD sends head_dim 80 here while the engine still folds the scale into to_q)
   ETAINV_DISPATCH_HALF(dtype, T, switch (d) {

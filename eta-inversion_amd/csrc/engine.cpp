@@ -163,6 +163,8 @@ struct etainv_engine {
   struct GraphEntry { int calls = 0; bool failed = false; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
   std::unordered_map<std::string, GraphEntry> graphs;
   hipStream_t cap_stream = nullptr;   // capture happens on a stream of the engine's own (the caller's is usually the legacy default stream, which cannot capture)
+  long long qkv_hm_launches = 0;      // fused QKV projections that wrote the head-major layout since creation
+  bool qkv_hm = true;                 // fused QKV projections write head-major planes where the GEMM and the attention kernel both can (ETAINV_QKV_HM)
   int graph_max_rows = 0;             // OFF by default: measured on MI355X at batch 1 (config 2) a replay is exactly as fast as the eager launches (1.456 vs 1.458 images/s)
   int64_t graph_replays = 0, graph_captures = 0;
 };
@@ -509,6 +511,25 @@ struct Fwd {
   struct LnIn { const float* s; const float* c; };   // folded LayerNorm of the input rows ((mean, rstd) per row in e->lnfinal)
   // ln_out: this GEMM writes the input of a LayerNorm -- leave (mean, rstd) of its output rows in e->lnfinal (partials from the epilogue when
   // the launch can, combined by a small pass; else a pass over the output)
+  IGemmParams gemm_params(const void* a, const Lin& l, void* out, int M, const LnIn* ln) {   // plain LayerNorm-consumer GEMM (what gemm() builds for it)
+    IGemmParams p;
+    p.a1 = a;
+    p.w = l.w;
+    p.out = out;
+    p.M = M;
+    p.N = l.n;
+    p.c1 = l.k;
+    p.H = 1;
+    p.W = M;
+    p.Ho = 1;
+    p.Wo = M;
+    p.taps = 1;
+    p.rows_per_batch = M;
+    p.bias = ln->c;
+    p.ln_stat = e->lnfinal;
+    p.ln_s = ln->s;
+    return p;
+  }
   int gemm(const void* a, const Lin& l, void* out, int M, const void* residual = nullptr, int geglu = 0, const void* a2 = nullptr,
            int c1 = 0, int c2 = 0, bool ln_out = false, const LnIn* ln = nullptr, bool gn_out = false, int rows_per_image = 0) {
     IGemmParams p;
@@ -616,15 +637,27 @@ struct Fwd {
       if (gemm(e->gnbuf, t.proj_in, e->hsA, M, nullptr, 0, nullptr, 0, 0, fold)) return 1;
     }
     // self-attention
+    int head_major = 0;   // the fused QKV projection writes head-major planes when both sides can (section 4.2: a 64-key tile becomes one contiguous block)
     if (fold) {
       const LnIn ln1{t.s_qkv, t.c_qkv};
-      if (gemm(e->hsA, t.qkv, e->qkvbuf, M, nullptr, 0, nullptr, 0, 0, false, &ln1)) return 1;
+      if (e->qkv_hm && self_attn_head_major_ok(d, e->dt)) {
+        IGemmParams q = gemm_params(e->hsA, t.qkv, e->qkvbuf, M, &ln1);
+        q.hm_heads = etainv_engine::kHeads;
+        q.hm_dim = d;
+        q.hm_tokens = hw;
+        if (igemm_hm_ok(q, e->dt)) {
+          head_major = 1;
+          ++e->qkv_hm_launches;
+          if (run(q, false)) return 1;
+        }
+      }
+      if (!head_major && gemm(e->hsA, t.qkv, e->qkvbuf, M, nullptr, 0, nullptr, 0, 0, false, &ln1)) return 1;
     } else {
       if (launch_layernorm(e->hsA, t.ln1.g, t.ln1.b, e->lnbuf, M, c, 1e-5f, e->dt, s)) return 1;
       if (gemm(e->lnbuf, t.qkv, e->qkvbuf, M)) return 1;
     }
     if (launch_self_attention_mode(e->qkvbuf, e->attnbuf, rows, hw, etainv_engine::kHeads, d, mode, n_img, e->dt, s, /*q_prescaled=*/d <= 80 && self_attn40_v2_enabled() && e->dt != ETAINV_F32,
-                                   ctrl ? (ctrl->src_exit_block ? -1 : ctrl->first_row) : 0)) return 1;
+                                   ctrl ? (ctrl->src_exit_block ? -1 : ctrl->first_row) : 0, head_major)) return 1;
     if (gemm(e->attnbuf, t.out1, e->hsB, M, e->hsA, 0, nullptr, 0, 0, fold)) return 1;
     if (self_rows != all_rows) {   // the other half of the batch enters the cross-attention with the same residual stream (and LayerNorm statistics)
       const size_t off = (size_t)M * c * e->esz, Mn = (size_t)(all_rows - self_rows) * hw;   // rows [0, all - self) -> rows [self, all)
@@ -721,6 +754,7 @@ extern "C" int etainv_engine_create(const etainv_engine_config* cfg, etainv_engi
   e->gn_fold = e->gn_fused && getenv("ETAINV_GN_FOLD") != nullptr;
   // hipGraph replay of small calls: opt-in, ETAINV_GRAPH_MAX_ROWS=<rows> (calls of at most that many UNet rows are captured and replayed)
   if (const char* gm = getenv("ETAINV_GRAPH_MAX_ROWS")) e->graph_max_rows = atoi(gm);
+  if (const char* hm = getenv("ETAINV_QKV_HM")) e->qkv_hm = strcmp(hm, "0") != 0;   // (default on: +0.8 % on the benchmark step, +1 % on config 5; "0" = row-major)
   if (build_model(e) || build_workspace(e)) {
     etainv_engine_destroy(e);
     return 1;
@@ -880,6 +914,12 @@ extern "C" int etainv_unet_forward(etainv_engine_t* e, const void* latent, int n
 }
 
 /* hipGraph path of small calls: captures / replays since the engine was created (tests, benchmarks) */
+extern "C" int etainv_engine_qkv_head_major_count(etainv_engine_t* e, long long* launches) {
+  ETAINV_CHECK(e && launches, "bad arguments");
+  *launches = e->qkv_hm_launches;
+  return 0;
+}
+
 extern "C" int etainv_engine_graph_stats(etainv_engine_t* e, int64_t* captures, int64_t* replays) {
   ETAINV_CHECK(e && captures && replays, "null argument");
   *captures = e->graph_captures;

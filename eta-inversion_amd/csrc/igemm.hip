@@ -80,7 +80,8 @@ __device__ __forceinline__ float row_sum16(float x) {
 
 // LN: the folded-LayerNorm role of the launch as a compile-time constant -- the ring kernels sit exactly at 256 VGPRs, and a role read at
 // run time makes the register allocator keep all three epilogues' values apart (0 = none, 1 = producer: row statistics from the epilogue,
-// 2 = consumer: rstd (acc - mean s) + c, 3 = GroupNorm producer: per-channel (sum, sum of squares) of the stored values over the rows of each wave tile)
+// 2 = consumer: rstd (acc - mean s) + c, 3 = GroupNorm producer: per-channel (sum, sum of squares) of the stored values over the rows of each wave tile,
+// 4 = consumer that stores the head-major QKV planes of IGemmParams::hm_*)
 // PATCH (256 x 160 ring, conv3x3 stride 1 on H, W multiples of 16 only): an M tile is a 16 x 16 PIXEL PATCH of one image and the K loop runs channel
 // chunk major, the nine taps inside: the activations of a chunk are brought to LDS ONCE as the halo'd 18 x 18 patch (41 DMA pieces of 1 KiB instead of
 // 9 x 32) and the nine taps read it at shifted rows; the halo outside the image comes from the zero page.  Measured motivation: profiles/
@@ -93,7 +94,8 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   constexpr int PPIECES = PROWS / 8;                       // 41
   constexpr int A_REGION = PATCH ? 2 * PROWS * 64 : STAGES * BM * 64;   // elements: two patch slots / the A ring
   constexpr bool ln_emit = LN == 1;
-  constexpr bool ln_use = LN == 2;
+  constexpr bool ln_use = LN == 2 || LN == 4;
+  constexpr bool hm_out = LN == 4;   // LayerNorm consumer that writes the head-major QKV planes (its own instantiation: the plain consumer sits at 256 VGPRs)
   constexpr bool gn_emit = LN == 3;
   constexpr int NTHR = WAVES_M * 128;      // WAVES_M x 2 waves
   constexpr int RP = NTHR / 8;             // LDS rows staged per pass (8 lanes x 16 B per 128-B row)
@@ -311,23 +313,26 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
   // size (measured, L2-resident: 8.6 B/clk/CU for 32-B segments, 16.8 for 64-B, 24.5 for 128-B) -- the epilogue of a
   // K = 320 GEMM was ~40 % of its time.  v_permlane16_swap exchanges (block 2k, lanes 16-31 / 48-63) with (block 2k+1,
   // lanes 0-15 / 32-47): every lane then owns 8 consecutive channels and an instruction writes 64-byte segments.
-  auto store_row_group = [&](T* prow, auto& po, auto nb_tag, bool row_ok, bool wide) __attribute__((always_inline)) {
+  // hm_d / hm_skip (head-major QKV output only): columns >= hm_d of the wave's span belong to the NEXT head, whose plane starts hm_skip elements
+  // further on (a store never straddles: heads are multiples of 8 channels)
+  auto store_row_group = [&](T* prow, auto& po, auto nb_tag, bool row_ok, bool wide, int hm_d = 1 << 30, int hm_skip = 0) __attribute__((always_inline)) {
     constexpr int NB = decltype(nb_tag)::value;
     if (p.debug & 64) row_ok = row_ok && po[0][0] == 0x12345678u && po[NB - 1][1] == 0x9abcdef0u;   // ablation: compute, (almost) never store
+    auto at = [&](int col) __attribute__((always_inline)) { return prow + col + (col >= hm_d ? hm_skip : 0); };
     if (wide) {
 #pragma unroll
       for (int k = 0; k + 1 < NB; k += 2) {
         const auto lo = __builtin_amdgcn_permlane16_swap(po[k][0], po[k + 1][0], false, false);
         const auto hi = __builtin_amdgcn_permlane16_swap(po[k][1], po[k + 1][1], false, false);
         const u32x4 v = {lo[0], hi[0], lo[1], hi[1]};
-        if (row_ok) *reinterpret_cast<u32x4*>(prow + (k + (fq & 1)) * 16 + (fq >> 1) * 8) = v;
+        if (row_ok) *reinterpret_cast<u32x4*>(at((k + (fq & 1)) * 16 + (fq >> 1) * 8)) = v;
       }
       if (NB & 1)
-        if (row_ok) *reinterpret_cast<u32x2*>(prow + (NB - 1) * 16 + fq * 4) = po[NB - 1];
+        if (row_ok) *reinterpret_cast<u32x2*>(at((NB - 1) * 16 + fq * 4)) = po[NB - 1];
     } else {
 #pragma unroll
       for (int k = 0; k < NB; ++k)
-        if (row_ok) *reinterpret_cast<u32x2*>(prow + k * 16 + fq * 4) = po[k];
+        if (row_ok) *reinterpret_cast<u32x2*>(at(k * 16 + fq * 4)) = po[k];
     }
   };
   // returns the store class of the tile: 0 = unknown number of store instructions (partial tile / slow path),
@@ -438,7 +443,17 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
               T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
               po[j] = *reinterpret_cast<u32x2*>(o);
             }
-            store_row_group(out + (int64_t)m * p.N + n0 + wn * WN, po, std::integral_constant<int, NT>{}, m < p.M, wide);
+            if constexpr (hm_out) {   // head-major QKV planes (launch_igemm checked: whole tile inside one batch row, the 80-column span = whole heads)
+              // (division-free: the kernel has no registers to spare.  8 heads; the span starts at a multiple of 80 columns; batch row by a magic multiply)
+              const int g = ((n0 + wn * WN) / 80) * (p.hm_dim == 40 ? 2 : 1);   // first head of the span, counted over q | k | v
+              const int part = g >> 3, head0 = g & 7;
+              const int b = (int)(((unsigned long long)(unsigned)m0 * (unsigned)p.hm_magic) >> 38);
+              T* plane = out + ((int64_t)part * p.M + (int64_t)b * p.hm_tokens) * (8 * p.hm_dim) + (int64_t)head0 * p.hm_tokens * p.hm_dim;
+              store_row_group(plane + (int64_t)(m - b * p.hm_tokens) * p.hm_dim, po, std::integral_constant<int, NT>{}, m < p.M, wide, p.hm_dim,
+                              (p.hm_tokens - 1) * p.hm_dim);
+            } else {
+              store_row_group(out + (int64_t)m * p.N + n0 + wn * WN, po, std::integral_constant<int, NT>{}, m < p.M, wide);
+            }
           }
         } else {
 #if ETAINV_RES_PREFETCH
@@ -1271,8 +1286,11 @@ static int launch_igemm_t(const IGemmParams& p_in, hipStream_t s, int* stat_P = 
         if (p.stat_out && p.stat_kind == 0) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 1, PATCH>(p, s, nullptr);
       if (p.stat_out && p.stat_kind == 1) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 3, PATCH>(p, s, nullptr);
     }
-    if constexpr (!UPS && !PATCH)
+    if constexpr (!UPS && !PATCH) {
+      if constexpr (STAGES == 3 && BM == 256 && BN == 160)
+        if (p.ln_stat && p.hm_heads) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 4, PATCH>(p, s, nullptr);
       if (p.ln_stat) return launch_igemm_t<T, BM, BN, WAVES_M, STAGES, UPS, 2, PATCH>(p, s, nullptr);
+    }
   }
   if constexpr (PATCH) p.stat_kind = p.stat_out ? 1 : 0;   // (a conv never emits LayerNorm row statistics)
   const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN) * (STAGES != 3 && p.ksplit > 1 ? p.ksplit : 1);   // virtual tiles with split-K
@@ -1348,6 +1366,20 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p) {
   }
 }
 
+static int ring_min_tiles() {
+  static const int v = getenv("ETAINV_RING_MIN_TILES") ? atoi(getenv("ETAINV_RING_MIN_TILES")) : 192;
+  return v;
+}
+
+// head-major QKV output: only the LayerNorm-consumer fast path of the 256 x 160 ring implements it (the dispatch below sends exactly these launches there)
+bool igemm_hm_ok(const IGemmParams& p, int dtype) {
+  if (dtype == ETAINV_F32 || !p.hm_heads || !p.ln_stat || p.geglu || p.taps != 1 || p.a2 || p.residual || p.stat_out || p.out_f32 || p.out_nchw || p.w_batch_stride) return false;
+  if ((p.hm_dim != 40 && p.hm_dim != 80) || p.hm_heads != 8 || p.hm_tokens > 16384 || p.M >= (1 << 24)) return false;
+  if (p.N != 3 * p.hm_heads * p.hm_dim || p.N % 160 != 0 || p.hm_tokens % 256 != 0 || p.M % p.hm_tokens != 0 || p.rows_per_batch % 64 != 0) return false;
+  if (getenv("ETAINV_NO_RING") || xs_gemm_applicable(p, dtype)) return false;
+  return (int64_t)cdiv(p.M, 256) * cdiv(p.N, 160) >= ring_min_tiles();
+}
+
 int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P) {
   if (stat_P) *stat_P = 0;
   if (dtype == ETAINV_F32) return launch_igemm_f32(p_in, s);   // fp32-operand parity mode (f32path.hip)
@@ -1372,6 +1404,8 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   ETAINV_CHECK(!p.ln_stat || (p.ln_s && p.bias && p.taps == 1 && !p.a2), "folded LayerNorm: s / c vectors, plain GEMM");
   ETAINV_CHECK(!p.ln_stat || (!p.residual && !p.rowvec && !p.stat_out), "folded LayerNorm: no residual / row vector / statistics output on the consumer");
   ETAINV_CHECK(!p.ln_stat || (!p.out_f32 && !p.out_nchw), "folded LayerNorm: the consumer stores the compute dtype, row-major (the fp32 / NCHW epilogues do not apply mean / rstd)");
+  ETAINV_CHECK(!p.hm_heads || igemm_hm_ok(p, dtype), "head-major QKV output: not available for this launch (ask igemm_hm_ok first)");
+  if (p.hm_heads) p.hm_magic = (int)(((1ull << 38) + (unsigned)p.hm_tokens - 1) / (unsigned)p.hm_tokens);   // m0 / hm_tokens == (m0 * magic) >> 38 for m0 < 2^24, hm_tokens <= 2^14
   if (xs_gemm_applicable(p, dtype)) {   // K = 320 LayerNorm consumers with many rows: stationary activation tile, epilogue under the other wave group's MFMAs
     ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)p.c1, s, igemm_algo_bytes(p));
     return launch_xs_gemm(p, dtype, s);

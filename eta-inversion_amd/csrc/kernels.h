@@ -22,6 +22,10 @@ struct IGemmParams {
   // timing experiments only (ETAINV_IGEMM_DEBUG bit mask): 1 no DMA in the loop, 2 no epilogue, 4 no MFMA, 8 stores hit cache-resident
   // rows, 16 no young-store vmcnt allowance, 32 8-byte stores (no lane swap), 64 epilogue without its stores, 128 scalar A&S erf in GEGLU
   int debug = 0;
+  // Head-major output of a fused QKV projection (round 4): out = three planes [part q|k|v][batch row][head][token][hm_dim] instead of [M][3 * heads * hm_dim],
+  // so that a 64-key tile of one head is one contiguous block for the attention kernel (igemm_hm_ok says whether a launch can do it: LayerNorm
+  // consumer on the 256 x 160 ring, hm_dim 40 / 80, whole tiles inside one batch row).  0 = row-major
+  int hm_heads = 0, hm_dim = 0, hm_tokens = 0, hm_magic = 0;   // (hm_magic: filled in by launch_igemm)
   unsigned long* stamps = nullptr;         // diagnostic build (-DETAINV_IGEMM_STAMPS) only
   int stagger = 0;                  // experiment (ETAINV_STAGGER): start delay of the second co-resident block, 64-cycle ticks
   int M = 0, N = 0;
@@ -54,6 +58,7 @@ struct IGemmParams {
 };
 // stat_P (optional): receives the number of partials per row written to p.stat_out (0: none written)
 int launch_igemm(const IGemmParams& p, int dtype, hipStream_t s, int* stat_P = nullptr);
+bool igemm_hm_ok(const IGemmParams& p, int dtype);   // may this launch (with hm_* set) write the head-major layout?
 
 // ---- xsgemm.hip: K = 320 LayerNorm-consumer projections (GEGLU, fused QKV) of the L^2-token blocks on a stationary activation tile with two wave
 // groups in anti-phase; launch_igemm routes to it when xs_gemm_applicable (bit-identical results)
@@ -103,7 +108,8 @@ bool self_attn40_v2_enabled();
 // first_row: the call carries rows [first_row, 4 n_img) of the [u_s, u_t, c_s, c_t] x n_img layout (0, or n_img when the uncond source rows are left out:
 // backward steps with eta == 0, etainv/pipeline.py)
 int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int heads, int d, int mode, int n_img, int dtype,
-                               hipStream_t s, int q_prescaled = 0, int first_row = 0);
+                               hipStream_t s, int q_prescaled = 0, int first_row = 0, int head_major = 0);
+bool self_attn_head_major_ok(int d, int dtype);
 struct CrossParams {
   int N = 0, heads = 8, n_ctx = 77;
   float scale_log2 = 0.f;

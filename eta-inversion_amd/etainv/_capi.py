@@ -53,6 +53,7 @@ SIGNATURES = {
     "etainv_maps_word_maps_ex": [_p, _i, _p, _i, _i, _i, C.c_uint, _p, _i, _f, _p],
     "etainv_local_blend": [_p, _p, _i, _p, _f, _p],
     "etainv_engine_graph_stats": [_p, C.POINTER(_i64), C.POINTER(_i64)],
+    "etainv_engine_qkv_head_major_count": [_p, C.POINTER(C.c_longlong)],
     "etainv_engine_workspace_bytes": [_p],
     "etainv_engine_weight_bytes": [_p],
     "etainv_prof_enable": [_i],

@@ -170,6 +170,13 @@ class Engine:
         return cap.value, rep.value
 
     @property
+    def qkv_head_major_launches(self):
+        """fused QKV projections that wrote the head-major layout (ETAINV_QKV_HM=1 at engine creation) since the engine was created"""
+        n = C.c_longlong()
+        _capi.check(self.lib.etainv_engine_qkv_head_major_count(self.h, C.byref(n)))
+        return n.value
+
+    @property
     def workspace_bytes(self):
         return self.lib.etainv_engine_workspace_bytes(self.h)
 

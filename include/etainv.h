@@ -211,6 +211,11 @@ int etainv_engine_context_generation(etainv_engine_t* e, uint64_t generation);
  * -- latent / context / output staged through engine-owned buffers, the timesteps through a device vector.  Same results as the eager launches
  * (the replay IS those launches); captures / replays counted since engine creation. */
 int etainv_engine_graph_stats(etainv_engine_t* e, int64_t* captures, int64_t* replays);
+/* Default since round 4 (ETAINV_QKV_HM=0 at engine creation switches it off): the fused QKV projection of a transformer block writes
+ * three head-major planes [q|k|v][row][head][token][head_dim] where both its GEMM kernel and the self-attention kernel can (head_dim 40 / 80, 16-bit modes,
+ * whole 256-row tiles inside one batch row), so that a 64-key tile is one contiguous block.  Same values, same arithmetic: results are bit-identical.
+ * `launches` = how many QKV projections took that path since the engine was created. */
+int etainv_engine_qkv_head_major_count(etainv_engine_t* e, long long* launches);
 int64_t etainv_engine_workspace_bytes(etainv_engine_t* e);
 int64_t etainv_engine_weight_bytes(etainv_engine_t* e);
 

@@ -114,3 +114,40 @@ def test_loop_with_graphs_equals_the_eager_loop(monkeypatch, editor):
     cap, rep = res[0][1]
     n_calls = 2 * 2 * S
     assert res[1][1] == (0, 0) and cap >= 3 and rep >= n_calls - 2 * cap, (cap, rep, n_calls)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_head_major_qkv_planes_equal_the_row_major_layout(monkeypatch, dtype):
+    """Head-major QKV planes (default; ETAINV_QKV_HM=0 = row-major): the fused QKV projection stores three head-major planes and the head_dim 40 / 80 self-attention kernel reads 64-key tiles as
+    contiguous blocks (csrc/igemm.hip role 4, csrc/attention.hip hm_rows).  Only the layout of an intermediate changes: outputs must be BIT-identical --
+    plain rows, the shared prefix of a CFG call, the MasaCtrl K / V remap, the prompt-to-prompt self-replace (Q, K of the source rows) with the
+    three-row layout and the early exit.  The counter proves the path ran (L = 64, 4+ rows: the 256 x 160 ring takes the QKV GEMMs of both levels)."""
+    from etainv import _capi
+    from etainv.engine import AttnControl, Engine
+    L, rows = 64, 8
+    res = []
+    for hm in (True, False):
+        monkeypatch.setenv("ETAINV_QKV_HM", "1" if hm else "0")          # (read at engine creation; on by default)
+        e = Engine(dtype=dtype, max_unet_batch=rows, latent_size=L, max_img=2)
+        e.load_synthetic(0)
+        g = torch.Generator().manual_seed(21)
+        x2 = torch.randn(2, 4, L, L, generator=g).cuda()
+        x4 = torch.randn(4, 4, L, L, generator=g).cuda()
+        ctx = torch.randn(rows, 77, 768, generator=g).cuda()
+        outs = [e.unet(x4, [500] * 4 + [480] * 4, ctx).clone(),                                      # 8 different rows (pairs at different timesteps: no shared prefix)
+                e.unet(x4, 700, ctx).clone(),                                                        # CFG call: rows r and r + 4 share the prefix
+                e.unet(x4, 300, ctx, AttnControl(mode=_capi.ATTN_MASA, n_img=2, masa_active=True, masa_first_block=10)).clone()]
+        ones = torch.ones(2, 77, device="cuda")
+        ptp = lambda first, ex: AttnControl(mode=_capi.ATTN_PTP, n_img=2, store_maps=True, equalizer=ones, cross_alpha=ones, self_replace_active=True,
+                                            self_max_tokens=(L // 2) ** 2, first_row=first, src_exit_block=ex)
+        e.maps_reset()
+        outs.append(e.unet(x4, 481, ctx, ptp(0, 0)).clone())                                         # [u_s, u_t, c_s, c_t] x 2, self-replace at the 32^2 level
+        ctx3 = torch.cat([ctx[2:4], ctx[6:8], ctx[4:6]]).contiguous()                                # rows [u_t, c_t, c_s] over latents [tgt, tgt, src]:
+        outs.append(e.unet(torch.cat([x4[2:], x4[2:], x4[:2]]), 481, ctx3, ptp(2, 12))[:4].clone())  # the cond source rows leave after block 12
+        torch.cuda.synchronize()
+        res.append((outs, e.qkv_head_major_launches))
+        e.close()
+    (a, n_hm), (b, n_rm) = res
+    assert n_rm == 0 and n_hm >= 5 * 4, (n_hm, n_rm)                      # (5 transformer blocks at each of the two levels per call, some calls on half the rows)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.isfinite(u).all() and torch.equal(u, v), f"call {i}: head-major planes changed the result"
