@@ -57,6 +57,7 @@ struct WeightSlot {
   int taps = 1;
   int dst_dtype = ETAINV_F32;  // F32 or the compute dtype (-1 placeholder replaced at build)
   float scale = 1.0f;          // constant folded into the values in fp32 before the rounding to the compute dtype
+  void** dst4 = nullptr;       // upsampler convs: also packed as four 2x2 phase kernels (launch_pack_ups4) into *dst4
   float* stage = nullptr;      // fp32 copy kept instead of packing at once: the consumer of a folded LayerNorm is packed when gamma / beta are known
   bool stage_and_pack = false; // fp32 copy kept AND packed (proj_in: the per-image GroupNorm fold needs the fp32 values on every call)
   bool set = false;
@@ -68,7 +69,7 @@ struct WeightSlot {
 };
 
 struct Norm { float* g = nullptr; float* b = nullptr; };
-struct Lin { void* w = nullptr; float* b = nullptr; int n = 0, k = 0; };
+struct Lin { void* w = nullptr; float* b = nullptr; int n = 0, k = 0; void* w4 = nullptr; };   // w4: phase form [4][n][4][k] of an upsampler conv (launch_pack_ups4)
 
 struct ResBlock {
   int cin = 0, cout = 0;
@@ -251,6 +252,13 @@ struct Builder {
     want(&l.b, (size_t)n * 4);
     add_slot(prefix + ".bias", {n}, reinterpret_cast<void**>(&l.b), 0, PK_PLAIN, 1, ETAINV_F32);
   }
+  void conv3x3_ups(const std::string& prefix, Lin& l, int n, int k) {   // conv behind a nearest-2x upsample: the 9-tap form + the four 2x2 phase kernels
+    conv3x3(prefix, l, n, k);
+    if (e->dt != ETAINV_F32) {
+      want(&l.w4, (size_t)16 * n * k * e->esz);
+      e->slots[e->slot_by_name.at(prefix + ".weight")].dst4 = &l.w4;
+    }
+  }
   void resblock(const std::string& prefix, int cin, int cout) {
     e->res.emplace_back();
     // NB: pointers into e->res are taken after all blocks exist (vector may grow) -> reserve() up front
@@ -369,7 +377,7 @@ int build_model(etainv_engine* e) {
       b.resblock("up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), rin + skipc, cout);
       if (i > 0) b.tblock("up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), cout);
     }
-    if (i < 3) b.conv3x3("up_blocks." + std::to_string(i) + ".upsamplers.0.conv", e->up_conv[i], cout, cout);
+    if (i < 3) b.conv3x3_ups("up_blocks." + std::to_string(i) + ".upsamplers.0.conv", e->up_conv[i], cout, cout);
     prev = cout;
   }
   b.norm("conv_norm_out", e->norm_out, ch[0]);
@@ -587,6 +595,13 @@ struct Fwd {
     p.M = rows * p.Ho * p.Wo;
     p.N = l.n;
     p.rows_per_batch = p.Ho * p.Wo;
+    if (ups && l.w4) {   // four 2 x 2 phase convs on the source image instead of nine taps on the upsampled one (4 / 9 of the FLOPs) where the ring can
+      IGemmParams q = p;
+      q.ups = 2;
+      q.taps = 4;
+      q.w = l.w4;
+      if (igemm_ups4_ok(q, e->dt)) return run(q, gn_out);
+    }
     return run(p, gn_out);
   }
   // x = cat[x1 (c1), x2 (c2)] -> out
@@ -799,6 +814,7 @@ extern "C" int etainv_engine_set_weight(etainv_engine_t* e, const char* name, co
   if (s.ndim == 1) { rows = s.shape[0]; cols = 1; }
   if (s.stage) ETAINV_HIP(hipMemcpyAsync(s.stage, data, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   if ((!s.stage || s.stage_and_pack) && launch_pack_weight(data, s.dst, rows, cols, s.pack, s.taps, s.dst_dtype, (hipStream_t)stream, s.scale)) return 1;
+  if (s.dst4 && launch_pack_ups4(data, *s.dst4, (int)s.shape[0], (int)s.shape[1], s.dst_dtype, (hipStream_t)stream)) return 1;
   s.set = true;
   e->ln_folded = false;
   bool seen = false;
@@ -1354,6 +1370,10 @@ extern "C" int etainv_op_conv3x3_ex(const void* x_nhwc, const void* w_okkc, cons
   p.N = cout;
   p.rows_per_batch = p.Ho * p.Wo;
   return launch_igemm(p, dtype, (hipStream_t)stream);
+}
+
+extern "C" int etainv_op_pack_ups4(const float* w_oc33, void* dst, int cout, int cin, int dtype, void* stream) {
+  return launch_pack_ups4(w_oc33, dst, cout, cin, dtype, (hipStream_t)stream);
 }
 
 extern "C" int etainv_op_conv3x3(const void* x_nhwc, const void* x2_nhwc, int c1, int c2, const void* w_okkc, const void* bias,

@@ -209,6 +209,29 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         a_e2[q] = m * p.c2 + lchunk * 8;
         a_mask[q] = 1;
       }
+    } else if (UPS && STAGES == 3) {
+      // conv3x3 behind a nearest-2x upsample as four 2x2 phase convs on the source image (launch_pack_ups4, IGemmParams::ups == 2).  Virtual rows
+      // are image-major, then phase (2 py + px), then source pixel: a tile lies inside one phase block (launch_igemm: H * W % BM == 0)
+      const int HWs = p.H * p.W;
+      const int blk = m0 / HWs, ph = blk & 3, b = blk >> 2;
+#pragma unroll
+      for (int q = 0; q < A_LOADS; ++q) {
+        const int r = m0 - blk * HWs + (tid >> 3) + RP * q;
+        const int ys = r / p.W, xs = r - ys * p.W;
+        a_b[q] = b;
+        a_y[q] = ys + (ph >> 1) - 1;             // source pixel of tap (0, 0)
+        a_x[q] = xs + (ph & 1) - 1;
+        const int pix0 = (b * p.H + a_y[q]) * p.W + a_x[q];
+        a_e1[q] = pix0 * p.c1 + lchunk * 8;
+        a_e2[q] = 0;
+        int mask = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int iy = a_y[q] + (t >> 1), ix = a_x[q] + (t & 1);
+          mask |= ((iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W)) << t;
+        }
+        a_mask[q] = mask;
+      }
     } else {
 #pragma unroll
       for (int q = 0; q < A_LOADS; ++q) {
@@ -242,6 +265,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         woff = img * wbs;
         it_boff = img * kp->bias_batch_stride;
       }
+      if constexpr (UPS && STAGES == 3) woff = (int64_t)((m0 / (p.H * p.W)) & 3) * p.N * (4 * cin);   // the phase's 2x2 kernel
     }
 #pragma unroll
     for (int q = 0; q < B_LOADS; ++q) {
@@ -403,7 +427,20 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         const int b_ = mt / tpi, r_ = mt - b_ * tpi, ty_ = r_ / tpr;
         pm0 = (b_ * p.H + ty_ * 16 + wm * 4) * p.W + (r_ - ty_ * tpr) * 16;
       }
-      auto row_m = [&](int i) __attribute__((always_inline)) { return PATCH ? pm0 + i * p.W + fr : mw + i * 16 + fr; };
+      int um0 = 0, uph = 0;
+      if constexpr (UPS && STAGES == 3) {   // virtual row -> output pixel (2 ys + py, 2 xs + px) of image b
+        const int HWs = p.H * p.W, blk = m0 / HWs;
+        uph = blk & 3;
+        um0 = (blk >> 2) * (4 * HWs);          // first output row of the image
+      }
+      auto row_m = [&](int i) __attribute__((always_inline)) {
+        if constexpr (UPS && STAGES == 3) {
+          const int HWs = p.H * p.W;
+          const int r = (mw + i * 16 + fr) % HWs, ys = r / p.W, xs = r - ys * p.W;
+          return um0 + (2 * ys + (uph >> 1)) * (2 * p.W) + 2 * xs + (uph & 1);
+        }
+        return PATCH ? pm0 + i * p.W + fr : mw + i * 16 + fr;
+      };
       const bool ln = ln_use;   // folded LayerNorm: v = rstd[m] * (acc - mean[m] * s[n]) + c[n]  (c arrives as the bias)
       float ln_mean[MT], ln_rstd[MT];
       if (!p.geglu) {
@@ -940,11 +977,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       for (int i = 0; i < A_LOADS; ++i) {
         const bool ok = (a_mask[i] >> it_tap) & 1;
         const T* g;
-        if constexpr (UPS) {   // fused nearest-2x upsample: the tap lands on source pixel ((oy + ky - 1) >> 1, (ox + kx - 1) >> 1)
-          const int iy = (a_y[i] + it_ky) >> 1, ix = (a_x[i] + it_kx) >> 1;
-          const unsigned elem = (unsigned)(((a_b[i] * p.H + iy) * p.W + ix) * cs + (second ? it_c0 - p.c1 : it_c0) + lchunk * 8);
-          g = ok ? src + elem : zero_page;
-        } else {
+        {   // (UPS: the phase conv is a plain 2 x 2 conv on the source image -- same addressing, tap width 2)
           const unsigned elem = (unsigned)((second ? a_e2[i] : a_e1[i]) + uoff);   // garbage for halo lanes, never dereferenced
           g = ok ? src + elem : zero_page;
         }
@@ -996,7 +1029,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         if (it_c0 == cin) {
           it_c0 = 0;
           ++it_tap;
-          if (++it_kx == 3) { it_kx = 0; ++it_ky; }
+          if (++it_kx == (UPS ? 2 : 3)) { it_kx = 0; ++it_ky; }
         }
       }
       if (++it_kt == nk) {
@@ -1214,7 +1247,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
 // elements; a 3x3 conv reads its input once, not nine times; the fused upsample reads the SMALL source)
 static double igemm_algo_bytes(const IGemmParams& p) {
   const double batch = (double)p.M / (double)p.rows_per_batch;
-  const double in_px = p.taps == 9 ? batch * (double)p.H * (double)p.W : (double)p.M;
+  const double in_px = p.taps != 1 ? batch * (double)p.H * (double)p.W : (double)p.M;
   const double out_el = (double)p.M * (double)(p.geglu ? p.N / 2 : p.N);
   return 2.0 * (in_px * (double)(p.c1 + p.c2) + (double)p.N * (double)p.taps * (double)(p.c1 + p.c2) + out_el * (p.out_f32 ? 2.0 : 1.0) +
                 (p.residual ? out_el : 0.0));
@@ -1372,6 +1405,16 @@ static int ring_min_tiles() {
 }
 
 // head-major QKV output: only the LayerNorm-consumer fast path of the 256 x 160 ring implements it (the dispatch below sends exactly these launches there)
+// phase form of the fused-upsample conv (IGemmParams::ups == 2, taps == 4, weights from launch_pack_ups4): the 256 x 160 ring only, whole tiles inside
+// one phase block of one image, GroupNorm-producer or plain epilogue
+bool igemm_ups4_ok(const IGemmParams& p, int dtype) {
+  if (dtype == ETAINV_F32 || p.taps != 4 || p.stride != 1 || p.a2 || p.geglu || p.residual || p.rowvec || p.ln_stat || p.out_f32 || p.out_nchw || p.w_batch_stride || p.pad0) return false;
+  if (p.N % 160 != 0 || (p.H * p.W) % 256 != 0 || p.Ho != 2 * p.H || p.Wo != 2 * p.W || p.M % (4 * p.H * p.W) != 0 || p.rows_per_batch != 4 * p.H * p.W) return false;
+  if (p.stat_out && p.stat_kind != 1) return false;
+  if (getenv("ETAINV_NO_RING") || (getenv("ETAINV_UPS4") && atoi(getenv("ETAINV_UPS4")) == 0)) return false;
+  return (int64_t)cdiv(p.M, 256) * cdiv(p.N, 160) >= ring_min_tiles();
+}
+
 bool igemm_hm_ok(const IGemmParams& p, int dtype) {
   if (dtype == ETAINV_F32 || !p.hm_heads || !p.ln_stat || p.geglu || p.taps != 1 || p.a2 || p.residual || p.stat_out || p.out_f32 || p.out_nchw || p.w_batch_stride) return false;
   if ((p.hm_dim != 40 && p.hm_dim != 80) || p.hm_heads != 8 || p.hm_tokens > 16384 || p.M >= (1 << 24)) return false;
@@ -1396,8 +1439,9 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   ETAINV_CHECK(p.a1 && p.w && p.out, "null pointer");
   ETAINV_CHECK(p.M > 0 && p.N > 0 && (p.N % 4) == 0, "N must be a positive multiple of 4");
   ETAINV_CHECK(p.c1 % BK == 0 && p.c2 % BK == 0 && (p.c1 + p.c2) > 0, "channel counts must be multiples of 64");
-  ETAINV_CHECK(p.taps == 1 || p.taps == 9, "taps must be 1 or 9");
-  ETAINV_CHECK(p.taps == 9 || (p.stride == 1 && !p.ups), "1x1 / Linear: stride 1, no upsample");
+  ETAINV_CHECK(p.taps == 1 || p.taps == 9 || (p.taps == 4 && p.ups == 2), "taps must be 1 or 9 (4: the phase form of a fused-upsample conv, ups == 2)");
+  ETAINV_CHECK(p.taps != 1 || (p.stride == 1 && !p.ups), "1x1 / Linear: stride 1, no upsample");
+  ETAINV_CHECK(p.ups != 2 || igemm_ups4_ok(p, dtype), "phase form of the fused-upsample conv: not available for this launch (ask igemm_ups4_ok first)");
   ETAINV_CHECK(!p.geglu || (p.N % 128) == 0, "GEGLU needs N % 128 == 0");
   ETAINV_CHECK(p.rows_per_batch > 0, "rows_per_batch");
   ETAINV_CHECK(!p.rowvec || p.rowvec_stride >= p.N, "rowvec_stride");
@@ -1429,8 +1473,8 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   // 8 x 8 level, where the ring on 3/4 of the CUs still beats the two-slot 128 x 160 kernel: same-box bench 4.897 (256) / 4.937 (192) / 4.910 (128)
   // images/s.  ETAINV_RING_MIN_TILES tunes it)
   static const int ring_min = getenv("ETAINV_RING_MIN_TILES") ? atoi(getenv("ETAINV_RING_MIN_TILES")) : 192;
-  if (!p.geglu && p.ups && p.N % 160 == 0 && huge_tiles >= ring_min && !getenv("ETAINV_NO_RING")) {
-    // the ring's issue is branch-free, so the fused-upsample addressing is its own instantiation
+  if (!p.geglu && p.ups == 2) {
+    // conv3x3 behind a nearest-2x upsample as four 2 x 2 phase convs (4 / 9 of the FLOPs): its own instantiation of the ring (row decode, output scatter)
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, true, 0>(p, s, stat_P)));
   } else if (!p.geglu && p.taps == 9 && p.stride == 1 && !p.ups && !p.a2 && !p.pad0 && p.H % 16 == 0 && p.W % 16 == 0 && p.H == p.Ho && p.W == p.Wo &&
              p.N % 160 == 0 && huge_tiles >= ring_min && !p.ln_stat && !p.out_nchw && !p.out_f32 && !p.w_batch_stride &&
@@ -1438,7 +1482,7 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
     // conv3x3 stride 1 on 16-pixel-aligned images: 16 x 16 pixel patches, the halo'd activation patch of a channel chunk loaded once for all nine taps
     // (same-box A/B, 128 rows: -1 ... -5 % per launch from the 16 x 16 level up, +1 % on the benchmark step; ETAINV_PATCHCONV=0 keeps the tap-major tiles)
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, false, 0, true>(p, s, stat_P)));
-  } else if (!p.geglu && p.N % 160 == 0 && huge_tiles >= ring_min && ln_ring_ok && !getenv("ETAINV_NO_RING")) {
+  } else if (!p.geglu && !p.ups && p.N % 160 == 0 && huge_tiles >= ring_min && ln_ring_ok && !getenv("ETAINV_NO_RING")) {   // (ups == 1, the 9-tap fused upsample, runs on the two-slot kernels below)
     // experimental (opt-in): 256 x 160 x 64 tile, 8 waves, one resident block per CU (26 % fewer L2 -> LDS bytes per
     // FLOP).  Measured equal to 128 x 160 with two resident blocks (1026 vs 1033 TFLOP/s on conv 1280->1280 @16x16)
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, false, 0>(p, s, stat_P)));

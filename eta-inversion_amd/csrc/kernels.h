@@ -58,7 +58,8 @@ struct IGemmParams {
 };
 // stat_P (optional): receives the number of partials per row written to p.stat_out (0: none written)
 int launch_igemm(const IGemmParams& p, int dtype, hipStream_t s, int* stat_P = nullptr);
-bool igemm_hm_ok(const IGemmParams& p, int dtype);   // may this launch (with hm_* set) write the head-major layout?
+bool igemm_hm_ok(const IGemmParams& p, int dtype);
+bool igemm_ups4_ok(const IGemmParams& p, int dtype);   // may this launch run the phase form (ups == 2, taps == 4) of a fused-upsample conv?   // may this launch (with hm_* set) write the head-major layout?
 
 // ---- xsgemm.hip: K = 320 LayerNorm-consumer projections (GEGLU, fused QKV) of the L^2-token blocks on a stationary activation tile with two wave
 // groups in anti-phase; launch_igemm routes to it when xs_gemm_applicable (bit-identical results)
@@ -146,6 +147,7 @@ int launch_time_embedding_dev(const float* t_dev, int rows, int dim, void* out, 
 // y = silu(x) elementwise on T
 int launch_silu(const void* x, void* out, int64_t n, int dtype, hipStream_t s);
 // cast fp32 -> T with optional row permutation (weights)
+int launch_pack_ups4(const float* src, void* dst, int cout, int cin, int dtype, hipStream_t s);   // conv3x3 weights -> four 2x2 phase kernels (IGemmParams::ups == 2)
 int launch_pack_weight(const float* src, void* dst, int64_t rows, int64_t cols, int mode, int taps, int dtype, hipStream_t s, float scale = 1.0f,
                        const float* colscale = nullptr);
 // LayerNorm(gamma, beta) folded into the Linear (w_src [rows][cols] fp32, pack mode 0 / 2) that consumes it: packed operand W' = gamma . W, the

@@ -302,6 +302,34 @@ int launch_silu(const void* x, void* out, int64_t n, int dtype, hipStream_t s) {
   return 0;
 }
 
+// conv3x3 behind a nearest-2x upsample == four 2x2 convs on the SOURCE image, one per output phase (py, px) = (y & 1, x & 1): the taps of a 3x3 row / column
+// that land on the same source pixel are summed.  Phase py = 0 groups kernel rows {0}, {1, 2}; py = 1 groups {0, 1}, {2} (same for columns).
+// src [cout][cin][3][3] fp32 -> dst [phase = 2 py + px][cout][tap = 2 ty + tx][cin], summed in fp32, rounded once
+template <typename TD>
+__global__ void pack_ups4_kernel(const float* __restrict__ src, TD* __restrict__ dst, int cout, int cin) {
+  const int64_t total = (int64_t)16 * cout * cin;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % cin);
+  const int t = (int)((i / cin) & 3);
+  const int n = (int)((i / ((int64_t)4 * cin)) % cout);
+  const int ph = (int)(i / ((int64_t)4 * cin * cout));
+  const int py = ph >> 1, px = ph & 1, ty = t >> 1, tx = t & 1;
+  const int ky0 = py == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), ky1 = py == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+  const int kx0 = px == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), kx1 = px == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+  const float* w = src + ((int64_t)n * cin + c) * 9;
+  float v = 0.f;
+  for (int ky = ky0; ky <= ky1; ++ky)
+    for (int kx = kx0; kx <= kx1; ++kx) v += w[ky * 3 + kx];
+  dst[i] = from_f32<TD>(v);
+}
+int launch_pack_ups4(const float* src, void* dst, int cout, int cin, int dtype, hipStream_t s) {
+  ETAINV_CHECK(src && dst && cout > 0 && cin > 0, "bad arguments");
+  ETAINV_DISPATCH_DTYPE(dtype, TD, hipLaunchKernelGGL(pack_ups4_kernel<TD>, dim3((unsigned)cdiv((int64_t)16 * cout * cin, (int64_t)256)), dim3(256), 0, s, src, (TD*)dst, cout, cin));
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_pack_weight(const float* src, void* dst, int64_t rows, int64_t cols, int mode, int taps, int dtype, hipStream_t s, float scale,
                        const float* colscale) {
   ETAINV_CHECK(src && dst && rows > 0 && cols > 0, "bad arguments");

@@ -71,6 +71,7 @@ SIGNATURES = {
     "etainv_op_ln_fold": [_p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _i, _p],
     "etainv_op_row_stats": [_p, _p, _i, _i, _f, _i, _p],
     "etainv_op_ln_finalize": [_p, _i, _i, _f, _p, _i, _p],
+    "etainv_op_pack_ups4": [_p, _p, _i, _i, _i, _p],
     "etainv_op_conv3x3": [_p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "etainv_op_conv3x3_ex": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "etainv_op_im2col3x3": [_p, _i, _i, _i, _i, _i, _p, _p, _i, _p],

@@ -265,6 +265,11 @@ int etainv_op_gemm_gnstat(const void* a, const void* w, const float* bias, const
 int etainv_op_groupnorm_pre(const void* x1, const void* x2, int c1, int c2, const float* part1, int wm1, const float* part2, int wm2,
                             const float* gamma, const float* beta, void* out, int b, int hw, int groups, float eps, int silu,
                             float* final_stats, int dtype, void* stream);
+/* conv3x3 behind a nearest-2x upsample (diffusers Upsample2D inside the UNet call of eta_inversion.py:321) in PHASE form: the nine taps on the upsampled image
+ * are four 2x2 convs on the source image, one per output phase (y & 1, x & 1) -- taps that land on the same source pixel are summed in fp32 and rounded
+ * once (4 / 9 of the FLOPs, the same result up to that rounding).  w_oc33 [cout][cin][3][3] fp32 -> dst [4][cout][4][cin] in the compute dtype; run it with
+ * etainv_op_conv3x3(..., upsample = 2, taps = 4): the 256 x 160 ring only (h * wd % 256 == 0, enough rows; otherwise an error -- upsample = 1 is the 9-tap form). */
+int etainv_op_pack_ups4(const float* w_oc33, void* dst, int cout, int cin, int dtype, void* stream);
 int etainv_op_conv3x3(const void* x_nhwc, const void* x2_nhwc, int c1, int c2, const void* w_okkc, const void* bias,
                       const float* rowvec, const void* residual, void* out, int b, int h, int wd, int cout,
                       int stride, int upsample, int taps, int dtype, void* stream);

@@ -380,6 +380,41 @@ def test_conv3x3_persistent_ring(capi, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,h,wd,cin,cout", [(16, 16, 16, 1280, 1280), (8, 32, 32, 640, 640), (12, 16, 32, 320, 640)])
+def test_conv3x3_fused_upsample_phase_form(capi, dtype, b, h, wd, cin, cout):
+    """conv3x3(nearest-2x upsample(x)) as four 2 x 2 phase convs on the source image (etainv_op_pack_ups4 + upsample = 2, taps = 4: 4 / 9 of the FLOPs):
+    against F.conv2d on the upsampled image (borders of the upsampled grid = zero padding; every phase; non-square images) and against the 9-tap fused
+    form (upsample = 1) -- the two differ only by the one rounding of the summed weights"""
+    lib = capi.load()
+    x = rnd(b, cin, h, wd, seed=1, dtype=dtype)
+    w32 = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5)
+    bias = rnd(cout, seed=3)
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w32, bias, padding=1)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    code = capi.dtype_code(dtype)
+    w4 = torch.empty(4, cout, 4, cin, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_pack_ups4(capi.ptr(w32.contiguous()), capi.ptr(w4), cout, cin, code, capi.stream_ptr()))
+    # the packed phase kernels are the fp32 sums of the taps that share a source pixel
+    py0 = torch.stack([w32[:, :, 0], w32[:, :, 1] + w32[:, :, 2]], 2)            # [cout][cin][ty][kx], py = 0
+    want00 = torch.stack([py0[..., 0], py0[..., 1] + py0[..., 2]], 3)            # px = 0 -> [cout][cin][ty][tx]
+    assert relerr(w4[0].float().reshape(cout, 2, 2, cin).permute(0, 3, 1, 2), want00) < (1e-3 if dtype == torch.float16 else 5e-3)
+    out = torch.empty(b, 2 * h, 2 * wd, cout, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_conv3x3(capi.ptr(x_nhwc), None, cin, 0, capi.ptr(w4), capi.ptr(bias), None, None, capi.ptr(out), b, h, wd, cout, 1, 2, 4, code,
+                                     capi.stream_ptr()))
+    out9 = torch.empty_like(out)
+    w9 = w32.to(dtype).permute(0, 2, 3, 1).contiguous()
+    capi.check(lib.etainv_op_conv3x3(capi.ptr(x_nhwc), None, cin, 0, capi.ptr(w9), capi.ptr(bias), None, None, capi.ptr(out9), b, h, wd, cout, 1, 1, 9, code,
+                                     capi.stream_ptr()))
+    e4, e9 = relerr(out.permute(0, 3, 1, 2), ref), relerr(out9.permute(0, 3, 1, 2), ref)
+    print(f"phase form {e4:.2e}, 9-tap form {e9:.2e} vs fp32")
+    assert e4 < TOL[dtype] and e9 < TOL[dtype] and e4 < 1.2 * e9 + 1e-4
+    # no launch for what the ring cannot do: an image that is not whole 256-row tiles per phase
+    with pytest.raises(Exception, match="phase form"):
+        capi.check(lib.etainv_op_conv3x3(capi.ptr(x_nhwc), None, cin, 0, capi.ptr(w4), capi.ptr(bias), None, None, capi.ptr(out), b, 8, 8, cout, 1, 2, 4, code,
+                                         capi.stream_ptr()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("b,h,cin,cout,res", [(16, 64, 320, 320, True), (16, 64, 960, 320, False), (64, 32, 640, 640, True), (256, 16, 1280, 1280, False),
                                               (7, 48, 320, 640, True)])
 def test_conv3x3_patch_mode(capi, dtype, monkeypatch, b, h, cin, cout, res):
