@@ -86,7 +86,7 @@ __device__ __forceinline__ float row_sum16(float x) {
 // chunk major, the nine taps inside: the activations of a chunk are brought to LDS ONCE as the halo'd 18 x 18 patch (41 DMA pieces of 1 KiB instead of
 // 9 x 32) and the nine taps read it at shifted rows; the halo outside the image comes from the zero page.  Measured motivation: profiles/
 // r04_conv_traffic_ablation.log (activation pieces for one tap in nine: conv3x3 -9 ... -15 %).
-template <typename T, int BM, int BN, int WAVES_M, int STAGES, bool UPS = false, int LN = 0, bool PATCH = false>
+template <typename T, int BM, int BN, int WAVES_M, int STAGES, int UPS = 0, int LN = 0, bool PATCH = false>   // UPS: 1 = nine taps on the upsampled grid, 2 = phase form
 __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) {
   static_assert(!PATCH || (STAGES == 3 && BM == 256 && WAVES_M == 4 && !UPS && (LN == 0 || LN == 3)), "patch mode: the 256-row ring, plain or GroupNorm-producer epilogue");
   constexpr int PW = 18;                                   // patch pitch (16 + halo)
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         a_e2[q] = m * p.c2 + lchunk * 8;
         a_mask[q] = 1;
       }
-    } else if (UPS && STAGES == 3) {
+    } else if (UPS == 2) {
       // conv3x3 behind a nearest-2x upsample as four 2x2 phase convs on the source image (launch_pack_ups4, IGemmParams::ups == 2).  Virtual rows
       // are image-major, then phase (2 py + px), then source pixel: a tile lies inside one phase block (launch_igemm: H * W % BM == 0)
       const int HWs = p.H * p.W;
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         woff = img * wbs;
         it_boff = img * kp->bias_batch_stride;
       }
-      if constexpr (UPS && STAGES == 3) woff = (int64_t)((m0 / (p.H * p.W)) & 3) * p.N * (4 * cin);   // the phase's 2x2 kernel
+      if constexpr (UPS == 2) woff = (int64_t)((m0 / (p.H * p.W)) & 3) * p.N * (4 * cin);   // the phase's 2x2 kernel
     }
 #pragma unroll
     for (int q = 0; q < B_LOADS; ++q) {
@@ -428,13 +428,13 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         pm0 = (b_ * p.H + ty_ * 16 + wm * 4) * p.W + (r_ - ty_ * tpr) * 16;
       }
       int um0 = 0, uph = 0;
-      if constexpr (UPS && STAGES == 3) {   // virtual row -> output pixel (2 ys + py, 2 xs + px) of image b
+      if constexpr (UPS == 2) {   // virtual row -> output pixel (2 ys + py, 2 xs + px) of image b
         const int HWs = p.H * p.W, blk = m0 / HWs;
         uph = blk & 3;
         um0 = (blk >> 2) * (4 * HWs);          // first output row of the image
       }
       auto row_m = [&](int i) __attribute__((always_inline)) {
-        if constexpr (UPS && STAGES == 3) {
+        if constexpr (UPS == 2) {
           const int HWs = p.H * p.W;
           const int r = (mw + i * 16 + fr) % HWs, ys = r / p.W, xs = r - ys * p.W;
           return um0 + (2 * ys + (uph >> 1)) * (2 * p.W) + 2 * xs + (uph & 1);
@@ -977,7 +977,11 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       for (int i = 0; i < A_LOADS; ++i) {
         const bool ok = (a_mask[i] >> it_tap) & 1;
         const T* g;
-        {   // (UPS: the phase conv is a plain 2 x 2 conv on the source image -- same addressing, tap width 2)
+        if constexpr (UPS == 1) {   // nine taps on the upsampled grid: the tap lands on source pixel ((oy + ky - 1) >> 1, (ox + kx - 1) >> 1)
+          const int iy = (a_y[i] + it_ky) >> 1, ix = (a_x[i] + it_kx) >> 1;
+          const unsigned elem = (unsigned)(((a_b[i] * p.H + iy) * p.W + ix) * cs + (second ? it_c0 - p.c1 : it_c0) + lchunk * 8);
+          g = ok ? src + elem : zero_page;
+        } else {   // (UPS == 2: the phase conv is a plain 2 x 2 conv on the source image -- same addressing, tap width 2)
           const unsigned elem = (unsigned)((second ? a_e2[i] : a_e1[i]) + uoff);   // garbage for halo lanes, never dereferenced
           g = ok ? src + elem : zero_page;
         }
@@ -1029,7 +1033,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         if (it_c0 == cin) {
           it_c0 = 0;
           ++it_tap;
-          if (++it_kx == (UPS ? 2 : 3)) { it_kx = 0; ++it_ky; }
+          if (++it_kx == (UPS == 2 ? 2 : 3)) { it_kx = 0; ++it_ky; }
         }
       }
       if (++it_kt == nk) {
@@ -1297,7 +1301,7 @@ static int pick_xcd_gn(const IGemmParams& p, int BM, int BN, int grid, int tiles
   return forced > 1 ? 1 : best;
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int STAGES = 2, bool UPS = false, int LN = 0, bool PATCH = false>
+template <typename T, int BM, int BN, int WAVES_M, int STAGES = 2, int UPS = 0, int LN = 0, bool PATCH = false>
 static int launch_igemm_t(const IGemmParams& p_in, hipStream_t s, int* stat_P = nullptr) {
   IGemmParams p = p_in;
   // Statistics producers: the fast epilogue (whole wave tiles inside one image and inside N) writes, for a LayerNorm (stat_kind 0), one (mean, M2)
@@ -1475,20 +1479,23 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   static const int ring_min = getenv("ETAINV_RING_MIN_TILES") ? atoi(getenv("ETAINV_RING_MIN_TILES")) : 192;
   if (!p.geglu && p.ups == 2) {
     // conv3x3 behind a nearest-2x upsample as four 2 x 2 phase convs (4 / 9 of the FLOPs): its own instantiation of the ring (row decode, output scatter)
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, true, 0>(p, s, stat_P)));
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, 2, 0>(p, s, stat_P)));
+  } else if (!p.geglu && p.ups == 1 && p.N % 160 == 0 && huge_tiles >= ring_min && !getenv("ETAINV_NO_RING")) {
+    // the nine-tap form (images that are not whole 256-row tiles per phase): the ring's issue is branch-free, so its addressing is its own instantiation
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, 1, 0>(p, s, stat_P)));
   } else if (!p.geglu && p.taps == 9 && p.stride == 1 && !p.ups && !p.a2 && !p.pad0 && p.H % 16 == 0 && p.W % 16 == 0 && p.H == p.Ho && p.W == p.Wo &&
              p.N % 160 == 0 && huge_tiles >= ring_min && !p.ln_stat && !p.out_nchw && !p.out_f32 && !p.w_batch_stride &&
              (!p.stat_out || p.stat_kind == 1) && !(getenv("ETAINV_PATCHCONV") && atoi(getenv("ETAINV_PATCHCONV")) == 0) && !getenv("ETAINV_NO_RING")) {
     // conv3x3 stride 1 on 16-pixel-aligned images: 16 x 16 pixel patches, the halo'd activation patch of a channel chunk loaded once for all nine taps
     // (same-box A/B, 128 rows: -1 ... -5 % per launch from the 16 x 16 level up, +1 % on the benchmark step; ETAINV_PATCHCONV=0 keeps the tap-major tiles)
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, false, 0, true>(p, s, stat_P)));
-  } else if (!p.geglu && !p.ups && p.N % 160 == 0 && huge_tiles >= ring_min && ln_ring_ok && !getenv("ETAINV_NO_RING")) {   // (ups == 1, the 9-tap fused upsample, runs on the two-slot kernels below)
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, 0, 0, true>(p, s, stat_P)));
+  } else if (!p.geglu && !p.ups && p.N % 160 == 0 && huge_tiles >= ring_min && ln_ring_ok && !getenv("ETAINV_NO_RING")) {   // (a fused upsample that did not fill the ring runs on the two-slot kernels below)
     // experimental (opt-in): 256 x 160 x 64 tile, 8 waves, one resident block per CU (26 % fewer L2 -> LDS bytes per
     // FLOP).  Measured equal to 128 x 160 with two resident blocks (1026 vs 1033 TFLOP/s on conv 1280->1280 @16x16)
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, false, 0>(p, s, stat_P)));
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, 0, 0>(p, s, stat_P)));
   } else if (p.geglu && ln_ring_ok && p.c1 >= (getenv("ETAINV_GEGLU_RING_MINK") ? atoi(getenv("ETAINV_GEGLU_RING_MINK")) : 320) && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 128) >= 256 && !getenv("ETAINV_NO_RING")) {
     // (since the interleaved windows the ring also wins at K = 320: 1.42 vs 1.55 ms for ff1 320 -> 2560 at 64 x 64 x 128 rows)
-    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 128, 4, 3, false, 0>(p, s, stat_P)));
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 128, 4, 3, 0, 0>(p, s, stat_P)));
   } else {
     // two-slot kernels: 128 x 160 (every channel count of SD1.x is a multiple of 320: no padded columns, 20 MFMAs per 9 fragment
     // reads), 128 x 128 (GEGLU / other widths), 64 x 64 for small M*N.  A two-slot block is bound by one memory latency per K tile
@@ -1527,9 +1534,9 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
     // (four LDS slots with three K tiles in flight -- the S = 4 form of the simple loop -- were measured for these kernels at batch 1: -37 % with
     // four slots everywhere (half the resident blocks), -1.5 % when only launches whose blocks are all resident anyway took it: a K step of a
     // lone block is bound by its own LDS-read -> MFMA chain, not by the memory latency)
-    ETAINV_DISPATCH_HALF(dtype, T, rc = cfg == 0   ? launch_igemm_t<T, 128, 160, 2, 2, false, 0>(pk, s, stat_P)
-                                        : cfg == 1 ? launch_igemm_t<T, 128, 128, 2, 2, false, 0>(pk, s, stat_P)
-                                                   : launch_igemm_t<T, 64, 64, 2, 2, false, 0>(pk, s, stat_P));
+    ETAINV_DISPATCH_HALF(dtype, T, rc = cfg == 0   ? launch_igemm_t<T, 128, 160, 2, 2, 0, 0>(pk, s, stat_P)
+                                        : cfg == 1 ? launch_igemm_t<T, 128, 128, 2, 2, 0, 0>(pk, s, stat_P)
+                                                   : launch_igemm_t<T, 64, 64, 2, 2, 0, 0>(pk, s, stat_P));
     prof_pause(false);
     if (rc) return rc;
     if (ks > 1) {
