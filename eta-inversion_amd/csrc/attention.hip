@@ -907,7 +907,7 @@ static int launch_self_t(const void* qkv, void* out, int b, int n, int heads, in
 }
 
 bool self_attn40_v2_enabled() {
-  static const bool on = getenv("ETAINV_ATT_OLD") == nullptr;
+  static const bool on = !env_on("ETAINV_ATT_OLD");
   return on;
 }
 
@@ -935,7 +935,7 @@ static int launch_self40(const void* qkv, void* out, int b, int n, int heads, in
 }
 
 bool self_attn_head_major_ok(int d, int dtype) {   // which launches read the head-major QKV planes (the 32x32x16 kernel of head_dim 40 / 80)
-  static const bool v2_80 = getenv("ETAINV_ATT80_OLD") == nullptr;
+  static const bool v2_80 = !env_on("ETAINV_ATT80_OLD");
   return dtype != ETAINV_F32 && self_attn40_v2_enabled() && (d == 40 || (d == 80 && v2_80));
 }
 
@@ -956,7 +956,7 @@ int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int hea
     // two 32-query blocks per wave, 2 waves per SIMD (measured: one block per wave with 3 or 4 waves per SIMD is 10-13 % slower)
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 40, 2, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s, first_row, head_major)));
   }
-  static const bool v2_80 = getenv("ETAINV_ATT80_OLD") == nullptr;   // A/B: head_dim 80 on the 32x32x16 kernel (one 32-query block per wave)
+  static const bool v2_80 = !env_on("ETAINV_ATT80_OLD");   // A/B: head_dim 80 on the 32x32x16 kernel (one 32-query block per wave)
   if (d == 80 && self_attn40_v2_enabled() && v2_80) {
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 80, 1, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s, first_row, head_major)));
   }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 
 #include "../../include/etainv.h"
@@ -103,6 +104,14 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- environment switches: ONE rule in both layers (etainv/pipeline.py _env_on has the same): a boolean switch is ON when the variable is set to
+// anything but "" or "0"; `env_flag(name, dflt)` reads a switch whose default is `dflt` (unset = default, "0" / "" = off, anything else = on)
+static inline bool env_on(const char* name) {
+  const char* v = getenv(name);
+  return v && v[0] && !(v[0] == '0' && !v[1]);
+}
+static inline bool env_flag(const char* name, bool dflt) { return getenv(name) ? env_on(name) : dflt; }
 
 // one-time per-device state of the launchers (function attributes, zero pages, workspaces) is indexed by the current device
 constexpr int kMaxDevices = 16;

@@ -764,12 +764,12 @@ extern "C" int etainv_engine_create(const etainv_engine_config* cfg, etainv_engi
   e->max_img = cfg->max_img;
   e->esz = e->dt == ETAINV_F32 ? 4 : 2;
   // fp32-operand mode: the standalone norms (the folds are fusions of the 16-bit kernels' epilogues)
-  e->ln_fused = !getenv("ETAINV_LN_UNFUSED") && e->dt != ETAINV_F32;
-  e->gn_fused = !getenv("ETAINV_GN_UNFUSED") && e->dt != ETAINV_F32;
-  e->gn_fold = e->gn_fused && getenv("ETAINV_GN_FOLD") != nullptr;
+  e->ln_fused = !env_on("ETAINV_LN_UNFUSED") && e->dt != ETAINV_F32;
+  e->gn_fused = !env_on("ETAINV_GN_UNFUSED") && e->dt != ETAINV_F32;
+  e->gn_fold = e->gn_fused && env_on("ETAINV_GN_FOLD");
   // hipGraph replay of small calls: opt-in, ETAINV_GRAPH_MAX_ROWS=<rows> (calls of at most that many UNet rows are captured and replayed)
   if (const char* gm = getenv("ETAINV_GRAPH_MAX_ROWS")) e->graph_max_rows = atoi(gm);
-  if (const char* hm = getenv("ETAINV_QKV_HM")) e->qkv_hm = strcmp(hm, "0") != 0;   // (default on: +0.8 % on the benchmark step, +1 % on config 5; "0" = row-major)
+  e->qkv_hm = env_flag("ETAINV_QKV_HM", true);   // (default on: +0.8 % on the benchmark step, +1 % on config 5; "0" = row-major)
   if (build_model(e) || build_workspace(e)) {
     etainv_engine_destroy(e);
     return 1;
@@ -880,10 +880,13 @@ static int unet_graph(etainv_engine_t* e, const void* latent, int n_lat, const i
   bool t_pairs = n_rows > n_lat && n_rows <= 2 * n_lat;                   // what unet_body's shared-prefix decision reads from the timesteps
   for (int r = n_lat; t_pairs && r < n_rows; ++r) t_pairs = t_host[r] == t_host[r - n_lat];
   const bool reuse = e->ctx_cache_on && e->ctx_cached == ctx && e->ctx_rows == n_rows && e->ctx_io == io_dtype && e->ctx_gen_cached == e->ctx_gen;
-  char key[160];
-  snprintf(key, sizeof key, "%d.%d.%d.%d.%d.%d|%d.%d.%d.%d.%d.%d.%d.%d.%d", n_rows, n_lat, io_dtype, (int)t_pairs, (int)reuse, e->map_div, ctrl ? ctrl->mode : -1,
-           ctrl ? ctrl->n_img : 0, ctrl ? ctrl->store_maps : 0, ctrl ? ctrl->self_replace_active : 0, ctrl ? ctrl->self_max_tokens : 0,
-           ctrl ? ctrl->masa_active : 0, ctrl ? ctrl->masa_first_block : 0, ctrl ? ctrl->first_row : 0, ctrl ? ctrl->src_exit_block : 0);
+  std::string key;   // (built with std::to_string: no fixed buffer a long signature could truncate into another signature's key)
+  for (const int v : {n_rows, n_lat, io_dtype, (int)t_pairs, (int)reuse, e->map_div, ctrl ? ctrl->mode : -1, ctrl ? ctrl->n_img : 0, ctrl ? ctrl->store_maps : 0,
+                      ctrl ? ctrl->self_replace_active : 0, ctrl ? ctrl->self_max_tokens : 0, ctrl ? ctrl->masa_active : 0, ctrl ? ctrl->masa_first_block : 0,
+                      ctrl ? ctrl->first_row : 0, ctrl ? ctrl->src_exit_block : 0}) {
+    key += std::to_string(v);
+    key += '.';
+  }
   auto& ge = e->graphs[key];
   // the first call of a signature runs eagerly: one-time allocations, function attributes and the LayerNorm fold happen outside any capture
   if (ge.failed || ++ge.calls < 2) return 2;
@@ -892,8 +895,13 @@ static int unet_graph(etainv_engine_t* e, const void* latent, int n_lat, const i
   if (!reuse) ETAINV_HIP(hipMemcpyAsync(e->g_ctx, ctx, (size_t)n_rows * etainv_engine::kCtx * etainv_engine::kCtxDim * io_size(io_dtype), hipMemcpyDeviceToDevice, s));
   if (launch_set_timesteps(t_host, n_rows, e->g_t, s)) return 1;
   if (!ge.exec) {
-    if (!e->cap_stream) ETAINV_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
-    ETAINV_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
+    // (a stream that cannot be created or put into capture mode sends this signature to the eager path, like every other capture failure)
+    if ((!e->cap_stream && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) ||
+        hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+      (void)hipGetLastError();
+      ge.failed = true;
+      return 2;
+    }
     const int rc = unet_body(e, e->g_lat, n_lat, t_host, e->g_ctx, n_rows, ctrl, e->g_out, io_dtype, (void*)e->cap_stream, e->g_t, reuse ? 1 : 0);
     hipGraph_t g = nullptr;
     const hipError_t ec = hipStreamEndCapture(e->cap_stream, &g);
@@ -929,7 +937,7 @@ extern "C" int etainv_unet_forward(etainv_engine_t* e, const void* latent, int n
   return 0;
 }
 
-/* hipGraph path of small calls: captures / replays since the engine was created (tests, benchmarks) */
+/* fused QKV projections that wrote the head-major planes since the engine was created (tests: the layout is really on the path) */
 extern "C" int etainv_engine_qkv_head_major_count(etainv_engine_t* e, long long* launches) {
   ETAINV_CHECK(e && launches, "bad arguments");
   *launches = e->qkv_hm_launches;
@@ -956,6 +964,10 @@ static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const in
     ETAINV_CHECK(ctrl->src_exit_block == 0 || (ctrl->mode == ETAINV_ATTN_PTP && ctrl->first_row == ctrl->n_img && !ctrl->mapper && !ctrl->replace_mat &&
                                                ctrl->src_exit_block >= (ctrl->self_replace_active ? 12 : 9) && ctrl->src_exit_block < 15),
                  "src_exit_block: prompt-to-prompt three-row call without cross edit; exit after block 9..14 (12..14 while the self-replace is active)");
+    // the store may keep other layers than the (L/4)^2 ones (etainv_maps_configure): an exit in front of the last stored block would silently drop the
+    // source rows' maps of the later layers (last stored block: res_div 2 -> 12, 4 -> 9, 8 -> 6)
+    ETAINV_CHECK(!ctrl->src_exit_block || !ctrl->store_maps || (e->map_div == 2 ? 12 : e->map_div == 4 ? 9 : 6) <= ctrl->src_exit_block,
+                 "src_exit_block lies in front of the last cross-attention layer the map store keeps (etainv_maps_configure): the source rows' maps would be lost");
     if (ctrl->mode == ETAINV_ATTN_PTP || ctrl->mode == ETAINV_ATTN_MASA)
       ETAINV_CHECK(n_rows == 4 * ctrl->n_img - ctrl->first_row, "ptp / masactrl need 4*n_img UNet rows [u_s,u_t,c_s,c_t] (ptp with first_row = n_img: 3*n_img rows [u_t,c_s,c_t])");
     if (ctrl->mode == ETAINV_ATTN_STORE)
@@ -1005,7 +1017,7 @@ static int unet_body(etainv_engine_t* e, const void* latent, int n_lat, const in
   // both halves (eta_inversion.py:320-321 `torch.cat([latent] * 2)`); the values are the same.  ETAINV_NO_PREFIX_SHARE=1: A/B switch.
   // (general form: n_lat < n_rows <= 2 n_lat -- rows r >= n_lat repeat latent r - n_lat; the 3 n_img-row backward calls of eta == 0 steps carry
   // latents [tgt, src] and rows [u_t, c_s, c_t]: the last n_img rows repeat the first n_img)
-  bool share = getenv("ETAINV_NO_PREFIX_SHARE") == nullptr && n_rows > n_lat && n_rows <= 2 * n_lat && !e->gn_fold;
+  bool share = !env_on("ETAINV_NO_PREFIX_SHARE") && n_rows > n_lat && n_rows <= 2 * n_lat && !e->gn_fold;
   for (int r = n_lat; share && r < n_rows; ++r) share = t_host[r] == t_host[r - n_lat];
   const int dup_n = n_rows - n_lat;   // rows copied from the head of every shared tensor to its tail
   const int pre_rows = share ? n_lat : n_rows;

@@ -1345,7 +1345,7 @@ static int launch_igemm_t(const IGemmParams& p_in, hipStream_t s, int* stat_P = 
 #ifdef ETAINV_IGEMM_STAMPS
   static uint64_t* d_stamps = nullptr;
   IGemmParams ps = p;
-  if (STAGES == 3 && getenv("ETAINV_IGEMM_STAMPS")) {
+  if (STAGES == 3 && env_on("ETAINV_IGEMM_STAMPS")) {
     if (!d_stamps) (void)hipMalloc(&d_stamps, 2048 * 8 * 16 * sizeof(uint64_t));
     (void)hipMemsetAsync(d_stamps, 0, 2048 * 8 * 16 * sizeof(uint64_t), s);
     ps.stamps = d_stamps;
@@ -1415,7 +1415,7 @@ bool igemm_ups4_ok(const IGemmParams& p, int dtype) {
   if (dtype == ETAINV_F32 || p.taps != 4 || p.stride != 1 || p.a2 || p.geglu || p.residual || p.rowvec || p.ln_stat || p.out_f32 || p.out_nchw || p.w_batch_stride || p.pad0) return false;
   if (p.N % 160 != 0 || (p.H * p.W) % 256 != 0 || p.Ho != 2 * p.H || p.Wo != 2 * p.W || p.M % (4 * p.H * p.W) != 0 || p.rows_per_batch != 4 * p.H * p.W) return false;
   if (p.stat_out && p.stat_kind != 1) return false;
-  if (getenv("ETAINV_NO_RING") || (getenv("ETAINV_UPS4") && atoi(getenv("ETAINV_UPS4")) == 0)) return false;
+  if (env_on("ETAINV_NO_RING") || !env_flag("ETAINV_UPS4", true)) return false;
   return (int64_t)cdiv(p.M, 256) * cdiv(p.N, 160) >= ring_min_tiles();
 }
 
@@ -1423,7 +1423,7 @@ bool igemm_hm_ok(const IGemmParams& p, int dtype) {
   if (dtype == ETAINV_F32 || !p.hm_heads || !p.ln_stat || p.geglu || p.taps != 1 || p.a2 || p.residual || p.stat_out || p.out_f32 || p.out_nchw || p.w_batch_stride) return false;
   if ((p.hm_dim != 40 && p.hm_dim != 80) || p.hm_heads != 8 || p.hm_tokens > 16384 || p.M >= (1 << 24)) return false;
   if (p.N != 3 * p.hm_heads * p.hm_dim || p.N % 160 != 0 || p.hm_tokens % 256 != 0 || p.M % p.hm_tokens != 0 || p.rows_per_batch % 64 != 0) return false;
-  if (getenv("ETAINV_NO_RING") || xs_gemm_applicable(p, dtype)) return false;
+  if (env_on("ETAINV_NO_RING") || xs_gemm_applicable(p, dtype)) return false;
   return (int64_t)cdiv(p.M, 256) * cdiv(p.N, 160) >= ring_min_tiles();
 }
 
@@ -1454,6 +1454,10 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   ETAINV_CHECK(!p.ln_stat || (!p.out_f32 && !p.out_nchw), "folded LayerNorm: the consumer stores the compute dtype, row-major (the fp32 / NCHW epilogues do not apply mean / rstd)");
   ETAINV_CHECK(!p.hm_heads || igemm_hm_ok(p, dtype), "head-major QKV output: not available for this launch (ask igemm_hm_ok first)");
   if (p.hm_heads) p.hm_magic = (int)(((1ull << 38) + (unsigned)p.hm_tokens - 1) / (unsigned)p.hm_tokens);   // m0 / hm_tokens == (m0 * magic) >> 38 for m0 < 2^24, hm_tokens <= 2^14
+  if (pp_gemm_applicable(p, dtype)) {
+    ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)p.c1, s, igemm_algo_bytes(p));
+    return launch_pp_gemm(p, dtype, s);
+  }
   if (xs_gemm_applicable(p, dtype)) {   // K = 320 LayerNorm consumers with many rows: stationary activation tile, epilogue under the other wave group's MFMAs
     ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)p.c1, s, igemm_algo_bytes(p));
     return launch_xs_gemm(p, dtype, s);
@@ -1480,20 +1484,20 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   if (!p.geglu && p.ups == 2) {
     // conv3x3 behind a nearest-2x upsample as four 2 x 2 phase convs (4 / 9 of the FLOPs): its own instantiation of the ring (row decode, output scatter)
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, 2, 0>(p, s, stat_P)));
-  } else if (!p.geglu && p.ups == 1 && p.N % 160 == 0 && huge_tiles >= ring_min && !getenv("ETAINV_NO_RING")) {
+  } else if (!p.geglu && p.ups == 1 && p.N % 160 == 0 && huge_tiles >= ring_min && !env_on("ETAINV_NO_RING")) {
     // the nine-tap form (images that are not whole 256-row tiles per phase): the ring's issue is branch-free, so its addressing is its own instantiation
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, 1, 0>(p, s, stat_P)));
   } else if (!p.geglu && p.taps == 9 && p.stride == 1 && !p.ups && !p.a2 && !p.pad0 && p.H % 16 == 0 && p.W % 16 == 0 && p.H == p.Ho && p.W == p.Wo &&
              p.N % 160 == 0 && huge_tiles >= ring_min && !p.ln_stat && !p.out_nchw && !p.out_f32 && !p.w_batch_stride &&
-             (!p.stat_out || p.stat_kind == 1) && !(getenv("ETAINV_PATCHCONV") && atoi(getenv("ETAINV_PATCHCONV")) == 0) && !getenv("ETAINV_NO_RING")) {
+             (!p.stat_out || p.stat_kind == 1) && env_flag("ETAINV_PATCHCONV", true) && !env_on("ETAINV_NO_RING")) {
     // conv3x3 stride 1 on 16-pixel-aligned images: 16 x 16 pixel patches, the halo'd activation patch of a channel chunk loaded once for all nine taps
     // (same-box A/B, 128 rows: -1 ... -5 % per launch from the 16 x 16 level up, +1 % on the benchmark step; ETAINV_PATCHCONV=0 keeps the tap-major tiles)
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, 0, 0, true>(p, s, stat_P)));
-  } else if (!p.geglu && !p.ups && p.N % 160 == 0 && huge_tiles >= ring_min && ln_ring_ok && !getenv("ETAINV_NO_RING")) {   // (a fused upsample that did not fill the ring runs on the two-slot kernels below)
+  } else if (!p.geglu && !p.ups && p.N % 160 == 0 && huge_tiles >= ring_min && ln_ring_ok && !env_on("ETAINV_NO_RING")) {   // (a fused upsample that did not fill the ring runs on the two-slot kernels below)
     // experimental (opt-in): 256 x 160 x 64 tile, 8 waves, one resident block per CU (26 % fewer L2 -> LDS bytes per
     // FLOP).  Measured equal to 128 x 160 with two resident blocks (1026 vs 1033 TFLOP/s on conv 1280->1280 @16x16)
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, 0, 0>(p, s, stat_P)));
-  } else if (p.geglu && ln_ring_ok && p.c1 >= (getenv("ETAINV_GEGLU_RING_MINK") ? atoi(getenv("ETAINV_GEGLU_RING_MINK")) : 320) && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 128) >= 256 && !getenv("ETAINV_NO_RING")) {
+  } else if (p.geglu && ln_ring_ok && p.c1 >= (getenv("ETAINV_GEGLU_RING_MINK") ? atoi(getenv("ETAINV_GEGLU_RING_MINK")) : 320) && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 128) >= 256 && !env_on("ETAINV_NO_RING")) {
     // (since the interleaved windows the ring also wins at K = 320: 1.42 vs 1.55 ms for ff1 320 -> 2560 at 64 x 64 x 128 rows)
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 128, 4, 3, 0, 0>(p, s, stat_P)));
   } else {
@@ -1509,7 +1513,7 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
     const int64_t tiles = (int64_t)cdiv(p.M, bm) * cdiv(p.N, bn);
     const int nk = p.taps * (p.c1 + p.c2) / BK;
     int ks = 1;
-    if (!p.geglu && !p.out_nchw && !p.out_f32 && tiles * 2 <= slots && nk >= 16 && !getenv("ETAINV_NO_SPLITK")) {
+    if (!p.geglu && !p.out_nchw && !p.out_f32 && tiles * 2 <= slots && nk >= 16 && !env_on("ETAINV_NO_SPLITK")) {
       static const int max_split = getenv("ETAINV_SPLITK_MAX") ? atoi(getenv("ETAINV_SPLITK_MAX")) : 32;
       for (int d = 2; d <= max_split; ++d)
         if (nk % d == 0 && nk / d >= 4 && tiles * d <= slots && (int64_t)p.M * p.N * d * 4 <= SPLITK_WS_BYTES) ks = d;

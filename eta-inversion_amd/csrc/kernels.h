@@ -58,13 +58,17 @@ struct IGemmParams {
 };
 // stat_P (optional): receives the number of partials per row written to p.stat_out (0: none written)
 int launch_igemm(const IGemmParams& p, int dtype, hipStream_t s, int* stat_P = nullptr);
-bool igemm_hm_ok(const IGemmParams& p, int dtype);
-bool igemm_ups4_ok(const IGemmParams& p, int dtype);   // may this launch run the phase form (ups == 2, taps == 4) of a fused-upsample conv?   // may this launch (with hm_* set) write the head-major layout?
+bool igemm_hm_ok(const IGemmParams& p, int dtype);     // may this launch (with hm_* set) write the head-major layout?
+bool igemm_ups4_ok(const IGemmParams& p, int dtype);   // may this launch run the phase form (ups == 2, taps == 4) of a fused-upsample conv?
 
 // ---- xsgemm.hip: K = 320 LayerNorm-consumer projections (GEGLU, fused QKV) of the L^2-token blocks on a stationary activation tile with two wave
 // groups in anti-phase; launch_igemm routes to it when xs_gemm_applicable (bit-identical results)
 bool xs_gemm_applicable(const IGemmParams& p, int dtype);
 int launch_xs_gemm(const IGemmParams& p, int dtype, hipStream_t s);
+
+// ---- ppgemm.hip: the 256 x 160 tile with its two wave groups in anti-phase (ping-pong); launch_igemm routes to it when pp_gemm_applicable
+bool pp_gemm_applicable(const IGemmParams& p, int dtype);
+int launch_pp_gemm(const IGemmParams& p, int dtype, hipStream_t s);
 
 // ---- f32path.hip: the fp32-operand execution (dtype == ETAINV_F32 routes here from the launchers of igemm / norm / attention)
 int launch_igemm_f32(const IGemmParams& p, hipStream_t s);

@@ -442,7 +442,7 @@ static inline int gn_apply_blocks() {
 // apply-pass instantiation: 0 = flat mode (C = 320 / 640: 320 vector items per wave iteration; -18 ... -25 % there, the wider tensors -- whose
 // rounds were already full -- lose a few percent to the extra index arithmetic), else vectors per lane
 static inline int gn_apply_mode(int C) {
-  static const bool no_flat = getenv("ETAINV_GN_NOFLAT") != nullptr;
+  static const bool no_flat = env_on("ETAINV_GN_NOFLAT");
   const int nvec = C >> 3;
   if (!no_flat && (nvec == 40 || nvec == 80)) return 0;
   return (nvec + 63) / 64;

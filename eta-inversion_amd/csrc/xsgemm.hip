@@ -364,7 +364,7 @@ int launch_xs_t(const XsParams& p, hipStream_t s) {
   const int num_mt = p.M / XS_BM;
   const int grid = num_mt < 256 ? num_mt : 256;
 #ifdef XS_STAMPS
-  if (getenv("ETAINV_XS_STAMPS")) {
+  if (env_on("ETAINV_XS_STAMPS")) {
     static unsigned long long* d = nullptr;
     if (!d) (void)hipMalloc(&d, 256 * 8 * 8 * sizeof(unsigned long long));
     XsParams ps = p;
@@ -398,8 +398,7 @@ int launch_xs_t(const XsParams& p, hipStream_t s) {
 // of 128 (GEGLU) / 96 (plain) columns.  OPT-IN (ETAINV_XSGEMM=1): measured on MI355X the kernel is SLOWER than the ring kernels (GEGLU 1.68 vs 1.31 ms,
 // QKV 0.72 vs 0.55 ms at 128 rows: profiles/r04_xsgemm_stamps.log) -- see DESIGN.md section 8 for what the in-kernel stamps say about why.
 bool xs_gemm_applicable(const IGemmParams& p, int dtype) {
-  const char* on = getenv("ETAINV_XSGEMM");   // (read per launch: the parity tests switch it inside one process)
-  if (!on || atoi(on) == 0 || (dtype != ETAINV_F16 && dtype != ETAINV_BF16)) return false;
+  if (!env_on("ETAINV_XSGEMM") || (dtype != ETAINV_F16 && dtype != ETAINV_BF16)) return false;
   if (!p.ln_stat || !p.ln_s || !p.bias || p.taps != 1 || p.a2 || p.c1 != 320 || p.residual || p.rowvec || p.out_f32 || p.out_nchw || p.stat_out ||
       p.w_batch_stride || p.ksplit > 1)
     return false;

@@ -124,8 +124,8 @@ enum etainv_attn_mode { ETAINV_ATTN_PLAIN = 0, ETAINV_ATTN_STORE = 1, ETAINV_ATT
 typedef struct etainv_attn_ctrl {
   int mode;
   int n_img;
-  /* STORE / PTP: accumulate the cond-half cross-attention probabilities of the (L/4)^2-token layers
-   * (AttentionStore, modules/utils/ptp.py:143-183) into the engine's map store. */
+  /* STORE / PTP: accumulate the cond-half cross-attention probabilities of the layers the store keeps -- the five (L/4)^2-token layers by default,
+   * the (L/2)^2 or (L/8)^2 ones after etainv_maps_configure -- (AttentionStore, modules/utils/ptp.py:143-183) into the engine's map store. */
   int store_maps;
   /* PTP cross edit (AttentionControlEdit.forward, modules/utils/ptp.py:205-218; Refine :245-258; Reweight
    * :261-274; Replace :234-242).  cross_alpha is the row of cross_replace_alpha for the current step. */
@@ -150,7 +150,8 @@ typedef struct etainv_attn_ctrl {
    * For backward steps with eta == 0 in which nothing is injected from the source any more (cross_replace_alpha row all zero, self-replace over): the
    * cond source row then only feeds the AttentionStore of the five (L/4)^2 cross layers (LocalBlend, modules/utils/ptp.py:37-39), the last of which is
    * block 9 -- its noise prediction is unused (the source latent is replayed).  Needs mapper == replace_mat == NULL; while self_replace_active the exit
-   * must lie behind the last (L/2)^2-token self-attention (block 12). */
+   * must lie behind the last (L/2)^2-token self-attention (block 12); with store_maps it must not lie in front of the last layer the store keeps
+   * (etainv_maps_configure: res_div 2 -> block 12, 4 -> block 9, 8 -> block 6) -- an earlier exit is an error, not a silent loss of maps. */
   int src_exit_block;
   int reserved[2];
 } etainv_attn_ctrl;

@@ -90,12 +90,23 @@ def oracle_worker(a):
 
 
 # ------------------------------------------------------------------------------------------------ native runs
-def native_run(dtype, S, L, n_pairs):
+def native_run(dtype, S, L, n_pairs, batch=None):
+    """batch (>= n_pairs): the n_pairs oracle-traced pairs are images 0 .. n_pairs-1 of a `batch`-image call; the other images cycle through the same
+    prompt pairs with latents / contexts of their own (tests/test_bench_shape_gpu.py: the benchmark's B = 32).  Returns the runs of ALL images."""
     from oracle import ptp as optp                       # host-side table builders only (checker infrastructure, like the tests)
     from etainv.engine import Engine
     from etainv.pipeline import EtaLoop, PtpTables, noise_table
     pairs, z0, ctx_src, ctx_tgt = inputs(n_pairs, L)
     B = n_pairs
+    if batch is not None and batch > n_pairs:
+        g = torch.Generator().manual_seed(321)
+        extra = batch - n_pairs
+        pairs = pairs + [pairs[i % n_pairs] for i in range(extra)]
+        z0 = torch.cat([z0, 0.8 * torch.randn(extra, 4, L, L, generator=g)])
+        xs, xt = torch.randn(extra, 2, 77, 768, generator=g), torch.randn(extra, 2, 77, 768, generator=g)
+        xt[:, 0] = xs[:, 0]
+        ctx_src, ctx_tgt = torch.cat([ctx_src, xs]), torch.cat([ctx_tgt, xt])
+        B = batch
     tok = optp.WordTokenizer()
     W = max(len(s.split(" ")) for s, _ in pairs)
     tokens = torch.ones(B, W, dtype=torch.int32)

@@ -415,17 +415,18 @@ def test_conv3x3_fused_upsample_phase_form(capi, dtype, b, h, wd, cin, cout):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("b,h,cin,cout,res", [(16, 64, 320, 320, True), (16, 64, 960, 320, False), (64, 32, 640, 640, True), (256, 16, 1280, 1280, False),
-                                              (7, 48, 320, 640, True)])
-def test_conv3x3_patch_mode(capi, dtype, monkeypatch, b, h, cin, cout, res):
+@pytest.mark.parametrize("b,h,wd,cin,cout,res", [(16, 64, 64, 320, 320, True), (16, 64, 64, 960, 320, False), (64, 32, 32, 640, 640, True),
+                                                 (256, 16, 16, 1280, 1280, False), (7, 48, 48, 320, 640, True), (48, 16, 32, 640, 640, True),
+                                                 (96, 32, 16, 320, 320, False)])
+def test_conv3x3_patch_mode(capi, dtype, monkeypatch, b, h, wd, cin, cout, res):
     """igemm.hip PATCH mode (ETAINV_PATCHCONV=1): an M tile is a 16 x 16 pixel patch whose halo'd 18 x 18 activation patch is brought to LDS once per
     channel chunk for all nine taps (K loop chunk-major).  Against F.conv2d and against the tap-major ring kernel (same fp32 accumulation of the same
-    products in another order: equal up to summation order); image borders, tile borders inside an image, bias + time row + residual epilogues."""
+    products in another order: equal up to summation order); image borders, tile borders inside an image, non-square images (the dispatch takes any H, W that are multiples of 16), bias + time row + residual epilogues."""
     lib = capi.load()
-    x = rnd(b, cin, h, h, seed=1, dtype=dtype)
+    x = rnd(b, cin, h, wd, seed=1, dtype=dtype)
     w = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5, dtype=dtype)
     bias, rowvec = rnd(cout, seed=3), rnd(b, cout, seed=5)
-    r = rnd(b, h, h, cout, seed=6, dtype=dtype) if res else None
+    r = rnd(b, h, wd, cout, seed=6, dtype=dtype) if res else None
     ref = F.conv2d(x.float(), w.float(), bias, padding=1) + rowvec[:, :, None, None]
     if res:
         ref = ref + r.float().permute(0, 3, 1, 2)
@@ -434,13 +435,13 @@ def test_conv3x3_patch_mode(capi, dtype, monkeypatch, b, h, cin, cout, res):
     outs = []
     for on in ("1", "0"):
         monkeypatch.setenv("ETAINV_PATCHCONV", on)
-        out = torch.full((b, h, h, cout), float("nan"), dtype=dtype, device="cuda")
-        capi.check(lib.etainv_op_conv3x3(capi.ptr(x_nhwc), None, cin, 0, capi.ptr(wk), capi.ptr(bias), capi.ptr(rowvec), capi.ptr(r), capi.ptr(out), b, h, h, cout,
+        out = torch.full((b, h, wd, cout), float("nan"), dtype=dtype, device="cuda")
+        capi.check(lib.etainv_op_conv3x3(capi.ptr(x_nhwc), None, cin, 0, capi.ptr(wk), capi.ptr(bias), capi.ptr(rowvec), capi.ptr(r), capi.ptr(out), b, h, wd, cout,
                                          1, 0, 9, capi.dtype_code(dtype), capi.stream_ptr()))
         torch.cuda.synchronize()
         outs.append(out)
     e1, e0, ed = relerr(outs[0].permute(0, 3, 1, 2), ref), relerr(outs[1].permute(0, 3, 1, 2), ref), relerr(outs[0], outs[1])
-    print(f"conv3x3 {b}x{h}x{h}x{cin}->{cout} {dtype}: patch mode {e1:.2e}, ring {e0:.2e} vs F.conv2d; patch vs ring {ed:.2e}")
+    print(f"conv3x3 {b}x{h}x{wd}x{cin}->{cout} {dtype}: patch mode {e1:.2e}, ring {e0:.2e} vs F.conv2d; patch vs ring {ed:.2e}")
     assert e1 < TOL[dtype] and e0 < TOL[dtype]
     assert ed < 0.5 * TOL[dtype]
     # per-image, per-patch-row worst case (a misplaced row hides in a global norm)
