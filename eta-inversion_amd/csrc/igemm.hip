@@ -1456,7 +1456,7 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   if (p.hm_heads) p.hm_magic = (int)(((1ull << 38) + (unsigned)p.hm_tokens - 1) / (unsigned)p.hm_tokens);   // m0 / hm_tokens == (m0 * magic) >> 38 for m0 < 2^24, hm_tokens <= 2^14
   if (pp_gemm_applicable(p, dtype)) {
     ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)p.c1, s, igemm_algo_bytes(p));
-    return launch_pp_gemm(p, dtype, s);
+    return launch_pp_gemm(p, dtype, s, stat_P);
   }
   if (xs_gemm_applicable(p, dtype)) {   // K = 320 LayerNorm consumers with many rows: stationary activation tile, epilogue under the other wave group's MFMAs
     ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)p.c1, s, igemm_algo_bytes(p));

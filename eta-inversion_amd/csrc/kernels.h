@@ -66,9 +66,10 @@ bool igemm_ups4_ok(const IGemmParams& p, int dtype);   // may this launch run th
 bool xs_gemm_applicable(const IGemmParams& p, int dtype);
 int launch_xs_gemm(const IGemmParams& p, int dtype, hipStream_t s);
 
-// ---- ppgemm.hip: the 256 x 160 tile with its two wave groups in anti-phase (ping-pong); launch_igemm routes to it when pp_gemm_applicable
+// ---- ppgemm.hip: the 256 x 160 tile with its two wave groups in anti-phase (ping-pong) and the epilogue of a tile under the next tile's main loop (two
+// accumulator sets): 1x1 / Linear with bias (+ residual, + LayerNorm row statistics), K >= 320; launch_igemm routes to it when pp_gemm_applicable
 bool pp_gemm_applicable(const IGemmParams& p, int dtype);
-int launch_pp_gemm(const IGemmParams& p, int dtype, hipStream_t s);
+int launch_pp_gemm(const IGemmParams& p, int dtype, hipStream_t s, int* stat_P = nullptr);
 
 // ---- f32path.hip: the fp32-operand execution (dtype == ETAINV_F32 routes here from the launchers of igemm / norm / attention)
 int launch_igemm_f32(const IGemmParams& p, hipStream_t s);

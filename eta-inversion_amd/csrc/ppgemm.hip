@@ -1,32 +1,38 @@
-// Ping-pong implicit GEMM for gfx950: the 256 x 160 x 64 tile of igemm.hip's ring with its two wave groups in ANTI-PHASE.
+// Ping-pong GEMM for the short-K 1x1 / Linear layers of the transformer blocks (gfx950): the 256 x 160 x 64 tile of igemm.hip's ring with
+//   (1) its two wave groups in ANTI-PHASE, one fragment set per wave, and
+//   (2) TWO accumulator sets: the epilogue of tile t runs in slices inside the memory phases of tile t + 1.
 //
-// Why (round 5): the ring kernel runs all eight waves of a block through the same program in lockstep -- both waves of every SIMD reach their matrix
-// clusters, their LDS read bursts and the K-step rendezvous together.  In-kernel stamps (profiles/r04_conv_patch_stamps_after.log) put ~600 of the
-// ~2370 cycles of a K step in that rendezvous with the matrix pipe idle; SQ counters (profiles/r05_pmc_sq_rows128.json) read 0.50 MFMA-busy for the conv
-// instantiation and 0.23-0.37 for the short-K ones.  Here waves 0-3 (group E, one per SIMD) and waves 4-7 (group L) run the same program ONE PHASE apart:
+// Why (round 5, measured: profiles/r05_pp_ablation.log, r05_pmc_sq_rows128.json).  The ring kernel runs its eight waves in lockstep; for the K = 320 .. 1280
+// GEMMs a tile is 5 .. 20 K steps of ~2400 cycles each -- bound by the LDS-DMA fill rate of the CU (52 KB per step at ~23 B/clk; the matrix pipe needs 1280
+// cycles per step) -- followed by an epilogue of ~7000 cycles (bias / residual / convert / stores, LayerNorm statistics) during which the matrix pipe AND
+// the DMA stream of the block stand still: 0.23-0.37 MFMA-busy in the SQ counters.  With the loop DMA-bound there is matrix and VALU time to spare inside it;
+// what is missing is a place for the epilogue to run.  Structure here:
 //
-//   phase of a wave = one 32-deep k-half of a K step:   MEM: 9 ds_read_b128 (its fragments of that half) + its share of the LDS-DMA issue
+//   phase of a wave = one 32-deep k-half of a K step:   MEM: 9 ds_read_b128 (its fragments of that half), its share of the LDS-DMA issue (addresses =
+//                                                             scalar base + a per-lane byte offset held in a register: no address arithmetic in the loop),
+//                                                             one SLICE of the previous tile's epilogue, lgkmcnt(0)
 //                                                        s_barrier
-//                                                        COMPUTE: s_setprio 1, 20 MFMAs 16x16x32 on the fragments, s_setprio 0
+//                                                        COMPUTE: s_setprio 1, 20 MFMAs 16x16x32 into the accumulator set of the tile's parity, s_setprio 0
 //                                                        s_barrier
-//   group L executes one extra s_barrier up front, so in every barrier interval one group computes while the other reads / issues: each SIMD's
-//   matrix pipe always has exactly one wave feeding it, and the memory instructions of a phase are issued by four waves at once under the other four
-//   waves' MFMAs (MI355X_MICROARCH.md "Two waves per SIMD", cdna_hip_programming.md "The 256^2 8-phase template").
+//   Waves 4-7 (group L) execute one extra s_barrier up front: in every barrier interval one wave of each SIMD computes while its partner is in a MEM phase
+//   (MI355X_MICROARCH.md "Two waves per SIMD"; cdna_hip_programming.md "The 256^2 8-phase template").  Alone (no DMA, no reads) the structure issues MFMAs
+//   for 96 % of the time.
 //
-// A wave needs ONE fragment set (36 VGPRs instead of the ring's 72: reads never overlap the wave's own MFMAs), which leaves room for a SECOND
-// accumulator set: the epilogue of tile t (bias / residual / convert / stores) is cut into slices that run in the MEM phases of tile t+1 while the
-// accumulators of t+1 fill -- the short-K GEMMs of the transformer blocks (K = 320: five K steps) no longer stop the matrix pipe for an epilogue as
-// long as their main loop.
+// Epilogue slices of tile t - 1 (accumulator set 1 - P): row group i of the wave tile in MEM phase ph = i (= 2 k + h, k < 2) of tile t -- residual loads
+// (inline asm: hipcc must not count them -- beside LDS-DMA it drains the whole queue at the first use of an ordinary load; the lines were brought to L2
+// a tile earlier by three touch pieces per wave aimed at the LDS dummy area), the phase's DMA pieces, a counted wait, then bias + residual, convert, lane
+// swap, three stores (+ the LayerNorm row statistics of the stored values).  The residual registers live inside one phase only.
+// vmcnt bookkeeping (loads, stores and LDS-DMA retire in issue order): every wait is a compile-time count of the operations issued BEHIND the ones that
+// must have landed -- wait_tile() below; an unexpected extra operation (bias or touch piece) only makes a wait cover more.  The counts need DMA issue in the
+// first four phases of every tile: launches with K >= 320 only (five K steps: the last tile of a block still issues through its step 2).
 //
-// LDS: 3-slot ring of [256 + 160 rows][64] K tiles exactly as in igemm.hip (row = 8 chunks of 16 B, physical chunk = chunk ^ (row & 7), filled
-// lane-linearly by global_load_lds_dwordx4 with the swizzle on the SOURCE chunk).  Hazards, in barrier intervals (group E reads half h of step s in
-// interval 4 s + 2 h, group L one interval later; a read issued in interval i has completed before the barrier that ends interval i + 1):
-//   * K tile s+2 goes into the slot of step s-1, whose last reads are L's in interval 4 s - 1: its first pieces are issued in a wave's MEM phase of
-//     (s, half 1) = interval 4 s + 2 / 4 s + 3, the rest in MEM (s + 1, half 0)                       -> WAR distance >= 3 intervals;
-//   * every wave waits (counted vmcnt) for its own pieces of step s+1 at the end of its MEM phase of (s, half 1); the barrier behind that wait
-//     precedes the first read of step s+1 (E: interval 4 s + 4)                                      -> RAW: wait, barrier, then read.
-// Operand / accumulator conventions are igemm.hip's (weights = MFMA A operand, activations = B: a lane holds 4 consecutive output channels of one
-// pixel row), and so is the accumulation order over K: results are bit-identical to the ring kernel's.
+// LDS: 3-slot ring of [256 + 160 rows][64] K tiles exactly as in igemm.hip (row = 8 chunks of 16 B, physical chunk = chunk ^ (row & 7), filled lane-linearly
+// by global_load_lds_dwordx4 with the swizzle on the SOURCE chunk).  Hazards, in barrier intervals (E reads half h of step s in interval 4 s + 2 h, L one later;
+// reads are waited for before the barrier that ends their MEM phase):
+//   * K tile s + 2 goes into the slot of step s - 1 (last read: L, interval 4 s - 1): weight pieces in MEM (s, half 0) = interval >= 4 s, activation
+//     pieces in MEM (s, half 1);
+//   * a wave waits for its own pieces of K tile s + 1 (issued >= 4 intervals earlier) in MEM (s, half 1); the barrier behind it precedes the first read.
+// Operand / accumulator conventions and the accumulation order over K are igemm.hip's: results are bit-identical to the ring kernel's.
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -56,16 +62,27 @@ template <> struct PMfma<bf16> {
 
 constexpr int PBM = 256, PBN = 160, PBK = 64;
 constexpr int PMT = 4, PNT = 5;                 // wave tile 64 x 80 (4 x 2 waves)
-constexpr int PSLOT_A = PBM * PBK, PSLOT_B = PBN * PBK;
+constexpr int PA_BYTES = PBM * PBK * 2, PB_BYTES = PBN * PBK * 2;   // one ring slot of each operand
+constexpr int POFF_B = 3 * PA_BYTES, POFF_DUMMY = POFF_B + 3 * PB_BYTES, POFF_BIAS = POFF_DUMMY + 1024;
+constexpr int PLDS = POFF_BIAS + 4 * PBN * 4;
 
-template <typename T>
+// ---- the slice schedule and the counted waits derived from it.  Slice i (row group i of the previous tile) rides in MEM phase ph = i of the next tile:
+//   [residual: five 8-byte loads of the row group]  [the phase's DMA pieces]  [wait: the loads have landed, the pieces stay in flight]  [bias, residual,
+//   convert, lane swap, three stores (+ one for the LayerNorm row statistics)]  [fragment reads]
+constexpr bool slice_in(int ph) { return ph >= 0 && ph < 4; }
+constexpr int n_stores(bool ST, int ph) { return slice_in(ph) ? 3 + (ST ? 1 : 0) : 0; }
+constexpr int n_loads(bool RES, int ph) { return RES && slice_in(ph) ? PNT : 0; }
+// MEM (k, half 1), behind that phase's residual loads and in front of its activation pieces: operations behind the last piece of K tile s + 1 (issued in
+// phase 2 k - 1, in front of that phase's stores)
+constexpr int wait_tile(bool RES, bool ST, int k) {
+  return n_stores(ST, 2 * k - 1) + n_loads(RES, 2 * k) + 3 + n_stores(ST, 2 * k) + n_loads(RES, 2 * k + 1);
+}
+
+template <typename T, bool RES, bool STAT>
 __global__ void __launch_bounds__(512, 2) pp_gemm_kernel(IGemmParams p) {
   typedef typename PMfma<T>::frag frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* sA = reinterpret_cast<T*>(smem);              // [3][256][64]
-  T* sB = sA + 3 * PSLOT_A;                        // [3][160][64]
-  T* dummy = sB + 3 * PSLOT_B;                     // 1 KiB: target of the pieces of waves that have no row in the last, partial B pass
-  float* sBias = reinterpret_cast<float*>(dummy + 512);   // [4][160] bias of the tiles in flight
+  float* sBias = reinterpret_cast<float*>(smem + POFF_BIAS);   // [4][160] bias of the tiles in flight
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -73,14 +90,14 @@ __global__ void __launch_bounds__(512, 2) pp_gemm_kernel(IGemmParams p) {
   const int fr = lane & 15, fq = lane >> 4;
   const bool late = wid >= 4;                       // group L
 
-  const int K = p.c1;
+  const int K = p.c1, N = p.N;
   const int nk = K / PBK;
-  const int tiles_n = p.N / PBN;
+  const int tiles_n = N / PBN;
   const int total_tiles = (p.M / PBM) * tiles_n;
   const int G = gridDim.x;
   const int my_tiles = (total_tiles - (int)blockIdx.x + G - 1) / G;
   if (my_tiles <= 0) return;
-  auto tile_origin = [&](int i, int& m0, int& n0) {
+  auto tile_origin = [&](int i, int& m0, int& n0) __attribute__((always_inline)) {
     int v = blockIdx.x + i * G;
     if ((total_tiles & 7) == 0) v = (v & 7) * (total_tiles >> 3) + (v >> 3);   // XCD-contiguous tile runs, n fastest (as in igemm.hip)
     const int tm = v / tiles_n;
@@ -88,189 +105,343 @@ __global__ void __launch_bounds__(512, 2) pp_gemm_kernel(IGemmParams p) {
     n0 = (v - tm * tiles_n) * PBN;
   };
   const int total_steps = my_tiles * nk;
+  const bool no_dma = p.debug & 1, no_epi = p.debug & 2, no_mfma = p.debug & 4;   // timing-only ablations (ETAINV_IGEMM_DEBUG)
 
-  // ---- issue side: the (tile, K tile) position whose pieces go out next; row r = (tid >> 3) + 64 q of a tile, lane chunk swizzled at the source
-  const int lchunk = (tid & 7) ^ ((tid >> 3) & 7);
-  const int wrow0 = wid * 8;
-  const T* a_row[4];
-  const T* w_row[3];
-  int it_tile = 0, it_kt = 0, it_step = 0;          // it_step: flattened index of the K tile at the issue position
+  // ---- issue side.  Row r = (tid >> 3) + 64 q of a tile, the lane's 16-byte chunk swizzled at the source: byte offset of the lane inside the tile's operand
+  // panel, the same for both operands (both are [rows][K] with K contiguous); the tile / K-tile position is a scalar base
+  const unsigned lrow = tid >> 3;
+  unsigned voff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) voff[q] = ((lrow + 64 * q) * (unsigned)K + (((tid & 7) ^ (lrow & 7)) << 3)) * 2u;
+  const unsigned voff_b2 = wid < 4 ? voff[2] : voff[0];   // weight rows 128 .. 159: waves 0-3; the others re-read row group 0 into the dummy area (uniform counts)
+  const int wrow_b = wid * 8 * PBK * 2;                   // byte offset of the wave's 8-row piece inside a 64-row pass
+  // LDS-DMA in the SGPR-base form by inline asm: `global_load_lds_dwordx4 v_off, s[base:base+1]` with M0 = the piece's LDS address.  (Through the builtin
+  // hipcc's loop optimisations widen the lane offsets to 64-bit register pairs and rebuild a 64-bit address per piece -- 10 more registers and, once those
+  // spill, scratch reloads with vmcnt(0) inside the loop.)  No register destination: nothing for the compiler to mis-time; M0 is written in the statement
+  // that uses it and nothing else in this kernel uses M0.
+#define PP_DMA(BYTES_INSN, voff32, sbase, ldsaddr) \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t" BYTES_INSN " %0, %1" : : "v"(voff32), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(ldsaddr)) : "memory")
+  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+  const char* a_base = nullptr;
+  const char* w_base = nullptr;
+  int it_tile = 0, it_kt = 0, issued = 0, islot = 0;      // issue position: (tile, K tile), K tiles issued so far, ring slot of the position
   auto setup_issue = [&](int tile) __attribute__((always_inline)) {
     int m0, n0;
     tile_origin(tile, m0, n0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) a_row[q] = reinterpret_cast<const T*>(p.a1) + (int64_t)(m0 + (tid >> 3) + 64 * q) * K + lchunk * 8;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      int n = n0 + (tid >> 3) + 64 * q;
-      n = n < p.N ? n : p.N - 1;
-      w_row[q] = reinterpret_cast<const T*>(p.w) + (int64_t)n * K + lchunk * 8;
-    }
+    a_base = reinterpret_cast<const char*>(p.a1) + (int64_t)m0 * K * 2;
+    w_base = reinterpret_cast<const char*>(p.w) + (int64_t)n0 * K * 2;
     if (p.bias && wid < 3) {                        // 160 floats: waves 0, 1 whole, wave 2 its first 32 lanes
-      const int c = wid * 64 + lane;
-      if (c < PBN) PP_GLDS(p.bias + n0 + c, sBias + (tile & 3) * PBN + wid * 64, 4);
+      const char* gb = reinterpret_cast<const char*>(p.bias + n0 + wid * 64);
+      const unsigned db = lds0 + POFF_BIAS + ((tile & 3) * PBN + wid * 64) * 4;
+      if (wid * 64 + lane < PBN) PP_DMA("global_load_lds_dword", (unsigned)(lane * 4), gb, db);
     }
-  };
-  auto issue_a = [&](int q0, int q1) __attribute__((always_inline)) {
-    T* dA = sA + (it_step % 3) * PSLOT_A;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (q >= q0 && q < q1) PP_GLDS(a_row[q] + it_kt * PBK, dA + (wrow0 + 64 * q) * PBK, 16);
   };
   auto issue_b = [&]() __attribute__((always_inline)) {
-    T* dB = sB + (it_step % 3) * PSLOT_B;
-    PP_GLDS(w_row[0] + it_kt * PBK, dB + wrow0 * PBK, 16);
-    PP_GLDS(w_row[1] + it_kt * PBK, dB + (wrow0 + 64) * PBK, 16);
-    PP_GLDS(w_row[2] + it_kt * PBK, wid < 4 ? dB + (wrow0 + 128) * PBK : dummy, 16);   // rows 128 .. 159: waves 0-3; the others aim at the dummy area (uniform counts)
+    if (no_dma) return;
+    const char* g = w_base + it_kt * (PBK * 2);
+    const unsigned d = lds0 + POFF_B + islot * PB_BYTES + wrow_b;
+    PP_DMA("global_load_lds_dwordx4", voff[0], g, d);
+    PP_DMA("global_load_lds_dwordx4", voff[1], g, d + 64 * PBK * 2);
+    PP_DMA("global_load_lds_dwordx4", voff_b2, g, wid < 4 ? d + 128 * PBK * 2 : lds0 + POFF_DUMMY);
+  };
+  auto issue_a = [&]() __attribute__((always_inline)) {
+    if (no_dma) return;
+    const char* g = a_base + it_kt * (PBK * 2);
+    const unsigned d = lds0 + islot * PA_BYTES + wrow_b;
+    PP_DMA("global_load_lds_dwordx4", voff[0], g, d);
+    PP_DMA("global_load_lds_dwordx4", voff[1], g, d + 1 * (64 * PBK * 2));
+    PP_DMA("global_load_lds_dwordx4", voff[2], g, d + 2 * (64 * PBK * 2));
+    PP_DMA("global_load_lds_dwordx4", voff[3], g, d + 3 * (64 * PBK * 2));
   };
   auto advance = [&]() __attribute__((always_inline)) {
-    ++it_step;
+    ++issued;
+    islot = islot == 2 ? 0 : islot + 1;
     if (++it_kt == nk) {
       it_kt = 0;
       if (++it_tile < my_tiles) setup_issue(it_tile);
     }
   };
 
-  f32x4 acc[PMT][PNT];
+  // ---- compute side
+  f32x4 acc0[PMT][PNT], acc1[PMT][PNT];            // (never zeroed: the first cluster of a tile takes C = 0; a row group's registers are free once its slice has stored it)
+  u32x4 fa[PMT] = {}, fb[PNT] = {};
+  unsigned a_rd[2], b_rd[2];                       // the lane's fragment byte offsets inside a slot, per k-half (row & 7 == fr & 7 for every row group)
 #pragma unroll
-  for (int i = 0; i < PMT; ++i)
+  for (int kk = 0; kk < 2; ++kk) {
+    a_rd[kk] = ((wm * 64 + fr) * PBK + (((kk * 4 + fq) ^ (fr & 7)) << 3)) * 2;
+    b_rd[kk] = POFF_B + ((wn * 80 + fr) * PBK + (((kk * 4 + fq) ^ (fr & 7)) << 3)) * 2;
+  }
+  auto read_frags = [&](int slot, auto kk_tag) __attribute__((always_inline)) {
+    constexpr int kk = decltype(kk_tag)::value;
+    const char* ba = smem + slot * PA_BYTES + a_rd[kk];
+    const char* bb = smem + slot * PB_BYTES + b_rd[kk];
 #pragma unroll
-    for (int j = 0; j < PNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  u32x4 fa[PMT], fb[PNT];
-
-  auto read_frags = [&](int slot, int kk) __attribute__((always_inline)) {
-    const T* tA = sA + slot * PSLOT_A;
-    const T* tB = sB + slot * PSLOT_B;
+    for (int i = 0; i < PMT; ++i) fa[i] = *reinterpret_cast<const u32x4*>(ba + i * (16 * PBK * 2));
 #pragma unroll
-    for (int i = 0; i < PMT; ++i) {
-      const int row = wm * 64 + i * 16 + fr;
-      fa[i] = *reinterpret_cast<const u32x4*>(tA + row * PBK + (((kk * 4 + fq) ^ (row & 7)) << 3));
-    }
-#pragma unroll
-    for (int j = 0; j < PNT; ++j) {
-      const int row = wn * 80 + j * 16 + fr;
-      fb[j] = *reinterpret_cast<const u32x4*>(tB + row * PBK + (((kk * 4 + fq) ^ (row & 7)) << 3));
-    }
+    for (int j = 0; j < PNT; ++j) fb[j] = *reinterpret_cast<const u32x4*>(bb + j * (16 * PBK * 2));
   };
-  auto compute = [&]() __attribute__((always_inline)) {
-    PP_LGKMCNT0();
+  auto cluster = [&](auto p_tag, auto first_tag) __attribute__((always_inline)) {
+    constexpr int P = decltype(p_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
+    if (!no_mfma) {
 #pragma unroll
-    for (int i = 0; i < PMT; ++i)
+      for (int i = 0; i < PMT; ++i)
 #pragma unroll
-      for (int j = 0; j < PNT; ++j) acc[i][j] = PMfma<T>::run(__builtin_bit_cast(frag, fb[j]), __builtin_bit_cast(frag, fa[i]), acc[i][j]);
+        for (int j = 0; j < PNT; ++j) {
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (P == 0) acc0[i][j] = PMfma<T>::run(__builtin_bit_cast(frag, fb[j]), __builtin_bit_cast(frag, fa[i]), FIRST ? z : acc0[i][j]);
+          else acc1[i][j] = PMfma<T>::run(__builtin_bit_cast(frag, fb[j]), __builtin_bit_cast(frag, fa[i]), FIRST ? z : acc1[i][j]);
+        }
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  T* out = reinterpret_cast<T*>(p.out);
-  const T* res = reinterpret_cast<const T*>(p.residual);
-  auto epilogue = [&](int tile) __attribute__((always_inline)) {
+  // ---- epilogue of one tile, by row group (lane: pixel row m = m0 + wm * 64 + i * 16 + fr, channels n0 + wn * 80 + j * 16 + fq * 4 .. + 3)
+  T* const out = reinterpret_cast<T*>(p.out);
+  const T* const res = reinterpret_cast<const T*>(p.residual);
+  const int64_t rg_stride = (int64_t)16 * N;        // elements between two row groups
+  // addresses = scalar element offset of the tile's origin (ep_base) + a per-lane byte offset that is the same for every tile (ep_lane: row group 0,
+  // channel block 0 of the lane)
+  int64_t ep_base = 0;
+  const unsigned ep_lane = (unsigned)(((wm * 64 + fr) * N + wn * 80 + fq * 4) * 2);
+  int ep_tile = 0, ep_m = 0, ep_pidx = 0;
+  auto ep_begin = [&](int tile) __attribute__((always_inline)) {
     int m0, n0;
     tile_origin(tile, m0, n0);
-    const float* tb = sBias + (tile & 3) * PBN + wn * 80;
-    f32x4 bv[PNT];
-#pragma unroll
-    for (int j = 0; j < PNT; ++j) bv[j] = p.bias ? *reinterpret_cast<const f32x4*>(tb + j * 16 + fq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    u32x2 rv[PMT][PNT];
-    if (res) {
-#pragma unroll
-      for (int i = 0; i < PMT; ++i)
-#pragma unroll
-        for (int j = 0; j < PNT; ++j)
-          rv[i][j] = *reinterpret_cast<const u32x2*>(res + (int64_t)(m0 + wm * 64 + i * 16 + fr) * p.N + n0 + wn * 80 + j * 16 + fq * 4);
+    ep_tile = tile;
+    ep_m = m0 + wm * 64 + fr;
+    ep_pidx = n0 / 80 + wn;
+    ep_base = (int64_t)m0 * N + n0;
+  };
+  // (one asm statement per row group: five loads in the SGPR-base form, early-clobber outputs)
+#define PP_RES_LOAD5(RV, voff32, sbase)                                                                                                                  \
+  asm volatile("global_load_dwordx2 %0, %5, %6\n\tglobal_load_dwordx2 %1, %5, %6 offset:32\n\tglobal_load_dwordx2 %2, %5, %6 offset:64\n\t"              \
+               "global_load_dwordx2 %3, %5, %6 offset:96\n\tglobal_load_dwordx2 %4, %5, %6 offset:128"                                                  \
+               : "=&v"(RV[0]), "=&v"(RV[1]), "=&v"(RV[2]), "=&v"(RV[3]), "=&v"(RV[4]) : "v"(voff32), "s"(sbase) : "memory")
+  // wait until at most n operations are in flight, then the residual registers may be read (names them: no consumer is scheduled above the wait)
+#define PP_RES_WAIT(n, RV) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(RV[0]), "+v"(RV[1]), "+v"(RV[2]), "+v"(RV[3]), "+v"(RV[4]) : "i"(n) : "memory")
+  // the residual tile of `tile` towards L2: three dword pieces per wave (lane = pixel row of the wave tile, at byte 0 / 128 / 156 of its 160-byte span)
+  // aimed at the LDS dummy area -- no register destination
+  auto res_touch = [&](int tile) __attribute__((always_inline)) {
+    int m0, n0;
+    tile_origin(tile, m0, n0);
+    const char* g = reinterpret_cast<const char*>(res) + ((int64_t)(m0 + wm * 64) * N + n0 + wn * 80) * 2;
+    const unsigned row = (unsigned)lane * (unsigned)N * 2u;
+    PP_DMA("global_load_lds_dword", row, g, lds0 + POFF_DUMMY);
+    PP_DMA("global_load_lds_dword", row + 128u, g, lds0 + POFF_DUMMY + 256);
+    PP_DMA("global_load_lds_dword", row + 156u, g, lds0 + POFF_DUMMY + 512);
+  };
+  // one row group: [residual loads] [dma(): the phase's DMA issue, n_young pieces] [wait] [arithmetic, stores]
+  auto store_group = [&](auto p_tag, auto i_tag, auto dma, auto young_tag) __attribute__((always_inline)) {
+    constexpr int Q = decltype(p_tag)::value, i = decltype(i_tag)::value, YOUNG = decltype(young_tag)::value;
+    const float* tb = sBias + (ep_tile & 3) * PBN + wn * 80 + fq * 4;
+    unsigned long long rv[PNT];
+    if constexpr (RES) {
+      const char* g = reinterpret_cast<const char*>(res) + (ep_base + i * rg_stride) * 2;
+      const unsigned el = ep_lane;
+      PP_RES_LOAD5(rv, el, g);
     }
+    dma();
+    if constexpr (RES) {
+      PP_RES_WAIT(YOUNG, rv);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    u32x2 po[PNT];
 #pragma unroll
-    for (int i = 0; i < PMT; ++i) {
-      T* prow = out + (int64_t)(m0 + wm * 64 + i * 16 + fr) * p.N + n0 + wn * 80;
-      u32x2 po[PNT];
+    for (int j = 0; j < PNT; ++j) {
+      f32x4 v;
+      if constexpr (Q == 0) v = acc0[i][j];
+      else v = acc1[i][j];
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(tb + j * 16);
+      if constexpr (RES) {
+        const unsigned long long r64 = rv[j];
+        T r[4];
+        *reinterpret_cast<unsigned long long*>(r) = r64;
+        v[0] += to_f32(r[0]); v[1] += to_f32(r[1]); v[2] += to_f32(r[2]); v[3] += to_f32(r[3]);
+      }
+      T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+      po[j] = *reinterpret_cast<u32x2*>(o);
+    }
+    // 16-byte stores after a lane swap between adjacent 16-column blocks (igemm.hip store_row_group): 64-byte segments per pixel row
+    T* prow = reinterpret_cast<T*>(reinterpret_cast<char*>(out + ep_base + i * rg_stride) + (ep_lane - fq * 8));
+#pragma unroll
+    for (int k = 0; k + 1 < PNT; k += 2) {
+      const auto lo = __builtin_amdgcn_permlane16_swap(po[k][0], po[k + 1][0], false, false);
+      const auto hi = __builtin_amdgcn_permlane16_swap(po[k][1], po[k + 1][1], false, false);
+      const u32x4 v = {lo[0], hi[0], lo[1], hi[1]};
+      *reinterpret_cast<u32x4*>(prow + (k + (fq & 1)) * 16 + (fq >> 1) * 8) = v;
+    }
+    *reinterpret_cast<u32x2*>(prow + (PNT - 1) * 16 + fq * 4) = po[PNT - 1];
+    if constexpr (STAT) {
+      // LayerNorm producer (igemm.hip emit_row_stat): (mean, M2) of the 20 stored values of this lane, merged over the four fq lanes = the 80 columns of the
+      // wave tile -> partial ep_pidx of row m
+      float sum = 0.f;
 #pragma unroll
       for (int j = 0; j < PNT; ++j) {
-        f32x4 v = acc[i][j] + bv[j];
-        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (res) {
-          T r[4];
-          *reinterpret_cast<u32x2*>(r) = rv[i][j];
-          v[0] += to_f32(r[0]); v[1] += to_f32(r[1]); v[2] += to_f32(r[2]); v[3] += to_f32(r[3]);
-        }
-        T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
-        po[j] = *reinterpret_cast<u32x2*>(o);
+        T o[4];
+        *reinterpret_cast<u32x2*>(o) = po[j];
+        sum += (to_f32(o[0]) + to_f32(o[1])) + (to_f32(o[2]) + to_f32(o[3]));
       }
-      // 16-byte stores after a lane swap between adjacent 16-column blocks (igemm.hip store_row_group): 64-byte segments per pixel row
+      float mu = sum * (1.0f / (float)(PNT * 4)), m2 = 0.f;
 #pragma unroll
-      for (int k = 0; k + 1 < PNT; k += 2) {
-        const auto lo = __builtin_amdgcn_permlane16_swap(po[k][0], po[k + 1][0], false, false);
-        const auto hi = __builtin_amdgcn_permlane16_swap(po[k][1], po[k + 1][1], false, false);
-        const u32x4 v = {lo[0], hi[0], lo[1], hi[1]};
-        *reinterpret_cast<u32x4*>(prow + (k + (fq & 1)) * 16 + (fq >> 1) * 8) = v;
+      for (int j = 0; j < PNT; ++j) {
+        T o[4];
+        *reinterpret_cast<u32x2*>(o) = po[j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float d = to_f32(o[q]) - mu; m2 += d * d; }
       }
-      *reinterpret_cast<u32x2*>(prow + (PNT - 1) * 16 + fq * 4) = po[PNT - 1];
+      {
+        float ma = mu, mb = mu, qa = m2, qb = m2;     // rows fq 0 | 1 (and 2 | 3), then the halves
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
+        float d = mb - ma;
+        ma += 0.5f * d;
+        qa += qb + d * d * (0.5f * (float)(PNT * 4));
+        float m_lo = ma, m_hi = ma, q_lo = qa, q_hi = qa;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(m_lo), "+v"(m_hi));
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(q_lo), "+v"(q_hi));
+        d = m_hi - m_lo;
+        mu = m_lo + 0.5f * d;
+        m2 = q_lo;
+        m2 += q_hi + d * d * (0.5f * (float)(2 * PNT * 4));
+      }
+      if (fq == 0) *reinterpret_cast<f32x2*>(p.stat_out + ((int64_t)(ep_m + i * 16) * p.stat_P + ep_pidx) * 2) = (f32x2){mu, m2};   // (one exec-masked store instruction)
     }
+  };
+  auto full_epilogue = [&](auto p_tag, int tile) __attribute__((always_inline)) {   // not overlapped: the last tile of the block
+    if (no_epi) return;
+    ep_begin(tile);
+    auto nothing = [&]() __attribute__((always_inline)) {};
+    typedef std::integral_constant<int, 0> Y0;
+    store_group(p_tag, std::integral_constant<int, 0>{}, nothing, Y0{});
+    store_group(p_tag, std::integral_constant<int, 1>{}, nothing, Y0{});
+    store_group(p_tag, std::integral_constant<int, 2>{}, nothing, Y0{});
+    store_group(p_tag, std::integral_constant<int, 3>{}, nothing, Y0{});
   };
 
   // ---- prologue: K tiles 0 and 1 whole; wait for tile 0
+  if constexpr (RES) {
+    res_touch(0);
+    if (my_tiles > 1) res_touch(1);
+  }
   setup_issue(0);
-  issue_a(0, 4); issue_b(); advance();
-  if (total_steps > 1) { issue_a(0, 4); issue_b(); advance(); PP_VMCNT(7); } else { PP_VMCNT(0); }
+  issue_a(); issue_b(); advance();
+  if (total_steps > 1) { issue_a(); issue_b(); advance(); PP_VMCNT(7); } else { PP_VMCNT(0); }
   __builtin_amdgcn_s_barrier();
   if (late) __builtin_amdgcn_s_barrier();           // group L runs one interval behind
 
-  int slot = 0, ct_kt = 0, ct_tile = 0;
-  for (int s = 0; s < total_steps; ++s) {
-    // ---- (s, half 0): MEM
-    read_frags(slot, 0);
-    // rest of the K tile whose first activation pieces went out in the previous step's half 1 (none for s == 0: the prologue issued K tile 1 whole)
-    if (s > 0 && it_step < total_steps) { issue_a(2, 4); issue_b(); advance(); }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    compute();
-    __builtin_amdgcn_s_barrier();
-    // ---- (s, half 1): MEM
-    read_frags(slot, 1);
-    if (it_step < total_steps) {                    // first pieces of K tile s + 2 -> slot of step s - 1
-      issue_a(0, 2);
-      PP_VMCNT(2);                                  // everything of K tile s + 1 has landed (for this wave); the two pieces just issued stay in flight
-    } else {
-      PP_VMCNT(0);
+  int slot = 0;
+  // one tile into accumulator set P; has_prev: the four slices of the previous tile's epilogue (set 1 - P) ride in the MEM phases of its first two steps.
+  // Order of a MEM phase: (slice: residual loads,) DMA issue, (slice: wait, arithmetic, stores,) fragment reads -- the slice's temporaries are dead before
+  // the fragment registers are written (two accumulator sets + fragments + a slice do not fit 256 registers together); the loop is DMA-bound, the MEM phases
+  // have the time
+  auto tile_body = [&](auto p_tag, int tile, bool has_prev) __attribute__((always_inline)) {
+    typedef std::integral_constant<int, 1 - decltype(p_tag)::value> QT;
+    if (has_prev) ep_begin(tile - 1);
+    for (int k = 0; k < nk; ++k) {
+      const bool more = issued < total_steps;       // a K tile s + 2 exists: its pieces go out in this step
+      // ---- (k, half 0): MEM
+      auto dma_b = [&]() __attribute__((always_inline)) { if (more) issue_b(); };
+      if (has_prev && k < 2 && !no_epi) {
+        if (k == 0) store_group(QT{}, std::integral_constant<int, 0>{}, dma_b, std::integral_constant<int, 3>{});
+        else store_group(QT{}, std::integral_constant<int, 2>{}, dma_b, std::integral_constant<int, 3>{});
+      } else {
+        dma_b();
+        if (RES && k == 2 && tile + 1 < my_tiles) res_touch(tile + 1);   // (tile + 1's residual is read a whole tile later)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(slot, std::integral_constant<int, 0>{});
+      PP_LGKMCNT0();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      if (k == 0) cluster(p_tag, std::true_type{});
+      else cluster(p_tag, std::false_type{});
+      __builtin_amdgcn_s_barrier();
+      // ---- (k, half 1): MEM
+      auto dma_a = [&]() __attribute__((always_inline)) {
+        if (more) {
+          // K tile s + 1 has landed (for this wave); everything issued behind it stays in flight
+          if (!has_prev || k >= 3) PP_VMCNT(3);
+          else if (k == 0) PP_VMCNT(wait_tile(RES, STAT, 0));
+          else if (k == 1) PP_VMCNT(wait_tile(RES, STAT, 1));
+          else PP_VMCNT(wait_tile(RES, STAT, 2));
+          issue_a();
+          advance();
+        } else {
+          PP_VMCNT(0);
+        }
+      };
+      if (has_prev && k < 2 && !no_epi) {
+        if (k == 0) store_group(QT{}, std::integral_constant<int, 1>{}, dma_a, std::integral_constant<int, 4>{});
+        else store_group(QT{}, std::integral_constant<int, 3>{}, dma_a, std::integral_constant<int, 4>{});
+      } else {
+        dma_a();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(slot, std::integral_constant<int, 1>{});
+      PP_LGKMCNT0();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster(p_tag, std::false_type{});
+      __builtin_amdgcn_s_barrier();
+      slot = slot == 2 ? 0 : slot + 1;
     }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    compute();
-    __builtin_amdgcn_s_barrier();
-    slot = slot == 2 ? 0 : slot + 1;
-    if (++ct_kt == nk) {
-      epilogue(ct_tile);
-      ct_kt = 0;
-      ++ct_tile;
-    }
+  };
+  for (int t = 0; t < my_tiles; t += 2) {
+    tile_body(std::integral_constant<int, 0>{}, t, t > 0);
+    if (t + 1 < my_tiles) tile_body(std::integral_constant<int, 1>{}, t + 1, true);
   }
+  if ((my_tiles - 1) & 1) full_epilogue(std::integral_constant<int, 1>{}, my_tiles - 1);
+  else full_epilogue(std::integral_constant<int, 0>{}, my_tiles - 1);
   if (!late) __builtin_amdgcn_s_barrier();
 }
 
 }  // namespace
 
-// plain 1x1 / Linear launches on whole tiles (prototype scope of the ping-pong kernel; ETAINV_PP=1)
+// 1x1 / Linear launches on whole tiles with K >= 320 and a bias-only epilogue.  OPT-IN (ETAINV_PP=1), measured on MI355X (profiles/r05_pp_gemm_check.log):
+// bit-identical to the ring kernel and 3-10 % faster on the shapes it takes -- but the layers that matter carry a residual (+ LayerNorm statistics), and
+// the residual needs register-destination loads that hipcc must not count: every form of inline asm with a VGPR output inside the slice makes the
+// allocator spill 130-270 registers (plain loads compile to 245 registers but are waited for with vmcnt(0), which drains the DMA queue four times per
+// tile).  The RES / STAT instantiations below are therefore refused by the predicate (ETAINV_PP_FORCE_ALL=1 lets them through: spilling, 4-7x slower -- evidence only).
 bool pp_gemm_applicable(const IGemmParams& p, int dtype) {
+  static const int mode = getenv("ETAINV_PP_FORCE_ALL") ? 2 : 1;
   if (!env_on("ETAINV_PP") || (dtype != ETAINV_F16 && dtype != ETAINV_BF16)) return false;
-  if (p.taps != 1 || p.a2 || p.geglu || p.rowvec || p.out_f32 || p.out_nchw || p.stat_out || p.ln_stat || p.w_batch_stride || p.ksplit > 1 || p.hm_heads) return false;
-  if (p.M % PBM != 0 || p.N % PBN != 0 || p.c1 % PBK != 0 || p.c1 < 2 * PBK) return false;
-  return (int64_t)(p.M / PBM) * (p.N / PBN) >= 192;
+  if (mode < 2 && (p.residual || p.stat_out)) return false;
+  if (p.taps != 1 || p.a2 || p.geglu || p.rowvec || p.out_f32 || p.out_nchw || p.ln_stat || p.w_batch_stride || p.ksplit > 1 || p.hm_heads) return false;
+  if (p.stat_out && (p.stat_kind != 0 || p.rows_per_batch % 64 != 0)) return false;
+  if (p.M % PBM != 0 || p.N % PBN != 0 || p.c1 % PBK != 0 || p.c1 < 5 * PBK) return false;
+  return (int64_t)(p.M / PBM) * (p.N / PBN) >= 512;   // at least two tiles per block: the overlapped epilogue is the point
 }
 
-int launch_pp_gemm(const IGemmParams& p, int dtype, hipStream_t s) {
-  const size_t lds = (size_t)3 * (PSLOT_A + PSLOT_B) * 2 + 1024 + 4 * PBN * sizeof(float);
+int launch_pp_gemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P) {
+  IGemmParams p = p_in;
+  if (p.stat_out) p.stat_P = p.N / 80;              // one (mean, M2) partial per row and wave-tile column, as the ring kernel
+  if (stat_P) *stat_P = p.stat_out ? p.stat_P : 0;
   const int tiles = (p.M / PBM) * (p.N / PBN);
   const int grid = std::min(tiles, 256);
-  static bool attr_set[kMaxDevices][2] = {};
+  static bool attr_set[kMaxDevices] = {};
   const int dev = current_device();
+  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), PLDS, s, p); };
   ETAINV_DISPATCH_HALF(dtype, T, {
-    const int di = dtype == ETAINV_F16 ? 0 : 1;
-    if (!attr_set[dev][di]) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_gemm_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set[dev][di] = true;
+    if (!attr_set[dev]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_gemm_kernel<f16, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_gemm_kernel<f16, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_gemm_kernel<f16, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_gemm_kernel<f16, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_gemm_kernel<bf16, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_gemm_kernel<bf16, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_gemm_kernel<bf16, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_gemm_kernel<bf16, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+      attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(pp_gemm_kernel<T>, dim3(grid), dim3(512), lds, s, p);
+    if (p.residual) {
+      if (p.stat_out) go(pp_gemm_kernel<T, true, true>); else go(pp_gemm_kernel<T, true, false>);
+    } else {
+      if (p.stat_out) go(pp_gemm_kernel<T, false, true>); else go(pp_gemm_kernel<T, false, false>);
+    }
   });
   ETAINV_LAUNCH_CHECK();
   return 0;
