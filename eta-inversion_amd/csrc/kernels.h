@@ -70,6 +70,10 @@ int launch_xs_gemm(const IGemmParams& p, int dtype, hipStream_t s);
 // accumulator sets): 1x1 / Linear with bias (+ residual, + LayerNorm row statistics), K >= 320; launch_igemm routes to it when pp_gemm_applicable
 bool pp_gemm_applicable(const IGemmParams& p, int dtype);
 int launch_pp_gemm(const IGemmParams& p, int dtype, hipStream_t s, int* stat_P = nullptr);
+// dual-N form: a 256 x 320 output tile as two 160-column halves sharing one staged activation K tile (-31 % LDS-DMA bytes per FLOP; the 1x1 GEMMs are bound
+// by the DMA fill rate): bias (+ residual) (+ LayerNorm row statistics) epilogues
+bool pp_dualn_applicable(const IGemmParams& p, int dtype);
+int launch_pp_dualn(const IGemmParams& p, int dtype, hipStream_t s, int* stat_P = nullptr);
 
 // ---- f32path.hip: the fp32-operand execution (dtype == ETAINV_F32 routes here from the launchers of igemm / norm / attention)
 int launch_igemm_f32(const IGemmParams& p, hipStream_t s);

@@ -399,6 +399,301 @@ __global__ void __launch_bounds__(512, 2) pp_gemm_kernel(IGemmParams p) {
   if (!late) __builtin_amdgcn_s_barrier();
 }
 
+
+// ============================================================================================================================================================
+// Dual-N ping-pong GEMM: 256 x 320 output tile as TWO 160-column halves that share one activation K tile.
+//
+// Why: the ablations of the kernel above (profiles/r05_pp_ablation.log) say the main loop of every non-PATCH GEMM on the 256 x 160 tile is bound by the
+// LDS-DMA fill rate of the CU: 52 KB per K step arrive at ~23 B/clk (2300-2700 cycles) while the matrix pipe needs 1280.  Bytes per FLOP are the lever:
+// with both 160-column halves of a 320-column span computed from ONE staged activation tile, a K tile costs 32 KB (activations) + 2 x 20 KB (weights) =
+// 72 KB for twice the FLOPs = -31 % (and 14 instead of 18 fragment reads per 40 MFMAs).  Two accumulator sets of 80 registers hold the two halves -- which
+// the ping-pong form can afford (one fragment set) and the ring cannot (256 registers with two).  All channel counts of SD1.x are multiples of 320.
+//
+// A K tile is four phases per wave -- (kk 0, half 0), (kk 0, half 1), (kk 1, half 0), (kk 1, half 1): the activation fragments of a k-half are read in the
+// first phase of the pair and kept -- i.e. eight barrier intervals (group E: interval 8 s + 2 ph, group L one later).  LDS: TWO slots of [256 + 320 rows][64]
+// (144 KB), recycled by region (every wave finishes its fragment reads before the barrier that ends its MEM phase):
+//   activation rows of slot s:  last read in L's phase 2 (interval 8 s + 5)  -> the pieces of K tile s + 2 go out in phase 3 of tile s (>= interval 8 s + 6)
+//   weight rows 0 .. 159:       last read in L's phase 2                      -> K tile s + 2 rows 0 .. 127 in phase 0 of tile s + 1 (>= interval 8 s + 8)
+//   weight rows 160 .. 319:     last read in L's phase 3 (interval 8 s + 7)   -> rows 128 .. 255 in phase 1, rows 256 .. 319 in phase 2 of tile s + 1
+//   every wave waits for ALL its pieces of K tile s + 2 (vmcnt(0): nothing else is in flight) in phase 3 of tile s + 1, in front of the activation pieces of
+//   K tile s + 3; the barrier behind that wait precedes the first read of K tile s + 2.  The youngest piece waited for is two intervals old, the oldest eight.
+// Epilogue (bias, residual, LayerNorm row statistics -- igemm.hip's arithmetic, bit-identical results): per half, at the end of the output tile, not overlapped.
+constexpr int DBN = 320;                           // two halves of PBN
+constexpr int DA_BYTES = PBM * PBK * 2, DB_BYTES = DBN * PBK * 2, DSLOT = DA_BYTES + DB_BYTES;
+constexpr int DOFF_BIAS = 2 * DSLOT, DLDS = DOFF_BIAS + 4 * DBN * 4;
+
+template <typename T, bool RES, bool STAT>
+__global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
+  typedef typename PMfma<T>::frag frag;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sBias = reinterpret_cast<float*>(smem + DOFF_BIAS);   // [4][320] bias of the tiles in flight
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const bool late = wid >= 4;
+
+  const int K = p.c1, N = p.N;
+  const int nk = K / PBK;
+  const int tiles_n = N / DBN;
+  const int total_tiles = (p.M / PBM) * tiles_n;
+  const int G = gridDim.x;
+  const int my_tiles = (total_tiles - (int)blockIdx.x + G - 1) / G;
+  if (my_tiles <= 0) return;
+  auto tile_origin = [&](int i, int& m0, int& n0) __attribute__((always_inline)) {
+    int v = blockIdx.x + i * G;
+    if ((total_tiles & 7) == 0) v = (v & 7) * (total_tiles >> 3) + (v >> 3);
+    const int tm = v / tiles_n;
+    m0 = tm * PBM;
+    n0 = (v - tm * tiles_n) * DBN;
+  };
+  const int total_steps = my_tiles * nk;
+  const bool no_dma = p.debug & 1, no_epi = p.debug & 2;
+  const bool has_bias = p.bias != nullptr;
+
+  // ---- issue side: two cursors (the activation pieces of a K tile go out four phases before its weight pieces)
+  const unsigned lrow = tid >> 3;
+  unsigned voff[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) voff[q] = ((lrow + 64 * q) * (unsigned)K + (((tid & 7) ^ (lrow & 7)) << 3)) * 2u;
+  const int wrow_b = wid * 8 * PBK * 2;
+  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+  const char* a_base = nullptr;
+  const char* w_base = nullptr;
+  int a_tile = 0, a_kt = 0, a_cnt = 0;              // activation cursor: (tile, K tile), K tiles issued
+  int b_tile = 0, b_kt = 0, b_cnt = 0;              // weight cursor
+  auto set_a = [&](int tile) __attribute__((always_inline)) {
+    int m0, n0;
+    tile_origin(tile, m0, n0);
+    a_base = reinterpret_cast<const char*>(p.a1) + (int64_t)m0 * K * 2;
+  };
+  auto set_b = [&](int tile) __attribute__((always_inline)) {
+    int m0, n0;
+    tile_origin(tile, m0, n0);
+    w_base = reinterpret_cast<const char*>(p.w) + (int64_t)n0 * K * 2;
+    if (p.bias && wid < 5) {                        // 320 floats: one 64-float piece per wave 0 .. 4
+      const char* gb = reinterpret_cast<const char*>(p.bias + n0 + wid * 64);
+      const unsigned db = lds0 + DOFF_BIAS + ((tile & 3) * DBN + wid * 64) * 4;
+      PP_DMA("global_load_lds_dword", (unsigned)(lane * 4), gb, db);
+    }
+  };
+  auto issue_a = [&]() __attribute__((always_inline)) {      // the four activation pieces of the K tile at the activation cursor; the cursor moves on
+    if (!no_dma) {
+      const char* g = a_base + a_kt * (PBK * 2);
+      const unsigned d = lds0 + (a_cnt & 1) * DSLOT + wrow_b;
+      PP_DMA("global_load_lds_dwordx4", voff[0], g, d);
+      PP_DMA("global_load_lds_dwordx4", voff[1], g, d + 1 * (64 * PBK * 2));
+      PP_DMA("global_load_lds_dwordx4", voff[2], g, d + 2 * (64 * PBK * 2));
+      PP_DMA("global_load_lds_dwordx4", voff[3], g, d + 3 * (64 * PBK * 2));
+    }
+    ++a_cnt;
+    if (++a_kt == nk) {
+      a_kt = 0;
+      if (++a_tile < my_tiles) set_a(a_tile);
+    }
+  };
+  auto issue_b = [&](auto q0_tag, auto q1_tag) __attribute__((always_inline)) {   // weight row passes [q0, q1) of the K tile at the weight cursor
+    constexpr int q0 = decltype(q0_tag)::value, q1 = decltype(q1_tag)::value;
+    if (!no_dma) {
+      const char* g = w_base + b_kt * (PBK * 2);
+      const unsigned d = lds0 + (b_cnt & 1) * DSLOT + DA_BYTES + wrow_b;
+#pragma unroll
+      for (int q = q0; q < q1; ++q) PP_DMA("global_load_lds_dwordx4", voff[q], g, d + q * (64 * PBK * 2));
+    }
+    if constexpr (q1 == 5) {
+      ++b_cnt;
+      if (++b_kt == nk) {
+        b_kt = 0;
+        if (++b_tile < my_tiles) set_b(b_tile);
+      }
+    }
+  };
+
+  // ---- compute side
+  f32x4 acc0[PMT][PNT], acc1[PMT][PNT];            // the two 160-column halves (zeroed by their epilogue: a "first cluster takes C = 0" variant of
+#pragma unroll                                     // the clusters doubles the loop body and sends hipcc's allocator into spilling)
+  for (int i = 0; i < PMT; ++i)
+#pragma unroll
+    for (int j = 0; j < PNT; ++j) acc0[i][j] = acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  u32x4 fa[PMT] = {}, fb[PNT] = {};
+  unsigned a_rd[2], b_rd[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    a_rd[kk] = ((wm * 64 + fr) * PBK + (((kk * 4 + fq) ^ (fr & 7)) << 3)) * 2;
+    b_rd[kk] = DA_BYTES + ((wn * 80 + fr) * PBK + (((kk * 4 + fq) ^ (fr & 7)) << 3)) * 2;
+  }
+  auto read_a = [&](int slot, auto kk_tag) __attribute__((always_inline)) {
+    const char* ba = smem + slot * DSLOT + a_rd[decltype(kk_tag)::value];
+#pragma unroll
+    for (int i = 0; i < PMT; ++i) fa[i] = *reinterpret_cast<const u32x4*>(ba + i * (16 * PBK * 2));
+  };
+  auto read_b = [&](int slot, auto kk_tag, auto nh_tag) __attribute__((always_inline)) {
+    const char* bb = smem + slot * DSLOT + b_rd[decltype(kk_tag)::value] + decltype(nh_tag)::value * (PBN * PBK * 2);
+#pragma unroll
+    for (int j = 0; j < PNT; ++j) fb[j] = *reinterpret_cast<const u32x4*>(bb + j * (16 * PBK * 2));
+  };
+  auto cluster = [&](auto nh_tag, auto first_tag) __attribute__((always_inline)) {
+    constexpr int NH = decltype(nh_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < PMT; ++i)
+#pragma unroll
+      for (int j = 0; j < PNT; ++j) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (NH == 0) acc0[i][j] = PMfma<T>::run(__builtin_bit_cast(frag, fb[j]), __builtin_bit_cast(frag, fa[i]), FIRST ? z : acc0[i][j]);
+        else acc1[i][j] = PMfma<T>::run(__builtin_bit_cast(frag, fb[j]), __builtin_bit_cast(frag, fa[i]), FIRST ? z : acc1[i][j]);
+      }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- epilogue of one 160-column half (igemm.hip's fast path: bias, residual, convert, lane swap, 16-byte stores; LayerNorm row statistics)
+  T* const out = reinterpret_cast<T*>(p.out);
+  const T* const res = reinterpret_cast<const T*>(p.residual);
+  auto epilogue_half = [&](auto nh_tag, int tile) __attribute__((always_inline)) {
+    constexpr int NH = decltype(nh_tag)::value;
+    int m0, n0;
+    tile_origin(tile, m0, n0);
+    n0 += NH * PBN;
+    const float* tb = sBias + (tile & 3) * DBN + NH * PBN + wn * 80 + fq * 4;   // (bias re-read from LDS per row group: 20 registers less across the half)
+    const int64_t lane_off = (int64_t)(m0 + wm * 64 + fr) * N + n0 + wn * 80;
+    u32x2 rv[PMT][PNT];
+    if constexpr (RES) {
+#pragma unroll
+      for (int i = 0; i < PMT; ++i)
+#pragma unroll
+        for (int j = 0; j < PNT; ++j) rv[i][j] = *reinterpret_cast<const u32x2*>(res + lane_off + (int64_t)i * 16 * N + j * 16 + fq * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < PMT; ++i) {
+      T* prow = out + lane_off + (int64_t)i * 16 * N;
+      u32x2 po[PNT];
+#pragma unroll
+      for (int j = 0; j < PNT; ++j) {
+        f32x4 v = NH == 0 ? acc0[i][j] : acc1[i][j];
+        if constexpr (NH == 0) acc0[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; else acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (has_bias) v += *reinterpret_cast<const f32x4*>(tb + j * 16);
+        if constexpr (RES) {
+          T r[4];
+          *reinterpret_cast<u32x2*>(r) = rv[i][j];
+          v[0] += to_f32(r[0]); v[1] += to_f32(r[1]); v[2] += to_f32(r[2]); v[3] += to_f32(r[3]);
+        }
+        T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+        po[j] = *reinterpret_cast<u32x2*>(o);
+      }
+#pragma unroll
+      for (int k = 0; k + 1 < PNT; k += 2) {
+        const auto lo = __builtin_amdgcn_permlane16_swap(po[k][0], po[k + 1][0], false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(po[k][1], po[k + 1][1], false, false);
+        const u32x4 v = {lo[0], hi[0], lo[1], hi[1]};
+        *reinterpret_cast<u32x4*>(prow + (k + (fq & 1)) * 16 + (fq >> 1) * 8) = v;
+      }
+      *reinterpret_cast<u32x2*>(prow + (PNT - 1) * 16 + fq * 4) = po[PNT - 1];
+      if constexpr (STAT) {
+        // (mean, M2) of the 20 stored values of this lane, merged over the four fq lanes by Chan's update in igemm.hip's order (even 16-lane row first, then
+        // the lower half first): partial n0 / 80 + wn of row m.  The exchanges go through ds_bpermute (__shfl_xor): inline asm with register outputs makes
+        // hipcc spill in this kernel (see pp_gemm_applicable)
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < PNT; ++j) {
+          T o[4];
+          *reinterpret_cast<u32x2*>(o) = po[j];
+          sum += (to_f32(o[0]) + to_f32(o[1])) + (to_f32(o[2]) + to_f32(o[3]));
+        }
+        float mu = sum * (1.0f / (float)(PNT * 4)), m2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < PNT; ++j) {
+          T o[4];
+          *reinterpret_cast<u32x2*>(o) = po[j];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const float d = to_f32(o[q]) - mu; m2 += d * d; }
+        }
+        {
+          const float mo = __shfl_xor(mu, 16, 64), qo = __shfl_xor(m2, 16, 64);
+          const bool odd = fq & 1;
+          float ma = odd ? mo : mu, mb = odd ? mu : mo, qa = odd ? qo : m2, qb = odd ? m2 : qo;
+          float d = mb - ma;
+          ma += 0.5f * d;
+          qa += qb + d * d * (0.5f * (float)(PNT * 4));
+          const float mo2 = __shfl_xor(ma, 32, 64), qo2 = __shfl_xor(qa, 32, 64);
+          const bool hi = fq >> 1;
+          float m_lo = hi ? mo2 : ma, m_hi = hi ? ma : mo2, q_lo = hi ? qo2 : qa, q_hi = hi ? qa : qo2;
+          d = m_hi - m_lo;
+          mu = m_lo + 0.5f * d;
+          m2 = q_lo;
+          m2 += q_hi + d * d * (0.5f * (float)(2 * PNT * 4));
+        }
+        if (fq == 0) *reinterpret_cast<f32x2*>(p.stat_out + ((int64_t)(m0 + wm * 64 + i * 16 + fr) * p.stat_P + n0 / 80 + wn) * 2) = (f32x2){mu, m2};
+      }
+    }
+  };
+
+  // ---- prologue: K tile 0 whole, the activation pieces of K tile 1; wait for K tile 0
+  set_a(0);
+  set_b(0);
+  issue_a();
+  issue_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+  if (total_steps > 1) { issue_a(); PP_VMCNT(4); } else { PP_VMCNT(0); }
+  __builtin_amdgcn_s_barrier();
+  if (late) __builtin_amdgcn_s_barrier();
+
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  int ct_kt = 0, ct_tile = 0;
+  for (int s = 0; s < total_steps; ++s) {
+    const int slot = s & 1;
+    const bool next = s + 1 < total_steps;          // a K tile s + 1 exists: its weight pieces go out in phases 0 .. 2 of this K tile
+    if (s > 0 && ct_kt == 0 && !no_epi) {           // the previous K tile finished an output tile: both halves, in front of this tile's first cluster
+      epilogue_half(I0{}, ct_tile - 1);
+      epilogue_half(I1{}, ct_tile - 1);
+    }
+    // ---- phase 0: (kk 0, half 0)
+    if (next) issue_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+    read_a(slot, I0{});
+    read_b(slot, I0{}, I0{});
+    PP_LGKMCNT0();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    cluster(I0{}, std::false_type{});
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1: (kk 0, half 1)
+    if (next) issue_b(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+    read_b(slot, I0{}, I1{});
+    PP_LGKMCNT0();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    cluster(I1{}, std::false_type{});
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: (kk 1, half 0)
+    if (next) issue_b(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
+    read_a(slot, I1{});
+    read_b(slot, I1{}, I0{});
+    PP_LGKMCNT0();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    cluster(I0{}, std::false_type{});
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3: (kk 1, half 1): K tile s + 1 has landed (for this wave); the activation pieces of K tile s + 2 go into the rows just read
+    PP_VMCNT(0);
+    if (s + 2 < total_steps) issue_a();
+    read_b(slot, I1{}, I1{});
+    PP_LGKMCNT0();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    cluster(I1{}, std::false_type{});
+    __builtin_amdgcn_s_barrier();
+    if (++ct_kt == nk) { ct_kt = 0; ++ct_tile; }
+  }
+  if (!no_epi) {
+    epilogue_half(I0{}, ct_tile - 1);
+    epilogue_half(I1{}, ct_tile - 1);
+  }
+  if (!late) __builtin_amdgcn_s_barrier();
+}
+
 }  // namespace
 
 // 1x1 / Linear launches on whole tiles with K >= 320 and a bias-only epilogue.  OPT-IN (ETAINV_PP=1), measured on MI355X (profiles/r05_pp_gemm_check.log):
@@ -414,6 +709,47 @@ bool pp_gemm_applicable(const IGemmParams& p, int dtype) {
   if (p.stat_out && (p.stat_kind != 0 || p.rows_per_batch % 64 != 0)) return false;
   if (p.M % PBM != 0 || p.N % PBN != 0 || p.c1 % PBK != 0 || p.c1 < 5 * PBK) return false;
   return (int64_t)(p.M / PBM) * (p.N / PBN) >= 512;   // at least two tiles per block: the overlapped epilogue is the point
+}
+
+// dual-N kernel: 1x1 / Linear on whole 256 x 320 tiles with bias (+ residual) (+ LayerNorm row statistics); ETAINV_DUALN=0 switches it off
+bool pp_dualn_applicable(const IGemmParams& p, int dtype) {
+  if (!env_flag("ETAINV_DUALN", true) || (dtype != ETAINV_F16 && dtype != ETAINV_BF16)) return false;
+  if (p.taps != 1 || p.a2 || p.geglu || p.rowvec || p.out_f32 || p.out_nchw || p.ln_stat || p.w_batch_stride || p.ksplit > 1 || p.hm_heads) return false;
+  if (p.stat_out && (p.stat_kind != 0 || p.rows_per_batch % 64 != 0)) return false;
+  if (p.M % PBM != 0 || p.N % DBN != 0 || p.c1 % PBK != 0 || p.c1 < 2 * PBK) return false;
+  static const int min_tiles = getenv("ETAINV_DUALN_MIN_TILES") ? atoi(getenv("ETAINV_DUALN_MIN_TILES")) : 192;
+  return (int64_t)(p.M / PBM) * (p.N / DBN) >= min_tiles;
+}
+
+int launch_pp_dualn(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P) {
+  IGemmParams p = p_in;
+  if (p.stat_out) p.stat_P = p.N / 80;
+  if (stat_P) *stat_P = p.stat_out ? p.stat_P : 0;
+  const int tiles = (p.M / PBM) * (p.N / DBN);
+  const int grid = std::min(tiles, 256);
+  static bool attr_set[kMaxDevices] = {};
+  const int dev = current_device();
+  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), DLDS, s, p); };
+  ETAINV_DISPATCH_HALF(dtype, T, {
+    if (!attr_set[dev]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<f16, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<f16, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<f16, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<f16, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<bf16, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<bf16, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<bf16, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<bf16, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+      attr_set[dev] = true;
+    }
+    if (p.residual) {
+      if (p.stat_out) go(pp_dualn_kernel<T, true, true>); else go(pp_dualn_kernel<T, true, false>);
+    } else {
+      if (p.stat_out) go(pp_dualn_kernel<T, false, true>); else go(pp_dualn_kernel<T, false, false>);
+    }
+  });
+  ETAINV_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_pp_gemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P) {

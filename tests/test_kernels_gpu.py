@@ -450,6 +450,48 @@ def test_conv3x3_patch_mode(capi, dtype, monkeypatch, b, h, wd, cin, cout, res):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,n,k,res,stat", [(65536, 320, 320, True, True), (65536, 320, 1280, True, True), (49152, 640, 640, True, False),
+                                            (49152, 640, 2560, False, True), (49152, 1280, 5120, True, True), (98304, 320, 128, False, False),
+                                            (131072 + 256 * 3, 320, 320, True, True)])
+def test_gemm_dual_n_ping_pong(capi, dtype, monkeypatch, m, n, k, res, stat):
+    """ppgemm.hip pp_dualn_kernel (default for 1x1 / Linear launches on whole 256 x 320 tiles with bias / residual / LayerNorm-statistics epilogues): two
+    160-column halves from one staged activation K tile, wave groups in anti-phase, 2-slot LDS ring recycled by region.  Against fp32 and, bit for bit,
+    against the ring kernel (same accumulation order); several tiles per block, an odd tile count per block, K tiles 2 .. 80, the row statistics"""
+    lib = capi.load()
+    dt = capi.dtype_code(dtype)
+    a, w = rnd(m, k, seed=1, dtype=dtype), rnd(n, k, seed=2, scale=k ** -0.5, dtype=dtype)
+    b_ = rnd(n, seed=3) + 0.5
+    r_ = rnd(m, n, seed=4, scale=2.0, dtype=dtype) if res else None
+    outs, parts, ps = [], [], []
+    for on in ("1", "0"):
+        monkeypatch.setenv("ETAINV_DUALN", on)
+        out = torch.full((m, n), float("nan"), dtype=dtype, device="cuda")
+        part = torch.full((m * (n // 32) * 2,), float("nan"), dtype=torch.float32, device="cuda") if stat else None
+        sp = C.c_int(-1)
+        capi.check(lib.etainv_op_gemm_ln(capi.ptr(a), capi.ptr(w), capi.ptr(b_), None, None, capi.ptr(r_), capi.ptr(out), capi.ptr(part),
+                                         C.byref(sp) if stat else None, m, n, k, 0, dt, capi.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(out)
+        parts.append(part)
+        ps.append(sp.value)
+    ref = a.float() @ w.float().t() + b_
+    if res:
+        ref = ref + r_.float()
+    assert relerr(outs[0], ref) < TOL[dtype]
+    err = (outs[0].float() - ref).reshape(-1, 256, n).norm(dim=(1, 2)) / ref.reshape(-1, 256, n).norm(dim=(1, 2))
+    assert float(err.max()) < 2 * TOL[dtype]          # a wrong tile hides in a global norm
+    assert torch.equal(outs[0], outs[1]), "dual-N kernel and ring kernel accumulate in the same order"
+    if stat:
+        assert ps[0] == ps[1] == n // 80
+        P = ps[0]
+        st = parts[0][: m * P * 2].view(m, P, 2)
+        xs = outs[0].float().view(m, P, n // P)
+        torch.testing.assert_close(st[..., 0], xs.mean(-1), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(st[..., 1], ((xs - xs.mean(-1, keepdim=True)) ** 2).sum(-1), rtol=2e-4, atol=1e-3)
+        torch.testing.assert_close(parts[0][: m * P * 2], parts[1][: m * P * 2], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_split_k_small_m_deep_k(capi, dtype):
     """batch-1 shapes of the 8x8 / 16x16 levels (M = 64 .. 256, K = 11520 / 23040): split-K partials + fixed-order reduction with
     the fused bias / time-embedding row / residual epilogue; a plain GEMM with M = 64, K = 5120 as well"""

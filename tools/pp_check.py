@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Ping-pong GEMM (ppgemm.hip, opt-in: ETAINV_PP=1; ETAINV_PP_FORCE_ALL=1 also takes the residual / statistics variants, which spill) against the ring kernel on the same inputs: equality and time.  GPU box only.
-    python tools/pp_check.py [res] [stat]     # which epilogue variants to include"""
+    python tools/pp_check.py [dualn] [res] [stat]     # dualn: the dual-N kernel (ETAINV_DUALN) instead; which epilogue variants to include"""
 import ctypes as C
 import os
 import sys
@@ -15,6 +15,7 @@ lib = _capi.load()
 st = _capi.stream_ptr()
 dt = torch.bfloat16
 code = _capi.dtype_code(dt)
+SWITCH = "ETAINV_DUALN" if "dualn" in sys.argv else "ETAINV_PP"
 variants = [(False, False)] + ([(True, False)] if "res" in sys.argv else []) + ([(False, True), (True, True)] if "stat" in sys.argv else [])
 
 
@@ -44,7 +45,7 @@ for m, n, k in shapes:
         res = res_t if with_res else None
         outs, stats, ms = {}, {}, {}
         for pp in ("0", "1"):
-            os.environ["ETAINV_PP"] = pp
+            os.environ[SWITCH] = pp
             out = torch.full((m, n), float("nan"), dtype=dt, device="cuda")
             part = torch.full((m, 16, 2), float("nan"), device="cuda") if with_stat else None
             P = C.c_int(0)
