@@ -71,8 +71,10 @@ int launch_xs_gemm(const IGemmParams& p, int dtype, hipStream_t s);
 bool pp_gemm_applicable(const IGemmParams& p, int dtype);
 int launch_pp_gemm(const IGemmParams& p, int dtype, hipStream_t s, int* stat_P = nullptr);
 // dual-N form: a 256 x 320 output tile as two 160-column halves sharing one staged activation K tile (-31 % LDS-DMA bytes per FLOP; the 1x1 GEMMs are bound
-// by the DMA fill rate): bias (+ residual) (+ LayerNorm row statistics) epilogues
+// by the DMA fill rate): bias (+ residual) (+ LayerNorm row statistics), LayerNorm consumer (row-major / head-major QKV planes), and -- as a 256 x 256 tile
+// of two 128-column halves -- the LayerNorm-consumer GEGLU projection
 bool pp_dualn_applicable(const IGemmParams& p, int dtype);
+bool pp_dualn_hm_ok(const IGemmParams& p, int dtype);   // ... as a LayerNorm consumer that writes the head-major QKV planes (hm_* set)?
 int launch_pp_dualn(const IGemmParams& p, int dtype, hipStream_t s, int* stat_P = nullptr);
 
 // ---- f32path.hip: the fp32-operand execution (dtype == ETAINV_F32 routes here from the launchers of igemm / norm / attention)

@@ -418,15 +418,32 @@ __global__ void __launch_bounds__(512, 2) pp_gemm_kernel(IGemmParams p) {
 //   every wave waits for ALL its pieces of K tile s + 2 (vmcnt(0): nothing else is in flight) in phase 3 of tile s + 1, in front of the activation pieces of
 //   K tile s + 3; the barrier behind that wait precedes the first read of K tile s + 2.  The youngest piece waited for is two intervals old, the oldest eight.
 // Epilogue (bias, residual, LayerNorm row statistics -- igemm.hip's arithmetic, bit-identical results): per half, at the end of the output tile, not overlapped.
-constexpr int DBN = 320;                           // two halves of PBN
-constexpr int DA_BYTES = PBM * PBK * 2, DB_BYTES = DBN * PBK * 2, DSLOT = DA_BYTES + DB_BYTES;
-constexpr int DOFF_BIAS = 2 * DSLOT, DLDS = DOFF_BIAS + 4 * DBN * 4;
+// Instantiations: HN = 160 (wave tile 64 x 80 per half) with EPI 0 = bias (+ residual) (+ LayerNorm row statistics), 1 = LayerNorm consumer
+// (out = rstd (acc - mean s) + c, IGemmParams::ln_stat), 2 = the same writing the head-major QKV planes (IGemmParams::hm_*); HN = 128 (wave tile 64 x 64
+// per half, 256 x 256 tile) with EPI 3 = LayerNorm consumer + GEGLU (a * gelu_erf(g), value / gate columns interleaved per 64 by pack mode 2).
+// The LayerNorm consumers' s vector and (mean, rstd) rows arrive by DMA with the bias (two-deep rings: the weight cursor enters tile t + 2 only after
+// the epilogue of tile t).
+template <int HN> struct DualN {
+  static constexpr int NT = HN / 32;                 // 16-column blocks per wave tile (two waves across a half)
+  static constexpr int WN = HN / 2;
+  static constexpr int BN2 = 2 * HN;                 // weight rows per K tile
+  static constexpr int PASSES = BN2 / 64;            // 64-row DMA passes of the weight tile
+  static constexpr int A_BYTES = PBM * PBK * 2, B_BYTES = BN2 * PBK * 2, SLOT = A_BYTES + B_BYTES;
+  static constexpr int OFF_BIAS = 2 * SLOT, OFF_S = OFF_BIAS + 2 * BN2 * 4, OFF_STAT = OFF_S + 2 * BN2 * 4, LDS = OFF_STAT + 2 * PBM * 2 * 4;
+};
 
-template <typename T, bool RES, bool STAT>
+template <typename T, int HN, int EPI, bool RES, bool STAT>
 __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
   typedef typename PMfma<T>::frag frag;
+  typedef DualN<HN> D;
+  constexpr int NT = D::NT, WN = D::WN, BN2 = D::BN2, PASSES = D::PASSES;
+  constexpr bool LNC = EPI != 0;                   // LayerNorm consumer
+  static_assert((HN == 160 && EPI <= 2) || (HN == 128 && EPI == 3), "instantiations");
+  static_assert(!LNC || (!RES && !STAT), "a LayerNorm consumer has no residual and emits no statistics");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sBias = reinterpret_cast<float*>(smem + DOFF_BIAS);   // [4][320] bias of the tiles in flight
+  float* sBias = reinterpret_cast<float*>(smem + D::OFF_BIAS);   // [2][BN2] bias (LayerNorm consumer: the folded c vector) of the tiles in flight
+  float* sS = reinterpret_cast<float*>(smem + D::OFF_S);         // [2][BN2] s vector
+  float* sStat = reinterpret_cast<float*>(smem + D::OFF_STAT);   // [2][256][2] (mean, rstd)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -436,7 +453,7 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
 
   const int K = p.c1, N = p.N;
   const int nk = K / PBK;
-  const int tiles_n = N / DBN;
+  const int tiles_n = N / BN2;
   const int total_tiles = (p.M / PBM) * tiles_n;
   const int G = gridDim.x;
   const int my_tiles = (total_tiles - (int)blockIdx.x + G - 1) / G;
@@ -446,7 +463,7 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
     if ((total_tiles & 7) == 0) v = (v & 7) * (total_tiles >> 3) + (v >> 3);
     const int tm = v / tiles_n;
     m0 = tm * PBM;
-    n0 = (v - tm * tiles_n) * DBN;
+    n0 = (v - tm * tiles_n) * BN2;
   };
   const int total_steps = my_tiles * nk;
   const bool no_dma = p.debug & 1, no_epi = p.debug & 2;
@@ -454,9 +471,9 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
 
   // ---- issue side: two cursors (the activation pieces of a K tile go out four phases before its weight pieces)
   const unsigned lrow = tid >> 3;
-  unsigned voff[5];
+  unsigned voff[PASSES];
 #pragma unroll
-  for (int q = 0; q < 5; ++q) voff[q] = ((lrow + 64 * q) * (unsigned)K + (((tid & 7) ^ (lrow & 7)) << 3)) * 2u;
+  for (int q = 0; q < PASSES; ++q) voff[q] = ((lrow + 64 * q) * (unsigned)K + (((tid & 7) ^ (lrow & 7)) << 3)) * 2u;
   const int wrow_b = wid * 8 * PBK * 2;
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
   const char* a_base = nullptr;
@@ -472,16 +489,19 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
     int m0, n0;
     tile_origin(tile, m0, n0);
     w_base = reinterpret_cast<const char*>(p.w) + (int64_t)n0 * K * 2;
-    if (p.bias && wid < 5) {                        // 320 floats: one 64-float piece per wave 0 .. 4
-      const char* gb = reinterpret_cast<const char*>(p.bias + n0 + wid * 64);
-      const unsigned db = lds0 + DOFF_BIAS + ((tile & 3) * DBN + wid * 64) * 4;
-      PP_DMA("global_load_lds_dword", (unsigned)(lane * 4), gb, db);
+    if (wid < BN2 / 64) {                           // BN2 floats: one 64-float piece per wave
+      const unsigned db = ((tile & 1) * BN2 + wid * 64) * 4;
+      if (has_bias) PP_DMA("global_load_lds_dword", (unsigned)(lane * 4), reinterpret_cast<const char*>(p.bias + n0 + wid * 64), lds0 + D::OFF_BIAS + db);
+      if constexpr (LNC) PP_DMA("global_load_lds_dword", (unsigned)(lane * 4), reinterpret_cast<const char*>(p.ln_s + n0 + wid * 64), lds0 + D::OFF_S + db);
     }
+    if constexpr (LNC)                              // (mean, rstd) of the tile's 256 rows: 512 floats = one dword per lane of the block
+      PP_DMA("global_load_lds_dword", (unsigned)(lane * 4), reinterpret_cast<const char*>(p.ln_stat + (int64_t)m0 * 2 + wid * 64),
+             lds0 + D::OFF_STAT + ((tile & 1) * 512 + wid * 64) * 4);
   };
   auto issue_a = [&]() __attribute__((always_inline)) {      // the four activation pieces of the K tile at the activation cursor; the cursor moves on
     if (!no_dma) {
       const char* g = a_base + a_kt * (PBK * 2);
-      const unsigned d = lds0 + (a_cnt & 1) * DSLOT + wrow_b;
+      const unsigned d = lds0 + (a_cnt & 1) * D::SLOT + wrow_b;
       PP_DMA("global_load_lds_dwordx4", voff[0], g, d);
       PP_DMA("global_load_lds_dwordx4", voff[1], g, d + 1 * (64 * PBK * 2));
       PP_DMA("global_load_lds_dwordx4", voff[2], g, d + 2 * (64 * PBK * 2));
@@ -497,11 +517,11 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
     constexpr int q0 = decltype(q0_tag)::value, q1 = decltype(q1_tag)::value;
     if (!no_dma) {
       const char* g = w_base + b_kt * (PBK * 2);
-      const unsigned d = lds0 + (b_cnt & 1) * DSLOT + DA_BYTES + wrow_b;
+      const unsigned d = lds0 + (b_cnt & 1) * D::SLOT + D::A_BYTES + wrow_b;
 #pragma unroll
       for (int q = q0; q < q1; ++q) PP_DMA("global_load_lds_dwordx4", voff[q], g, d + q * (64 * PBK * 2));
     }
-    if constexpr (q1 == 5) {
+    if constexpr (q1 == PASSES) {
       ++b_cnt;
       if (++b_kt == nk) {
         b_kt = 0;
@@ -511,137 +531,188 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
   };
 
   // ---- compute side
-  f32x4 acc0[PMT][PNT], acc1[PMT][PNT];            // the two 160-column halves (zeroed by their epilogue: a "first cluster takes C = 0" variant of
-#pragma unroll                                     // the clusters doubles the loop body and sends hipcc's allocator into spilling)
+  f32x4 acc0[PMT][NT], acc1[PMT][NT];              // the two halves (zeroed by their epilogue: a "first cluster takes C = 0" variant of the clusters doubles
+#pragma unroll                                     // the loop body and sends hipcc's allocator into spilling)
   for (int i = 0; i < PMT; ++i)
 #pragma unroll
-    for (int j = 0; j < PNT; ++j) acc0[i][j] = acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  u32x4 fa[PMT] = {}, fb[PNT] = {};
+    for (int j = 0; j < NT; ++j) acc0[i][j] = acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  u32x4 fa[PMT] = {}, fb[NT] = {};
   unsigned a_rd[2], b_rd[2];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
     a_rd[kk] = ((wm * 64 + fr) * PBK + (((kk * 4 + fq) ^ (fr & 7)) << 3)) * 2;
-    b_rd[kk] = DA_BYTES + ((wn * 80 + fr) * PBK + (((kk * 4 + fq) ^ (fr & 7)) << 3)) * 2;
+    b_rd[kk] = D::A_BYTES + ((wn * WN + fr) * PBK + (((kk * 4 + fq) ^ (fr & 7)) << 3)) * 2;
   }
   auto read_a = [&](int slot, auto kk_tag) __attribute__((always_inline)) {
-    const char* ba = smem + slot * DSLOT + a_rd[decltype(kk_tag)::value];
+    const char* ba = smem + slot * D::SLOT + a_rd[decltype(kk_tag)::value];
 #pragma unroll
     for (int i = 0; i < PMT; ++i) fa[i] = *reinterpret_cast<const u32x4*>(ba + i * (16 * PBK * 2));
   };
   auto read_b = [&](int slot, auto kk_tag, auto nh_tag) __attribute__((always_inline)) {
-    const char* bb = smem + slot * DSLOT + b_rd[decltype(kk_tag)::value] + decltype(nh_tag)::value * (PBN * PBK * 2);
+    const char* bb = smem + slot * D::SLOT + b_rd[decltype(kk_tag)::value] + decltype(nh_tag)::value * (HN * PBK * 2);
 #pragma unroll
-    for (int j = 0; j < PNT; ++j) fb[j] = *reinterpret_cast<const u32x4*>(bb + j * (16 * PBK * 2));
+    for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const u32x4*>(bb + j * (16 * PBK * 2));
   };
-  auto cluster = [&](auto nh_tag, auto first_tag) __attribute__((always_inline)) {
+  auto cluster = [&](auto nh_tag) __attribute__((always_inline)) {
     constexpr int NH = decltype(nh_tag)::value;
-    constexpr bool FIRST = decltype(first_tag)::value;
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < PMT; ++i)
 #pragma unroll
-      for (int j = 0; j < PNT; ++j) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (NH == 0) acc0[i][j] = PMfma<T>::run(__builtin_bit_cast(frag, fb[j]), __builtin_bit_cast(frag, fa[i]), FIRST ? z : acc0[i][j]);
-        else acc1[i][j] = PMfma<T>::run(__builtin_bit_cast(frag, fb[j]), __builtin_bit_cast(frag, fa[i]), FIRST ? z : acc1[i][j]);
+      for (int j = 0; j < NT; ++j) {
+        if constexpr (NH == 0) acc0[i][j] = PMfma<T>::run(__builtin_bit_cast(frag, fb[j]), __builtin_bit_cast(frag, fa[i]), acc0[i][j]);
+        else acc1[i][j] = PMfma<T>::run(__builtin_bit_cast(frag, fb[j]), __builtin_bit_cast(frag, fa[i]), acc1[i][j]);
       }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- epilogue of one 160-column half (igemm.hip's fast path: bias, residual, convert, lane swap, 16-byte stores; LayerNorm row statistics)
+  // ---- epilogue of one half (igemm.hip's fast-path arithmetic).  Lane: pixel row m = m0 + wm * 64 + i * 16 + fr, channels n0 + wn * WN + j * 16 + fq * 4 .. + 3
   T* const out = reinterpret_cast<T*>(p.out);
   const T* const res = reinterpret_cast<const T*>(p.residual);
+  // NB 16-channel blocks of one pixel row: 16-byte stores after a lane swap between adjacent blocks (igemm.hip store_row_group); hm_d / hm_skip: columns
+  // >= hm_d of the span belong to the next head, whose plane starts hm_skip elements further on
+  auto store_blocks = [&](T* prow, auto& po, auto nb_tag, int hm_d, int hm_skip) __attribute__((always_inline)) {
+    constexpr int NB = decltype(nb_tag)::value;
+    auto at = [&](int col) __attribute__((always_inline)) { return prow + col + (col >= hm_d ? hm_skip : 0); };
+#pragma unroll
+    for (int k = 0; k + 1 < NB; k += 2) {
+      const auto lo = __builtin_amdgcn_permlane16_swap(po[k][0], po[k + 1][0], false, false);
+      const auto hi = __builtin_amdgcn_permlane16_swap(po[k][1], po[k + 1][1], false, false);
+      const u32x4 v = {lo[0], hi[0], lo[1], hi[1]};
+      *reinterpret_cast<u32x4*>(at((k + (fq & 1)) * 16 + (fq >> 1) * 8)) = v;
+    }
+    if constexpr (NB & 1) *reinterpret_cast<u32x2*>(at((NB - 1) * 16 + fq * 4)) = po[NB - 1];
+  };
   auto epilogue_half = [&](auto nh_tag, int tile) __attribute__((always_inline)) {
     constexpr int NH = decltype(nh_tag)::value;
     int m0, n0;
     tile_origin(tile, m0, n0);
-    n0 += NH * PBN;
-    const float* tb = sBias + (tile & 3) * DBN + NH * PBN + wn * 80 + fq * 4;   // (bias re-read from LDS per row group: 20 registers less across the half)
-    const int64_t lane_off = (int64_t)(m0 + wm * 64 + fr) * N + n0 + wn * 80;
-    u32x2 rv[PMT][PNT];
-    if constexpr (RES) {
+    n0 += NH * HN;
+    const int cofs = (tile & 1) * BN2 + NH * HN + wn * WN + fq * 4;   // the lane's first column inside the staged vectors
+    const float* tb = sBias + cofs;                 // (bias / c re-read from LDS per row group: 20 registers less across the half)
+    const float* ts = sS + cofs;
+    const int mrow = m0 + wm * 64 + fr;
+    if constexpr (EPI == 3) {
+      // GEGLU: wave columns [0, WN/2) hold a, [WN/2, WN) the matching gate; output width N / 2
+      const int No = N >> 1;
 #pragma unroll
-      for (int i = 0; i < PMT; ++i)
+      for (int i = 0; i < PMT; ++i) {
+        const f32x2 st = *reinterpret_cast<const f32x2*>(sStat + (tile & 1) * 512 + (wm * 64 + i * 16 + fr) * 2);
+        u32x2 po[NT / 2];
 #pragma unroll
-        for (int j = 0; j < PNT; ++j) rv[i][j] = *reinterpret_cast<const u32x2*>(res + lane_off + (int64_t)i * 16 * N + j * 16 + fq * 4);
-    }
-#pragma unroll
-    for (int i = 0; i < PMT; ++i) {
-      T* prow = out + lane_off + (int64_t)i * 16 * N;
-      u32x2 po[PNT];
-#pragma unroll
-      for (int j = 0; j < PNT; ++j) {
-        f32x4 v = NH == 0 ? acc0[i][j] : acc1[i][j];
-        if constexpr (NH == 0) acc0[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; else acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (has_bias) v += *reinterpret_cast<const f32x4*>(tb + j * 16);
-        if constexpr (RES) {
-          T r[4];
-          *reinterpret_cast<u32x2*>(r) = rv[i][j];
-          v[0] += to_f32(r[0]); v[1] += to_f32(r[1]); v[2] += to_f32(r[2]); v[3] += to_f32(r[3]);
+        for (int j = 0; j < NT / 2; ++j) {
+          f32x4 a = NH == 0 ? acc0[i][j] : acc1[i][j], g = NH == 0 ? acc0[i][j + NT / 2] : acc1[i][j + NT / 2];
+          if constexpr (NH == 0) { acc0[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc0[i][j + NT / 2] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+          else { acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[i][j + NT / 2] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+          a = (a - st[0] * *reinterpret_cast<const f32x4*>(ts + j * 16)) * st[1];
+          g = (g - st[0] * *reinterpret_cast<const f32x4*>(ts + j * 16 + WN / 2)) * st[1];
+          a += *reinterpret_cast<const f32x4*>(tb + j * 16);
+          g += *reinterpret_cast<const f32x4*>(tb + j * 16 + WN / 2);
+          const gelu_f32x2 g01 = gelu_pair((gelu_f32x2){g[0], g[1]}), g23 = gelu_pair((gelu_f32x2){g[2], g[3]});
+          T o[4] = {from_f32<T>(a[0] * g01[0]), from_f32<T>(a[1] * g01[1]), from_f32<T>(a[2] * g23[0]), from_f32<T>(a[3] * g23[1])};
+          po[j] = *reinterpret_cast<u32x2*>(o);
         }
-        T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
-        po[j] = *reinterpret_cast<u32x2*>(o);
+        store_blocks(out + (int64_t)(mrow + i * 16) * No + ((n0 + wn * WN) >> 1), po, std::integral_constant<int, NT / 2>{}, 1 << 30, 0);
+      }
+    } else {
+      const int64_t lane_off = (int64_t)mrow * N + n0 + wn * WN;
+      u32x2 rv[PMT][NT];
+      if constexpr (RES) {
+#pragma unroll
+        for (int i = 0; i < PMT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) rv[i][j] = *reinterpret_cast<const u32x2*>(res + lane_off + (int64_t)i * 16 * N + j * 16 + fq * 4);
+      }
+      // head-major QKV planes (igemm.hip, LN == 4): the wave's 80-column span = one head (d = 80) or two (d = 40); the tile lies inside one batch row
+      T* plane = nullptr;
+      int hm_tok0 = 0;
+      if constexpr (EPI == 2) {
+        const int g = ((n0 + wn * WN) / 80) * (p.hm_dim == 40 ? 2 : 1);   // first head of the span, counted over q | k | v
+        const int part = g >> 3, head0 = g & 7;
+        const int b = m0 / p.hm_tokens;
+        hm_tok0 = b * p.hm_tokens;
+        plane = out + ((int64_t)part * p.M + (int64_t)b * p.hm_tokens) * (8 * p.hm_dim) + (int64_t)head0 * p.hm_tokens * p.hm_dim;
       }
 #pragma unroll
-      for (int k = 0; k + 1 < PNT; k += 2) {
-        const auto lo = __builtin_amdgcn_permlane16_swap(po[k][0], po[k + 1][0], false, false);
-        const auto hi = __builtin_amdgcn_permlane16_swap(po[k][1], po[k + 1][1], false, false);
-        const u32x4 v = {lo[0], hi[0], lo[1], hi[1]};
-        *reinterpret_cast<u32x4*>(prow + (k + (fq & 1)) * 16 + (fq >> 1) * 8) = v;
-      }
-      *reinterpret_cast<u32x2*>(prow + (PNT - 1) * 16 + fq * 4) = po[PNT - 1];
-      if constexpr (STAT) {
-        // (mean, M2) of the 20 stored values of this lane, merged over the four fq lanes by Chan's update in igemm.hip's order (even 16-lane row first, then
-        // the lower half first): partial n0 / 80 + wn of row m.  The exchanges go through ds_bpermute (__shfl_xor): inline asm with register outputs makes
-        // hipcc spill in this kernel (see pp_gemm_applicable)
-        float sum = 0.f;
+      for (int i = 0; i < PMT; ++i) {
+        f32x2 st = {0.f, 1.f};
+        if constexpr (LNC) st = *reinterpret_cast<const f32x2*>(sStat + (tile & 1) * 512 + (wm * 64 + i * 16 + fr) * 2);
+        u32x2 po[NT];
 #pragma unroll
-        for (int j = 0; j < PNT; ++j) {
-          T o[4];
-          *reinterpret_cast<u32x2*>(o) = po[j];
-          sum += (to_f32(o[0]) + to_f32(o[1])) + (to_f32(o[2]) + to_f32(o[3]));
+        for (int j = 0; j < NT; ++j) {
+          f32x4 v = NH == 0 ? acc0[i][j] : acc1[i][j];
+          if constexpr (NH == 0) acc0[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; else acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if constexpr (LNC) {
+            v = (v - st[0] * *reinterpret_cast<const f32x4*>(ts + j * 16)) * st[1] + *reinterpret_cast<const f32x4*>(tb + j * 16);
+          } else {
+            if (has_bias) v += *reinterpret_cast<const f32x4*>(tb + j * 16);
+          }
+          if constexpr (RES) {
+            T r[4];
+            *reinterpret_cast<u32x2*>(r) = rv[i][j];
+            v[0] += to_f32(r[0]); v[1] += to_f32(r[1]); v[2] += to_f32(r[2]); v[3] += to_f32(r[3]);
+          }
+          T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+          po[j] = *reinterpret_cast<u32x2*>(o);
         }
-        float mu = sum * (1.0f / (float)(PNT * 4)), m2 = 0.f;
+        if constexpr (EPI == 2)
+          store_blocks(plane + (int64_t)(mrow + i * 16 - hm_tok0) * p.hm_dim, po, std::integral_constant<int, NT>{}, p.hm_dim, (p.hm_tokens - 1) * p.hm_dim);
+        else
+          store_blocks(out + lane_off + (int64_t)i * 16 * N, po, std::integral_constant<int, NT>{}, 1 << 30, 0);
+        if constexpr (STAT) {
+          // (mean, M2) of the 20 stored values of this lane, merged over the four fq lanes by Chan's update in igemm.hip's order (even 16-lane row first, then
+          // the lower half first): partial n0 / 80 + wn of row m.  The exchanges go through ds_bpermute (__shfl_xor): inline asm with register outputs makes
+          // hipcc spill in this kernel (see pp_gemm_applicable)
+          float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < PNT; ++j) {
-          T o[4];
-          *reinterpret_cast<u32x2*>(o) = po[j];
+          for (int j = 0; j < NT; ++j) {
+            T o[4];
+            *reinterpret_cast<u32x2*>(o) = po[j];
+            sum += (to_f32(o[0]) + to_f32(o[1])) + (to_f32(o[2]) + to_f32(o[3]));
+          }
+          float mu = sum * (1.0f / (float)(NT * 4)), m2 = 0.f;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { const float d = to_f32(o[q]) - mu; m2 += d * d; }
+          for (int j = 0; j < NT; ++j) {
+            T o[4];
+            *reinterpret_cast<u32x2*>(o) = po[j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float d = to_f32(o[q]) - mu; m2 += d * d; }
+          }
+          {
+            const float mo = __shfl_xor(mu, 16, 64), qo = __shfl_xor(m2, 16, 64);
+            const bool odd = fq & 1;
+            float ma = odd ? mo : mu, mb = odd ? mu : mo, qa = odd ? qo : m2, qb = odd ? m2 : qo;
+            float d = mb - ma;
+            ma += 0.5f * d;
+            qa += qb + d * d * (0.5f * (float)(NT * 4));
+            const float mo2 = __shfl_xor(ma, 32, 64), qo2 = __shfl_xor(qa, 32, 64);
+            const bool hi = fq >> 1;
+            float m_lo = hi ? mo2 : ma, m_hi = hi ? ma : mo2, q_lo = hi ? qo2 : qa, q_hi = hi ? qa : qo2;
+            d = m_hi - m_lo;
+            mu = m_lo + 0.5f * d;
+            m2 = q_lo;
+            m2 += q_hi + d * d * (0.5f * (float)(2 * NT * 4));
+          }
+          if (fq == 0) *reinterpret_cast<f32x2*>(p.stat_out + ((int64_t)(mrow + i * 16) * p.stat_P + n0 / 80 + wn) * 2) = (f32x2){mu, m2};
         }
-        {
-          const float mo = __shfl_xor(mu, 16, 64), qo = __shfl_xor(m2, 16, 64);
-          const bool odd = fq & 1;
-          float ma = odd ? mo : mu, mb = odd ? mu : mo, qa = odd ? qo : m2, qb = odd ? m2 : qo;
-          float d = mb - ma;
-          ma += 0.5f * d;
-          qa += qb + d * d * (0.5f * (float)(PNT * 4));
-          const float mo2 = __shfl_xor(ma, 32, 64), qo2 = __shfl_xor(qa, 32, 64);
-          const bool hi = fq >> 1;
-          float m_lo = hi ? mo2 : ma, m_hi = hi ? ma : mo2, q_lo = hi ? qo2 : qa, q_hi = hi ? qa : qo2;
-          d = m_hi - m_lo;
-          mu = m_lo + 0.5f * d;
-          m2 = q_lo;
-          m2 += q_hi + d * d * (0.5f * (float)(2 * PNT * 4));
-        }
-        if (fq == 0) *reinterpret_cast<f32x2*>(p.stat_out + ((int64_t)(m0 + wm * 64 + i * 16 + fr) * p.stat_P + n0 / 80 + wn) * 2) = (f32x2){mu, m2};
       }
     }
   };
 
   // ---- prologue: K tile 0 whole, the activation pieces of K tile 1; wait for K tile 0
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  constexpr int QA = 2, QB = PASSES == 5 ? 4 : 3;   // weight passes [0, QA) in phase 0, [QA, QB) in phase 1, [QB, PASSES) in phase 2
   set_a(0);
   set_b(0);
   issue_a();
-  issue_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+  issue_b(I0{}, std::integral_constant<int, PASSES>{});
   if (total_steps > 1) { issue_a(); PP_VMCNT(4); } else { PP_VMCNT(0); }
   __builtin_amdgcn_s_barrier();
   if (late) __builtin_amdgcn_s_barrier();
 
-  typedef std::integral_constant<int, 0> I0;
-  typedef std::integral_constant<int, 1> I1;
   int ct_kt = 0, ct_tile = 0;
   for (int s = 0; s < total_steps; ++s) {
     const int slot = s & 1;
@@ -651,30 +722,30 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
       epilogue_half(I1{}, ct_tile - 1);
     }
     // ---- phase 0: (kk 0, half 0)
-    if (next) issue_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+    if (next) issue_b(I0{}, std::integral_constant<int, QA>{});
     read_a(slot, I0{});
     read_b(slot, I0{}, I0{});
     PP_LGKMCNT0();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    cluster(I0{}, std::false_type{});
+    cluster(I0{});
     __builtin_amdgcn_s_barrier();
     // ---- phase 1: (kk 0, half 1)
-    if (next) issue_b(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+    if (next) issue_b(std::integral_constant<int, QA>{}, std::integral_constant<int, QB>{});
     read_b(slot, I0{}, I1{});
     PP_LGKMCNT0();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    cluster(I1{}, std::false_type{});
+    cluster(I1{});
     __builtin_amdgcn_s_barrier();
     // ---- phase 2: (kk 1, half 0)
-    if (next) issue_b(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
+    if (next) issue_b(std::integral_constant<int, QB>{}, std::integral_constant<int, PASSES>{});
     read_a(slot, I1{});
     read_b(slot, I1{}, I0{});
     PP_LGKMCNT0();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    cluster(I0{}, std::false_type{});
+    cluster(I0{});
     __builtin_amdgcn_s_barrier();
     // ---- phase 3: (kk 1, half 1): K tile s + 1 has landed (for this wave); the activation pieces of K tile s + 2 go into the rows just read
     PP_VMCNT(0);
@@ -683,7 +754,7 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
     PP_LGKMCNT0();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    cluster(I1{}, std::false_type{});
+    cluster(I1{});
     __builtin_amdgcn_s_barrier();
     if (++ct_kt == nk) { ct_kt = 0; ++ct_tile; }
   }
@@ -711,41 +782,62 @@ bool pp_gemm_applicable(const IGemmParams& p, int dtype) {
   return (int64_t)(p.M / PBM) * (p.N / PBN) >= 512;   // at least two tiles per block: the overlapped epilogue is the point
 }
 
-// dual-N kernel: 1x1 / Linear on whole 256 x 320 tiles with bias (+ residual) (+ LayerNorm row statistics); ETAINV_DUALN=0 switches it off
-bool pp_dualn_applicable(const IGemmParams& p, int dtype) {
-  if (!env_flag("ETAINV_DUALN", true) || (dtype != ETAINV_F16 && dtype != ETAINV_BF16)) return false;
-  if (p.taps != 1 || p.a2 || p.geglu || p.rowvec || p.out_f32 || p.out_nchw || p.ln_stat || p.w_batch_stride || p.ksplit > 1 || p.hm_heads) return false;
-  if (p.stat_out && (p.stat_kind != 0 || p.rows_per_batch % 64 != 0)) return false;
-  if (p.M % PBM != 0 || p.N % DBN != 0 || p.c1 % PBK != 0 || p.c1 < 2 * PBK) return false;
+// dual-N kernel: 1x1 / Linear on whole tiles -- 256 x 320 with bias (+ residual) (+ LayerNorm row statistics) or as a LayerNorm consumer (row-major or
+// head-major QKV planes), 256 x 256 for the LayerNorm-consumer GEGLU projection; ETAINV_DUALN=0 switches it off.  Returns the epilogue kind or -1
+static int dualn_kind(const IGemmParams& p, int dtype) {
+  if (!env_flag("ETAINV_DUALN", true) || (dtype != ETAINV_F16 && dtype != ETAINV_BF16)) return -1;
+  if (p.taps != 1 || p.a2 || p.rowvec || p.out_f32 || p.out_nchw || p.w_batch_stride || p.ksplit > 1) return -1;
+  if (p.stat_out && (p.stat_kind != 0 || p.rows_per_batch % 64 != 0)) return -1;
+  if (p.M % PBM != 0 || p.c1 % PBK != 0 || p.c1 < 2 * PBK) return -1;
+  int kind;
+  if (p.geglu) {
+    if (!p.ln_stat || !p.ln_s || !p.bias || p.residual || p.stat_out || p.hm_heads || p.N % 256 != 0) return -1;
+    kind = 3;
+  } else if (p.ln_stat) {
+    if (!p.ln_s || !p.bias || p.residual || p.stat_out || p.N % 320 != 0) return -1;
+    kind = p.hm_heads ? 2 : 1;
+    if (kind == 2 && ((p.hm_dim != 40 && p.hm_dim != 80) || p.hm_heads != 8 || p.N != 3 * 8 * p.hm_dim || p.hm_tokens % 256 != 0 || p.M % p.hm_tokens != 0)) return -1;
+  } else {
+    if (p.hm_heads || p.N % 320 != 0) return -1;
+    kind = 0;
+  }
+  // enough tiles, and a last round of the persistent grid that is at least 80 % full (a half-empty last round gives the -31 % DMA bytes back)
   static const int min_tiles = getenv("ETAINV_DUALN_MIN_TILES") ? atoi(getenv("ETAINV_DUALN_MIN_TILES")) : 192;
-  return (int64_t)(p.M / PBM) * (p.N / DBN) >= min_tiles;
+  const int64_t tiles = (int64_t)(p.M / PBM) * (p.N / (kind == 3 ? 256 : 320));
+  const int64_t rounds = (tiles + 255) / 256;
+  if (tiles < min_tiles || tiles * 5 < rounds * 256 * 4) return -1;
+  return kind;
+}
+bool pp_dualn_applicable(const IGemmParams& p, int dtype) { return dualn_kind(p, dtype) >= 0; }
+bool pp_dualn_hm_ok(const IGemmParams& p, int dtype) { return dualn_kind(p, dtype) == 2; }
+
+template <typename T, int HN, int EPI, bool RES, bool STAT>
+static void launch_dualn_t(const IGemmParams& p, int grid, hipStream_t s) {
+  static bool attr_set[kMaxDevices] = {};
+  const int dev = current_device();
+  if (!attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<T, HN, EPI, RES, STAT>), hipFuncAttributeMaxDynamicSharedMemorySize, DualN<HN>::LDS);
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((pp_dualn_kernel<T, HN, EPI, RES, STAT>), dim3(grid), dim3(512), DualN<HN>::LDS, s, p);
 }
 
 int launch_pp_dualn(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P) {
   IGemmParams p = p_in;
+  const int kind = dualn_kind(p, dtype);
+  ETAINV_CHECK(kind >= 0, "not a dual-N launch (ask pp_dualn_applicable first)");
   if (p.stat_out) p.stat_P = p.N / 80;
   if (stat_P) *stat_P = p.stat_out ? p.stat_P : 0;
-  const int tiles = (p.M / PBM) * (p.N / DBN);
+  const int tiles = (p.M / PBM) * (p.N / (kind == 3 ? 256 : 320));
   const int grid = std::min(tiles, 256);
-  static bool attr_set[kMaxDevices] = {};
-  const int dev = current_device();
-  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), DLDS, s, p); };
   ETAINV_DISPATCH_HALF(dtype, T, {
-    if (!attr_set[dev]) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<f16, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<f16, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<f16, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<f16, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<bf16, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<bf16, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<bf16, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<bf16, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
-      attr_set[dev] = true;
-    }
-    if (p.residual) {
-      if (p.stat_out) go(pp_dualn_kernel<T, true, true>); else go(pp_dualn_kernel<T, true, false>);
+    if (kind == 3) launch_dualn_t<T, 128, 3, false, false>(p, grid, s);
+    else if (kind == 2) launch_dualn_t<T, 160, 2, false, false>(p, grid, s);
+    else if (kind == 1) launch_dualn_t<T, 160, 1, false, false>(p, grid, s);
+    else if (p.residual) {
+      if (p.stat_out) launch_dualn_t<T, 160, 0, true, true>(p, grid, s); else launch_dualn_t<T, 160, 0, true, false>(p, grid, s);
     } else {
-      if (p.stat_out) go(pp_dualn_kernel<T, false, true>); else go(pp_dualn_kernel<T, false, false>);
+      if (p.stat_out) launch_dualn_t<T, 160, 0, false, true>(p, grid, s); else launch_dualn_t<T, 160, 0, false, false>(p, grid, s);
     }
   });
   ETAINV_LAUNCH_CHECK();

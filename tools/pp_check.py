@@ -67,4 +67,36 @@ for m, n, k in shapes:
         fl = 2.0 * m * n * k
         print(f"M={m} N={n} K={k} res={int(with_res)} stat={int(with_stat)}: ring {ms['0']:.3f} ms {fl / ms['0'] / 1e9:7.1f} TF | pp {ms['1']:.3f} ms {fl / ms['1'] / 1e9:7.1f} TF | "
               f"pp/ring {ms['1'] / ms['0']:.3f} | bit-equal {same}" + (f" | stats max diff {sdiff:.2e}" if with_stat else "") + f" | rel err vs fp32 {err:.2e}", flush=True)
+if "ln" in sys.argv:
+    # LayerNorm consumers (row-major) and the GEGLU projection: out = rstd (x W'^T - mean s) + c on raw rows, statistics from a pass over x
+    for m, c, n_out, geglu in ((524288, 320, 320, 0), (524288, 320, 960, 0), (131072, 640, 640, 0), (131072, 640, 1920, 0), (32768, 1280, 1280, 0), (32768, 1280, 3840, 0),
+                               (524288, 320, 2560, 1), (131072, 640, 5120, 1), (32768, 1280, 10240, 1), (393216, 320, 2560, 1)):
+        x = (torch.randn(m, c, device="cuda", generator=g) * 0.5 + 0.3).to(dt)
+        w = torch.randn(n_out, c, device="cuda", generator=g) * c ** -0.5
+        gamma, beta, bias = 1.0 + 0.3 * torch.randn(c, device="cuda", generator=g), 0.2 * torch.randn(c, device="cuda", generator=g), torch.randn(n_out, device="cuda", generator=g)
+        wp = torch.empty(n_out, c, dtype=dt, device="cuda")
+        s_vec, c_vec = torch.empty(n_out, device="cuda"), torch.empty(n_out, device="cuda")
+        stat = torch.empty(m, 2, device="cuda")
+        _capi.check(lib.etainv_op_ln_fold(_capi.ptr(w), _capi.ptr(gamma), _capi.ptr(beta), _capi.ptr(bias), n_out, c, geglu, 1.0, _capi.ptr(wp), _capi.ptr(s_vec), _capi.ptr(c_vec), code, st))
+        _capi.check(lib.etainv_op_row_stats(_capi.ptr(x), _capi.ptr(stat), m, c, 1e-5, code, st))
+        n_store = n_out // 2 if geglu else n_out
+        outs, ms = {}, {}
+        for pp in ("0", "1"):
+            os.environ[SWITCH] = pp
+            out = torch.full((m, n_store), float("nan"), dtype=dt, device="cuda")
+            fn = lambda: _capi.check(lib.etainv_op_gemm_ln(_capi.ptr(x), _capi.ptr(wp), _capi.ptr(c_vec), _capi.ptr(s_vec), _capi.ptr(stat), None, _capi.ptr(out), None, None,
+                                                            m, n_out, c, geglu, code, st))
+            fn()
+            torch.cuda.synchronize()
+            outs[pp] = out
+            ms[pp] = min(timeit(fn) for _ in range(3))
+        ndiff = int((outs["0"] != outs["1"]).sum())
+        maxd = float((outs["0"].float() - outs["1"].float()).abs().max())
+        h = torch.nn.functional.layer_norm(x[:4096].float(), (c,), gamma, beta, 1e-5) @ w.t() + bias
+        ref = h[:, :n_out // 2] * torch.nn.functional.gelu(h[:, n_out // 2:]) if geglu else h
+        err = float((outs["1"][:4096].float() - ref).norm() / ref.norm())
+        bad += not (err < 1e-2 and ndiff <= 1e-4 * out.numel())
+        fl = 2.0 * m * n_out * c
+        print(f"LN consumer M={m} C={c} N={n_out} geglu={geglu}: ring {ms['0']:.3f} ms {fl / ms['0'] / 1e9:7.1f} TF | dual-N {ms['1']:.3f} ms {fl / ms['1'] / 1e9:7.1f} TF | "
+              f"ratio {ms['1'] / ms['0']:.3f} | elements that differ {ndiff} of {out.numel()} (max abs {maxd:.2e}) | rel err vs fp32 {err:.2e}", flush=True)
 print("MISMATCHES:", bad)
