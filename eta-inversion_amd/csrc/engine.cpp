@@ -1335,6 +1335,28 @@ extern "C" int etainv_op_gemm_gnstat(const void* a, const void* w, const float* 
   return launch_igemm(p, dtype, (hipStream_t)stream, wm_out);
 }
 
+extern "C" int etainv_op_conv3x3_gnstat(const void* x_nhwc, const void* w_okkc, const float* bias, const float* rowvec, const void* residual, void* out,
+                                        float* part, int* wm_out, int b, int h, int wd, int cin, int cout, int dtype, void* stream) {
+  IGemmParams p;
+  p.a1 = x_nhwc;
+  p.w = w_okkc;
+  p.bias = bias;
+  p.rowvec = rowvec;
+  p.rowvec_stride = cout;
+  p.residual = residual;
+  p.out = out;
+  p.c1 = cin;
+  p.H = p.Ho = h;
+  p.W = p.Wo = wd;
+  p.taps = 9;
+  p.M = b * h * wd;
+  p.N = cout;
+  p.rows_per_batch = h * wd;
+  p.stat_out = part;
+  p.stat_kind = 1;
+  return launch_igemm(p, dtype, (hipStream_t)stream, wm_out);
+}
+
 extern "C" int etainv_op_groupnorm_pre(const void* x1, const void* x2, int c1, int c2, const float* part1, int wm1, const float* part2, int wm2,
                                        const float* gamma, const float* beta, void* out, int b, int hw, int groups, float eps, int silu,
                                        float* final_stats, int dtype, void* stream) {

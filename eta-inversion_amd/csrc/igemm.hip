@@ -1454,6 +1454,10 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   ETAINV_CHECK(!p.ln_stat || (!p.out_f32 && !p.out_nchw), "folded LayerNorm: the consumer stores the compute dtype, row-major (the fp32 / NCHW epilogues do not apply mean / rstd)");
   ETAINV_CHECK(!p.hm_heads || igemm_hm_ok(p, dtype), "head-major QKV output: not available for this launch (ask igemm_hm_ok first)");
   if (p.hm_heads) p.hm_magic = (int)(((1ull << 38) + (unsigned)p.hm_tokens - 1) / (unsigned)p.hm_tokens);   // m0 / hm_tokens == (m0 * magic) >> 38 for m0 < 2^24, hm_tokens <= 2^14
+  if (pp_conv_applicable(p, dtype)) {    // ping-pong PATCH conv3x3 (ppconv.hip)
+    ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(9 * p.c1), s, igemm_algo_bytes(p));
+    return launch_pp_conv(p, dtype, s, stat_P);
+  }
   if (pp_dualn_applicable(p, dtype)) {   // dual-N ping-pong kernel (ppgemm.hip)
     ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)p.c1, s, igemm_algo_bytes(p));
     return launch_pp_dualn(p, dtype, s, stat_P);

@@ -77,6 +77,11 @@ bool pp_dualn_applicable(const IGemmParams& p, int dtype);
 bool pp_dualn_hm_ok(const IGemmParams& p, int dtype);   // ... as a LayerNorm consumer that writes the head-major QKV planes (hm_* set)?
 int launch_pp_dualn(const IGemmParams& p, int dtype, hipStream_t s, int* stat_P = nullptr);
 
+// ---- ppconv.hip: conv3x3 stride 1 in PATCH form (16 x 16 pixel tiles, halo'd activation patch per channel chunk) with the wave groups in anti-phase and a
+// lean issue side; bias + time row + residual + GroupNorm-statistics epilogues; launch_igemm routes to it when pp_conv_applicable
+bool pp_conv_applicable(const IGemmParams& p, int dtype);
+int launch_pp_conv(const IGemmParams& p, int dtype, hipStream_t s, int* stat_P = nullptr);
+
 // ---- f32path.hip: the fp32-operand execution (dtype == ETAINV_F32 routes here from the launchers of igemm / norm / attention)
 int launch_igemm_f32(const IGemmParams& p, hipStream_t s);
 int launch_groupnorm_f32(const void* x1, const void* x2, int c1, int c2, const float* gamma, const float* beta, void* out, int b, int hw, int groups,

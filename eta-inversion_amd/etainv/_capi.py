@@ -67,6 +67,7 @@ SIGNATURES = {
     "etainv_engine_cache_context": [_p, _i],
     "etainv_engine_context_generation": [_p, C.c_uint64],
     "etainv_op_gemm_gnstat": [_p, _p, _p, _p, _p, _p, C.POINTER(_i), _i, _i, _i, _i, _i, _p],
+    "etainv_op_conv3x3_gnstat": [_p, _p, _p, _p, _p, _p, _p, C.POINTER(_i), _i, _i, _i, _i, _i, _i, _p],
     "etainv_op_groupnorm_pre": [_p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _p, _i, _p],
     "etainv_op_ln_fold": [_p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _i, _p],
     "etainv_op_row_stats": [_p, _p, _i, _i, _f, _i, _p],

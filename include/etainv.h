@@ -263,6 +263,10 @@ int etainv_op_ln_finalize(const float* partials, int p, int cw, float eps, float
  * apply pass's per-channel scale / shift planes). */
 int etainv_op_gemm_gnstat(const void* a, const void* w, const float* bias, const void* residual, void* out, float* part, int* wm_out, int m,
                           int n, int k, int rows_per_image, int dtype, void* stream);
+/* etainv_op_conv3x3 (stride 1, single source, nine taps) that also leaves the GroupNorm partials of its stored output, as etainv_op_gemm_gnstat does for
+ * the 1x1 layers: conv1 / conv2 of [3P] diffusers ResnetBlock2D feed the next GroupNorm (inside the UNet call of eta_inversion.py:321). */
+int etainv_op_conv3x3_gnstat(const void* x_nhwc, const void* w_okkc, const float* bias, const float* rowvec, const void* residual, void* out,
+                             float* part, int* wm_out, int b, int h, int wd, int cin, int cout, int dtype, void* stream);
 int etainv_op_groupnorm_pre(const void* x1, const void* x2, int c1, int c2, const float* part1, int wm1, const float* part2, int wm2,
                             const float* gamma, const float* beta, void* out, int b, int hw, int groups, float eps, int silu,
                             float* final_stats, int dtype, void* stream);

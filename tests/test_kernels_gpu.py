@@ -450,6 +450,53 @@ def test_conv3x3_patch_mode(capi, dtype, monkeypatch, b, h, wd, cin, cout, res):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,h,wd,cin,cout,res", [(16, 64, 64, 320, 320, True), (16, 64, 64, 960, 320, False), (64, 32, 32, 640, 640, True),
+                                                 (256, 16, 16, 1280, 1280, False), (48, 16, 32, 640, 640, True), (7, 48, 48, 320, 640, True)])
+def test_conv3x3_ping_pong_patch(capi, dtype, monkeypatch, b, h, wd, cin, cout, res):
+    """ppconv.hip (default for conv3x3 stride 1 on 16-pixel-aligned images): the PATCH-mode K loop with the wave groups in anti-phase and a lean issue side.
+    Against F.conv2d, bit for bit against igemm.hip's PATCH ring (same accumulation order), and the GroupNorm partials of the stored output (per channel
+    sum / sum of squares over every 64-row block) against a pass over the output; image borders, several tiles per block, an odd tile count, non-square"""
+    lib = capi.load()
+    dt = capi.dtype_code(dtype)
+    x = rnd(b, cin, h, wd, seed=1, dtype=dtype)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5, dtype=dtype)
+    bias, rowvec = rnd(cout, seed=3), rnd(b, cout, seed=5)
+    r = rnd(b, h, wd, cout, seed=6, dtype=dtype) if res else None
+    ref = F.conv2d(x.float(), w.float(), bias, padding=1) + rowvec[:, :, None, None]
+    if res:
+        ref = ref + r.float().permute(0, 3, 1, 2)
+    x_nhwc, wk = x.permute(0, 2, 3, 1).contiguous(), w.permute(0, 2, 3, 1).contiguous()
+    outs, parts, wms = [], [], []
+    for on in ("1", "0"):
+        monkeypatch.setenv("ETAINV_PPCONV", on)
+        out = torch.full((b, h, wd, cout), float("nan"), dtype=dtype, device="cuda")
+        part = torch.full((b * h * wd // 16 * 2 * cout,), float("nan"), device="cuda")
+        wm = C.c_int(-1)
+        capi.check(lib.etainv_op_conv3x3_gnstat(capi.ptr(x_nhwc), capi.ptr(wk), capi.ptr(bias), capi.ptr(rowvec), capi.ptr(r), capi.ptr(out), capi.ptr(part),
+                                                C.byref(wm), b, h, wd, cin, cout, dt, capi.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(out)
+        parts.append(part)
+        wms.append(wm.value)
+        out2 = torch.full((b, h, wd, cout), float("nan"), dtype=dtype, device="cuda")        # the plain epilogue (no statistics)
+        capi.check(lib.etainv_op_conv3x3(capi.ptr(x_nhwc), None, cin, 0, capi.ptr(wk), capi.ptr(bias), capi.ptr(rowvec), capi.ptr(r), capi.ptr(out2), b, h, wd, cout,
+                                         1, 0, 9, dt, capi.stream_ptr()))
+        assert torch.equal(out, out2)
+    assert relerr(outs[0].permute(0, 3, 1, 2), ref) < TOL[dtype]
+    d = (outs[0].float() - ref.permute(0, 2, 3, 1)).reshape(b * h, -1).norm(dim=1) / ref.permute(0, 2, 3, 1).reshape(b * h, -1).norm(dim=1)
+    assert float(d.max()) < 3 * TOL[dtype]                 # per image row: a misplaced patch row hides in a global norm
+    assert torch.equal(outs[0], outs[1]), "ping-pong and ring PATCH kernels accumulate in the same order"
+    assert wms[0] == wms[1] == 64
+    # partials: blocks of 64 VIRTUAL rows (patches of 16 x 16 pixels enumerated image-major, 4 patch rows per block) -> compare per image
+    n_blk = b * h * wd // 64
+    st = parts[0][: n_blk * 2 * cout].view(b, h * wd // 64, 2, cout).sum(1)
+    xf = outs[0].float().reshape(b, h * wd, cout)
+    torch.testing.assert_close(st[:, 0], xf.sum(1), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(st[:, 1], (xf * xf).sum(1), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(parts[0][: n_blk * 2 * cout], parts[1][: n_blk * 2 * cout], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("m,n,k,res,stat", [(65536, 320, 320, True, True), (65536, 320, 1280, True, True), (49152, 640, 640, True, False),
                                             (49152, 640, 2560, False, True), (49152, 1280, 5120, True, True), (98304, 320, 128, False, False),
                                             (131072 + 256 * 3, 320, 320, True, True)])
