@@ -402,6 +402,14 @@ def main():
     for cand in (sorted((ROOT / "profiles").glob("r*_pmc_traffic_rows128.json"), reverse=True) if 4 * B == 128 else []):
         traffic, traffic_src = json.load(open(cand))["igemm"]["hbm_bytes_per_launch"], f"profiles/{cand.name} (one 128-row UNet call)"
         break
+    # matrix-pipe busy share of the same kernels from the SQ counters (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE over tools/unet_call.py
+    # --rows 128, aggregated by tools/pmc_sq.py): file-sourced like `traffic`, named in the JSON
+    mfma_busy, mfma_busy_src = None, None
+    for cand in (sorted((ROOT / "profiles").glob("r*_pmc_sq_rows128.json"), reverse=True) if 4 * B == 128 else []):
+        fam = json.load(open(cand)).get("summary", {}).get("igemm_family")
+        if fam and fam.get("mfma_busy_frac") is not None:
+            mfma_busy, mfma_busy_src = fam["mfma_busy_frac"], f"profiles/{cand.name} (one 128-row UNet call, cycle-weighted over the implicit-GEMM kernels)"
+            break
     images = B * world * a.steps
     value = images / dt
     # MFMA FLOPs the kernels EXECUTED per image (implicit GEMMs + both attentions of the profiled step: the launchers record 2 M N K / 4 B h N^2 d
@@ -428,8 +436,10 @@ def main():
                                                f"{6 * S_STEPS * F_UNET_TFLOP:.1f}",
                        "sharding": f"batch-shard x{world}, final all_gather of latents"},
             "end_to_end_mfma_frac": value / world * exec_tflop_per_image / MFMA_PEAK_TFLOPS,
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv3x3 / conv1x1 / linear)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "implicit-GEMM family: pp_conv_kernel (conv3x3, PATCH ping-pong), pp_dualn_kernel (1x1 / Linear / GEGLU, dual-N "
+                                                    "ping-pong), igemm_kernel (strided / upsampling / small launches)", "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_busy_src,
                          "note": "achieved = GEMM FLOPs only over the kernel's whole duration; its epilogues also carry bias / time row / residual / GEGLU and, "
                                  "since round 2, the LayerNorm and GroupNorm statistics that were separate passes (ETAINV_LN_UNFUSED / ETAINV_GN_UNFUSED move them "
                                  "back out: higher igemm TFLOP/s, lower images/s)",

@@ -423,6 +423,15 @@ __global__ void __launch_bounds__(512, 2) pp_gemm_kernel(IGemmParams p) {
 // per half, 256 x 256 tile) with EPI 3 = LayerNorm consumer + GEGLU (a * gelu_erf(g), value / gate columns interleaved per 64 by pack mode 2).
 // The LayerNorm consumers' s vector and (mean, rstd) rows arrive by DMA with the bias (two-deep rings: the weight cursor enters tile t + 2 only after
 // the epilogue of tile t).
+// sum over the 16 lanes of a DPP row (igemm.hip row_sum16)
+__device__ __forceinline__ float dualn_row_sum16(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true));
+  return x;
+}
+
 template <int HN> struct DualN {
   static constexpr int NT = HN / 32;                 // 16-column blocks per wave tile (two waves across a half)
   static constexpr int WN = HN / 2;
@@ -432,7 +441,7 @@ template <int HN> struct DualN {
   static constexpr int OFF_BIAS = 2 * SLOT, OFF_S = OFF_BIAS + 2 * BN2 * 4, OFF_STAT = OFF_S + 2 * BN2 * 4, LDS = OFF_STAT + 2 * PBM * 2 * 4;
 };
 
-template <typename T, int HN, int EPI, bool RES, bool STAT>
+template <typename T, int HN, int EPI, bool RES, int STAT>   // STAT: 0 none, 1 LayerNorm row statistics, 2 GroupNorm channel statistics of the stored output
 __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
   typedef typename PMfma<T>::frag frag;
   typedef DualN<HN> D;
@@ -616,6 +625,83 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
         }
         store_blocks(out + (int64_t)(mrow + i * 16) * No + ((n0 + wn * WN) >> 1), po, std::integral_constant<int, NT / 2>{}, 1 << 30, 0);
       }
+    } else if constexpr (STAT == 2) {
+      // GroupNorm producer (proj_out of the transformer blocks): per channel, sum and sum of squares of the stored values over the 64 rows of the wave tile
+      // -> stat_out[row tile][0 / 1][channel] (igemm.hip's gn_emit: row groups 0 .. 3, then the 16 pixel lanes by DPP -- identical partials).  By column-
+      // block pairs (0, 1), (2, 3), (4) -- the pairs of the 16-byte stores: 16 registers of sums at a time, the next pair's residual in flight
+      const int64_t lane_off = (int64_t)mrow * N + n0 + wn * WN;
+      const int64_t rt = (int64_t)(m0 + wm * 64) / 64;
+      float* gs = p.stat_out;
+      u32x2 rva[PMT][2], rvb[PMT][2];
+      auto load_res = [&](auto& rv, auto j0_tag, auto nb_tag) __attribute__((always_inline)) {
+        constexpr int j0 = decltype(j0_tag)::value, NB = decltype(nb_tag)::value;
+#pragma unroll
+        for (int i = 0; i < PMT; ++i)
+#pragma unroll
+          for (int jj = 0; jj < NB; ++jj) rv[i][jj] = *reinterpret_cast<const u32x2*>(res + lane_off + (int64_t)i * 16 * N + (j0 + jj) * 16 + fq * 4);
+      };
+      auto do_pair = [&](auto& rv, auto j0_tag, auto nb_tag) __attribute__((always_inline)) {
+        constexpr int j0 = decltype(j0_tag)::value, NB = decltype(nb_tag)::value;
+        f32x4 sm[NB], sq[NB];
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj) sm[jj] = sq[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < PMT; ++i) {
+          u32x2 po[NB];
+#pragma unroll
+          for (int jj = 0; jj < NB; ++jj) {
+            f32x4 v = NH == 0 ? acc0[i][j0 + jj] : acc1[i][j0 + jj];
+            if constexpr (NH == 0) acc0[i][j0 + jj] = (f32x4){0.f, 0.f, 0.f, 0.f}; else acc1[i][j0 + jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (has_bias) v += *reinterpret_cast<const f32x4*>(tb + (j0 + jj) * 16);
+            if constexpr (RES) {
+              T r[4];
+              *reinterpret_cast<u32x2*>(r) = rv[i][jj];
+              v[0] += to_f32(r[0]); v[1] += to_f32(r[1]); v[2] += to_f32(r[2]); v[3] += to_f32(r[3]);
+            }
+            T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+            po[jj] = *reinterpret_cast<u32x2*>(o);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float x = to_f32(o[q]);
+              sm[jj][q] += x;
+              sq[jj][q] += x * x;
+            }
+          }
+          T* prow = out + lane_off + (int64_t)i * 16 * N;
+          if constexpr (NB == 2) {
+            const auto lo = __builtin_amdgcn_permlane16_swap(po[0][0], po[1][0], false, false);
+            const auto hi = __builtin_amdgcn_permlane16_swap(po[0][1], po[1][1], false, false);
+            const u32x4 v = {lo[0], hi[0], lo[1], hi[1]};
+            *reinterpret_cast<u32x4*>(prow + (j0 + (fq & 1)) * 16 + (fq >> 1) * 8) = v;
+          } else {
+            *reinterpret_cast<u32x2*>(prow + j0 * 16 + fq * 4) = po[0];
+          }
+        }
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            sm[jj][q] = dualn_row_sum16(sm[jj][q]);
+            sq[jj][q] = dualn_row_sum16(sq[jj][q]);
+          }
+          const int n = n0 + wn * WN + (j0 + jj) * 16 + fq * 4;
+          if (fr == 0) {
+            *reinterpret_cast<f32x4*>(gs + (rt * 2 + 0) * N + n) = sm[jj];
+            *reinterpret_cast<f32x4*>(gs + (rt * 2 + 1) * N + n) = sq[jj];
+          }
+        }
+      };
+      typedef std::integral_constant<int, 0> J0;
+      typedef std::integral_constant<int, 2> J2;
+      typedef std::integral_constant<int, 4> J4;
+      typedef std::integral_constant<int, 1> N1;
+      typedef std::integral_constant<int, 2> N2;
+      static_assert(NT == 5, "pairs (0, 1), (2, 3), (4)");
+      if constexpr (RES) { load_res(rva, J0{}, N2{}); load_res(rvb, J2{}, N2{}); }
+      do_pair(rva, J0{}, N2{});
+      if constexpr (RES) load_res(rva, J4{}, N1{});
+      do_pair(rvb, J2{}, N2{});
+      do_pair(rva, J4{}, N1{});
     } else {
       const int64_t lane_off = (int64_t)mrow * N + n0 + wn * WN;
       u32x2 rv[PMT][NT];
@@ -661,7 +747,7 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
           store_blocks(plane + (int64_t)(mrow + i * 16 - hm_tok0) * p.hm_dim, po, std::integral_constant<int, NT>{}, p.hm_dim, (p.hm_tokens - 1) * p.hm_dim);
         else
           store_blocks(out + lane_off + (int64_t)i * 16 * N, po, std::integral_constant<int, NT>{}, 1 << 30, 0);
-        if constexpr (STAT) {
+        if constexpr (STAT == 1) {
           // (mean, M2) of the 20 stored values of this lane, merged over the four fq lanes by Chan's update in igemm.hip's order (even 16-lane row first, then
           // the lower half first): partial n0 / 80 + wn of row m.  The exchanges go through ds_bpermute (__shfl_xor): inline asm with register outputs makes
           // hipcc spill in this kernel (see pp_gemm_applicable)
@@ -787,7 +873,7 @@ bool pp_gemm_applicable(const IGemmParams& p, int dtype) {
 static int dualn_kind(const IGemmParams& p, int dtype) {
   if (!env_flag("ETAINV_DUALN", true) || (dtype != ETAINV_F16 && dtype != ETAINV_BF16)) return -1;
   if (p.taps != 1 || p.a2 || p.rowvec || p.out_f32 || p.out_nchw || p.w_batch_stride || p.ksplit > 1) return -1;
-  if (p.stat_out && (p.stat_kind != 0 || p.rows_per_batch % 64 != 0)) return -1;
+  if (p.stat_out && p.rows_per_batch % 64 != 0) return -1;     // (LayerNorm rows: partial index per wave tile; GroupNorm: whole wave tiles inside one image)
   if (p.M % PBM != 0 || p.c1 % PBK != 0 || p.c1 < 2 * PBK) return -1;
   int kind;
   if (p.geglu) {
@@ -811,7 +897,7 @@ static int dualn_kind(const IGemmParams& p, int dtype) {
 bool pp_dualn_applicable(const IGemmParams& p, int dtype) { return dualn_kind(p, dtype) >= 0; }
 bool pp_dualn_hm_ok(const IGemmParams& p, int dtype) { return dualn_kind(p, dtype) == 2; }
 
-template <typename T, int HN, int EPI, bool RES, bool STAT>
+template <typename T, int HN, int EPI, bool RES, int STAT>
 static void launch_dualn_t(const IGemmParams& p, int grid, hipStream_t s) {
   static bool attr_set[kMaxDevices] = {};
   const int dev = current_device();
@@ -826,18 +912,22 @@ int launch_pp_dualn(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat
   IGemmParams p = p_in;
   const int kind = dualn_kind(p, dtype);
   ETAINV_CHECK(kind >= 0, "not a dual-N launch (ask pp_dualn_applicable first)");
-  if (p.stat_out) p.stat_P = p.N / 80;
+  if (p.stat_out) p.stat_P = p.stat_kind == 1 ? 64 : p.N / 80;   // GroupNorm: rows per partial block; LayerNorm: partials per row
   if (stat_P) *stat_P = p.stat_out ? p.stat_P : 0;
   const int tiles = (p.M / PBM) * (p.N / (kind == 3 ? 256 : 320));
   const int grid = std::min(tiles, 256);
   ETAINV_DISPATCH_HALF(dtype, T, {
-    if (kind == 3) launch_dualn_t<T, 128, 3, false, false>(p, grid, s);
-    else if (kind == 2) launch_dualn_t<T, 160, 2, false, false>(p, grid, s);
-    else if (kind == 1) launch_dualn_t<T, 160, 1, false, false>(p, grid, s);
+    if (kind == 3) launch_dualn_t<T, 128, 3, false, 0>(p, grid, s);
+    else if (kind == 2) launch_dualn_t<T, 160, 2, false, 0>(p, grid, s);
+    else if (kind == 1) launch_dualn_t<T, 160, 1, false, 0>(p, grid, s);
     else if (p.residual) {
-      if (p.stat_out) launch_dualn_t<T, 160, 0, true, true>(p, grid, s); else launch_dualn_t<T, 160, 0, true, false>(p, grid, s);
+      if (p.stat_out && p.stat_kind == 1) launch_dualn_t<T, 160, 0, true, 2>(p, grid, s);
+      else if (p.stat_out) launch_dualn_t<T, 160, 0, true, 1>(p, grid, s);
+      else launch_dualn_t<T, 160, 0, true, 0>(p, grid, s);
     } else {
-      if (p.stat_out) launch_dualn_t<T, 160, 0, false, true>(p, grid, s); else launch_dualn_t<T, 160, 0, false, false>(p, grid, s);
+      if (p.stat_out && p.stat_kind == 1) launch_dualn_t<T, 160, 0, false, 2>(p, grid, s);
+      else if (p.stat_out) launch_dualn_t<T, 160, 0, false, 1>(p, grid, s);
+      else launch_dualn_t<T, 160, 0, false, 0>(p, grid, s);
     }
   });
   ETAINV_LAUNCH_CHECK();

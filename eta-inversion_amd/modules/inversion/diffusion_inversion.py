@@ -102,18 +102,22 @@ class DiffusionInversion:
         return out
 
     def predict_noise(self, latent, t, context, guidance_scale, is_fwd: bool = False, **kwargs):
+        """eps(latent, t, context) with classifier-free guidance (reference :263-286): guidance None = plain UNet call; a context twice as long as the
+        latent batch = [uncond rows, cond rows] over the same latents; the scales 0 / 1 need one half only"""
+        def eps(x, ctx):
+            return self.unet(x, t, encoder_hidden_states=ctx, **kwargs)["sample"]
+
         if guidance_scale is None:
-            return self.unet(latent, t, encoder_hidden_states=context, **kwargs)["sample"]
-        if latent.shape[0] * 2 == context.shape[0]:
-            latent = torch.cat([latent] * 2)
-        else:
-            assert latent.shape[0] == context.shape[0]
-        n = latent.shape[0] // 2
-        if isinstance(guidance_scale, (int, float)) and guidance_scale == 0:
-            return self.unet(latent[:n], t, encoder_hidden_states=context[:n], **kwargs)["sample"]
-        if isinstance(guidance_scale, (int, float)) and guidance_scale == 1:
-            return self.unet(latent[n:], t, encoder_hidden_states=context[n:], **kwargs)["sample"]
-        return self._cfg(self.unet(latent, t, encoder_hidden_states=context, **kwargs)["sample"], guidance_scale)
+            return eps(latent, context)
+        rows = context.shape[0]
+        if rows == 2 * latent.shape[0]:
+            latent = latent.repeat(2, *([1] * (latent.dim() - 1)))
+        assert latent.shape[0] == rows
+        half = rows // 2
+        if isinstance(guidance_scale, (int, float)) and guidance_scale in (0, 1):
+            keep = slice(half, rows) if guidance_scale == 1 else slice(0, half)
+            return eps(latent[keep], context[keep])
+        return self._cfg(eps(latent, context), guidance_scale)
 
     def step_forward(self, noise_pred, t, latent, *args, **kwargs) -> Any:
         return self.scheduler_fwd.step(noise_pred, t, latent, *args, **kwargs)
@@ -121,21 +125,18 @@ class DiffusionInversion:
     def step_backward(self, noise_pred, t, latent, *args, **kwargs) -> Any:
         return self.scheduler_bwd.step(noise_pred, t, latent, *args, **kwargs)
 
+    def _hooked_step(self, latent, t, context, scale, forward: bool):
+        """one scheduler step between the controller's begin_step / end_step hooks (reference :328-341); the forward hook gets no timestep"""
+        latent = self.controller.begin_step(latent=latent) if forward else self.controller.begin_step(latent=latent, t=t)
+        eps = self.predict_noise(latent, t, context, scale, is_fwd=True) if forward else self.predict_noise(latent, t, context, scale)
+        stepped = (self.step_forward if forward else self.step_backward)(eps, t, latent).prev_sample
+        return self.controller.end_step(latent=stepped, noise_pred=eps, t=t), eps
+
     def predict_step_forward(self, latent, t, context, guidance_scale_fwd=None):
-        guidance_scale_fwd = guidance_scale_fwd or self.guidance_scale_fwd
-        latent = self.controller.begin_step(latent=latent)
-        noise_pred = self.predict_noise(latent, t, context, guidance_scale_fwd, is_fwd=True)
-        new_latent = self.step_forward(noise_pred, t, latent).prev_sample
-        new_latent = self.controller.end_step(latent=new_latent, noise_pred=noise_pred, t=t)
-        return new_latent, noise_pred
+        return self._hooked_step(latent, t, context, guidance_scale_fwd or self.guidance_scale_fwd, True)
 
     def predict_step_backward(self, latent, t, context, guidance_scale_bwd=None):
-        guidance_scale_bwd = guidance_scale_bwd or self.guidance_scale_bwd
-        latent = self.controller.begin_step(latent=latent, t=t)
-        noise_pred = self.predict_noise(latent, t, context, guidance_scale_bwd)
-        new_latent = self.step_backward(noise_pred, t, latent).prev_sample
-        new_latent = self.controller.end_step(latent=new_latent, noise_pred=noise_pred, t=t)
-        return new_latent, noise_pred
+        return self._hooked_step(latent, t, context, guidance_scale_bwd or self.guidance_scale_bwd, False)
 
     def get_timesteps_forward(self) -> torch.Tensor:
         return self.scheduler_fwd.timesteps
@@ -145,14 +146,15 @@ class DiffusionInversion:
 
     # ------------------------------------------------------------------ loops
     def diffusion_forward(self, latent, context, guidance_scale_fwd=None) -> Dict[str, Any]:
-        guidance_scale_fwd = guidance_scale_fwd or self.guidance_scale_fwd
-        latents, noise_preds = [latent], []
-        latent = latent.clone().detach()
+        """the inversion trajectory z_0 .. z_T with the noise predicted at each step (reference :401-418)"""
+        scale = guidance_scale_fwd or self.guidance_scale_fwd
+        trajectory, eps_seen = [latent], []
+        z = latent.clone().detach()
         for t in self.pbar(self.get_timesteps_forward(), desc="forward"):
-            latent, noise_pred = self.predict_step_forward(latent, t, context, guidance_scale_fwd)
-            noise_preds.append(noise_pred)
-            latents.append(latent)
-        return {"latents": latents, "noise_preds": noise_preds, "zT_inv": latents[-1]}
+            z, eps = self.predict_step_forward(z, t, context, scale)
+            trajectory.append(z)
+            eps_seen.append(eps)
+        return {"latents": trajectory, "noise_preds": eps_seen, "zT_inv": trajectory[-1]}
 
     def diffusion_backward(self, latent, context, inv_result):
         for t in self.pbar(self.get_timesteps_backward(), desc="backward"):
@@ -167,27 +169,26 @@ class DiffusionInversion:
         return {**kwargs, **res}
 
     def cat_context(self, contexts: List[torch.Tensor]) -> torch.Tensor:
-        n, b = len(contexts), contexts[0].shape[0]
-        assert b == 2, "Cfg should have batch dimension 2"
-        x = torch.stack(contexts, 1)
-        return x.reshape(b * n, *x.shape[2:])
+        """[(uncond, cond)] x n -> rows [uncond x n, cond x n] (reference :476-479)"""
+        if any(c.shape[0] != 2 for c in contexts):
+            raise AssertionError("Cfg should have batch dimension 2")
+        return torch.stack(contexts, dim=1).flatten(0, 1)
 
     def cat_latent(self, latents: List[torch.Tensor]) -> torch.Tensor:
         return torch.cat(latents)
 
     def sample(self, inv_result, prompt=None, context=None):
+        """backward pass from the inverted latent under `context` (a list = several prompts over copies of the latent; reference :507-528)"""
         if inv_result is None:
             return None
-        latent = inv_result["latents"][-1]
-        context = context if context is not None else self.create_context(prompt)
+        if context is None:
+            context = self.create_context(prompt)
+        z_T = inv_result["latents"][-1]
         if isinstance(context, list):
-            n = len(context)
+            z_T = self.cat_latent([z_T] * len(context))
             context = self.cat_context(context)
-            latent = self.cat_latent([latent] * n)
-        z0 = self.diffusion_backward(latent, context, inv_result)
-        if z0 is None:
-            return None
-        return {"image": self.decode(z0), "latent": z0}
+        z0 = self.diffusion_backward(z_T, context, inv_result)
+        return None if z0 is None else {"image": self.decode(z0), "latent": z0}
 
     def invert_sample(self, image, prompt: str):
         context = self.create_context(prompt)

@@ -60,18 +60,11 @@ class StablePreprocess:
         from PIL import Image
         if isinstance(image, (str, Path)):
             image = np.array(Image.open(str(image)).convert("RGB"))
-        if self.center_crop:
+        if self.center_crop:                          # the centred square of side min(h, w) (reference :45-61)
             h, w = image.shape[:2]
-            if w > h:
-                x1 = (w - h) // 2
-                x2 = w - h - x1
-                if x2 > 0:
-                    image = image[:, x1:-x2]
-            else:
-                y1 = (h - w) // 2
-                y2 = h - w - y1
-                if y2 > 0:
-                    image = image[y1:-y2]
+            side = min(h, w)
+            top, left = (h - side) // 2, (w - side) // 2
+            image = image[top:top + side, left:left + side]
         if self.pil_resize:
             image = np.array(Image.fromarray(image).resize((self.size, self.size)))
         else:

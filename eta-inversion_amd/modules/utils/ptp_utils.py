@@ -5,32 +5,33 @@ from .seq_aligner import get_word_inds  # noqa: F401  (same function, re-exporte
 
 
 def update_alpha_time_word(alpha, bounds, prompt_ind, word_inds=None):
-    if isinstance(bounds, float):
-        bounds = (0, bounds)
-    n = alpha.shape[0]
-    start, end = int(bounds[0] * n), int(bounds[1] * n)
-    if word_inds is None:
-        word_inds = torch.arange(alpha.shape[2])
-    alpha[:start, prompt_ind, word_inds] = 0
-    alpha[start:end, prompt_ind, word_inds] = 1
-    alpha[end:, prompt_ind, word_inds] = 0
+    """alpha[step, prompt_ind, words] := 1 for steps in [lo * n, hi * n) (n = number of table rows), 0 outside; a single float bounds the window
+    from 0 (reference :326-336)"""
+    lo, hi = (0.0, bounds) if isinstance(bounds, float) else (bounds[0], bounds[1])
+    rows = alpha.shape[0]
+    window = torch.zeros(rows, dtype=alpha.dtype)
+    window[int(lo * rows):int(hi * rows)] = 1
+    cols = torch.arange(alpha.shape[2]) if word_inds is None else word_inds
+    alpha[:, prompt_ind, cols] = window[:, None].expand(rows, len(cols)) if cols.dim() else window
     return alpha
 
 
 def get_time_words_attention_alpha(prompts, num_steps, cross_replace_steps, tokenizer, max_num_words=77):
-    """(num_steps+1, n_prompts-1, 1, 1, 77): 1 while the cross-attention edit is active for that token."""
-    if not isinstance(cross_replace_steps, dict):
-        cross_replace_steps = {"default_": cross_replace_steps}
-    if "default_" not in cross_replace_steps:
-        cross_replace_steps["default_"] = (0., 1.)
-    alpha = torch.zeros(num_steps + 1, len(prompts) - 1, max_num_words)
-    for i in range(len(prompts) - 1):
-        alpha = update_alpha_time_word(alpha, cross_replace_steps["default_"], i)
-    for word, bounds in cross_replace_steps.items():
+    """(num_steps+1, n_prompts-1, 1, 1, 77): 1 while the cross-attention edit is active for that token: the "default_" window for every token of
+    every edited prompt, then per-word windows for the tokens of the words named in `cross_replace_steps` (reference :339-357)"""
+    windows = dict(cross_replace_steps) if isinstance(cross_replace_steps, dict) else {"default_": cross_replace_steps}
+    windows.setdefault("default_", (0., 1.))
+    if isinstance(cross_replace_steps, dict):
+        cross_replace_steps.setdefault("default_", (0., 1.))      # (the reference fills the caller's dict in)
+    n_edit = len(prompts) - 1
+    alpha = torch.zeros(num_steps + 1, n_edit, max_num_words)
+    for e in range(n_edit):
+        update_alpha_time_word(alpha, windows["default_"], e)
+    for word, bounds in windows.items():
         if word == "default_":
             continue
-        for i in range(1, len(prompts)):
-            inds = get_word_inds(prompts[i], word, tokenizer)
+        for e in range(n_edit):
+            inds = get_word_inds(prompts[e + 1], word, tokenizer)
             if len(inds) > 0:
-                alpha = update_alpha_time_word(alpha, bounds, i - 1, torch.as_tensor(inds))
-    return alpha.reshape(num_steps + 1, len(prompts) - 1, 1, 1, max_num_words)
+                update_alpha_time_word(alpha, bounds, e, torch.as_tensor(inds))
+    return alpha.reshape(num_steps + 1, n_edit, 1, 1, max_num_words)

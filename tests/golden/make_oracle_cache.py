@@ -4,7 +4,7 @@
     python tests/golden/make_oracle_cache.py                 # every leg that has no file yet
     python tests/golden/make_oracle_cache.py --force         # recompute everything
     python tests/golden/make_oracle_cache.py --only realsize # legs whose name contains the pattern
-    python tests/golden/make_oracle_cache.py --list
+    python tests/golden/make_oracle_cache.py --list           # have / miss / STALE (written from another oracle/*.py or leg source: MANIFEST.json)
 
 CPU only (the legs regenerate their inputs from seeds and never touch the engine); about an hour on 8 cores, dominated by the L = 64 / 96
 loops and their emulated-16-bit floors.  The S = 50 free-running runs of `tests/parity_s50.py` (50 min per pair on the GPU box's host) are
@@ -63,12 +63,24 @@ def main():
     ap.add_argument("--list", action="store_true")
     ap.add_argument("--threads", type=int, default=os.cpu_count())
     ap.add_argument("--from-parity-cache", default=None)
+    ap.add_argument("--stamp-manifest", action="store_true", help="record today's oracle / leg fingerprints for every committed result WITHOUT recomputing it: "
+                    "only right after `ETAINV_SLOW=1 pytest tests/test_oracle_cache.py` has shown that the files equal the live oracle")
     a = ap.parse_args()
     os.environ["ETAINV_ORACLE"] = "write"
     torch.set_num_threads(a.threads)
     oc = import_legs()
     if a.from_parity_cache:
         return convert_parity_cache(Path(a.from_parity_cache), oc)
+    if a.stamp_manifest:
+        n = 0
+        for name, (fn, cases) in oc.LEGS.items():
+            for args in cases:
+                key = oc.key_of(name, args)
+                if (oc.CACHE_DIR / f"{key}.npz").exists():
+                    oc.record(key, fn)
+                    n += 1
+        print(f"stamped {n} entries: oracle {oc.oracle_fingerprint()}")
+        return
     todo = []
     for name, (fn, cases) in oc.LEGS.items():
         for args in cases:
@@ -77,7 +89,9 @@ def main():
                 continue
             exists = (oc.CACHE_DIR / f"{key}.npz").exists()
             if a.list:
-                print(("have " if exists else "miss ") + key)
+                why = oc.stale_reason(key, fn) if exists else None
+                print(("STALE " if why else "have  " if exists else "miss  ") + key + (f"   <- {why}" if why else "") +
+                      ("" if not exists or key in oc.read_manifest() else "   (no manifest entry)"))
             elif a.force or not exists:
                 todo.append((name, args, key))
     if a.list:

@@ -6,7 +6,8 @@ function decorated with `@oracle_leg(cases=[...])`: a pure function of its (smal
 seeds inside it -- whose result (latents, eps, best indices, losses, word maps, reference-precision floors) is stored once under
 `tests/golden/oracle_cache/<module>.<function>[<args>].npz` by `tests/golden/make_oracle_cache.py` and read back by the tests.
 
-  ETAINV_ORACLE=cache (default)  read the committed file; a missing file is computed live (and reported)
+  ETAINV_ORACLE=cache (default)  read the committed file; a missing or STALE file (MANIFEST.json: written from another oracle/*.py or leg source) is
+                                 computed live (and reported)
   ETAINV_ORACLE=live             ignore the files and run the oracle (the pre-round-4 behaviour; `tests/test_oracle_cache.py` does this for
                                  every leg under @pytest.mark.slow and for a small one in the default CPU suite, so the files cannot drift)
   ETAINV_ORACLE=write            like cache, and a missing file is written after it has been computed (make_oracle_cache.py --force deletes first)
@@ -99,6 +100,79 @@ def load(path):
         return _unpack(skel, z)
 
 
+# ------------------------------------------------------------------------------------------------ fingerprints: a committed result belongs to ONE oracle
+# A result file is keyed by leg name and arguments only; what it was computed FROM is recorded next to it: MANIFEST.json maps each key to the
+# fingerprint of oracle/*.py and of the leg's own source at the time it was written (comments, docstrings and formatting do not count: the hash is
+# taken over the AST).  A mismatch makes the entry STALE: the wrapper recomputes it live (and says so), `make_oracle_cache.py --list` reports it and
+# the CPU suite fails (tests/test_oracle_cache.py) -- an edit of the oracle can no longer leave the GPU suite comparing against yesterday's oracle.
+MANIFEST = CACHE_DIR / "MANIFEST.json"
+_fp_cache = {}
+
+
+def _ast_hash(src):
+    import ast
+    import hashlib
+    import textwrap
+    tree = ast.parse(textwrap.dedent(src))
+    for node in ast.walk(tree):                      # docstrings are not behaviour
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef, ast.Module, ast.AsyncFunctionDef)) and node.body and \
+                isinstance(node.body[0], ast.Expr) and isinstance(getattr(node.body[0], "value", None), ast.Constant) and isinstance(node.body[0].value.value, str):
+            node.body = node.body[1:] or [ast.Pass()]
+    return hashlib.sha256(ast.dump(tree, include_attributes=False).encode()).hexdigest()[:16]
+
+
+def oracle_fingerprint():
+    if "oracle" not in _fp_cache:
+        import hashlib
+        h = hashlib.sha256()
+        for f in sorted((ROOT / "oracle").glob("*.py")):
+            h.update(f.name.encode())
+            h.update(_ast_hash(f.read_text()).encode())
+        _fp_cache["oracle"] = h.hexdigest()[:16]
+    return _fp_cache["oracle"]
+
+
+def leg_fingerprint(fn):
+    """the leg's own source plus, one level deep, the helpers of its module it names (input builders, shared configuration constants)"""
+    import ast
+    import hashlib
+    import inspect
+    import textwrap
+    src = inspect.getsource(fn)
+    h = hashlib.sha256(_ast_hash(src).encode())
+    names = sorted({n.id for n in ast.walk(ast.parse(textwrap.dedent(src))) if isinstance(n, ast.Name)})
+    for nm in names:
+        obj = fn.__globals__.get(nm)
+        if inspect.isfunction(obj) and obj.__module__ == fn.__module__ and obj is not fn:
+            h.update(nm.encode())
+            h.update(_ast_hash(inspect.getsource(getattr(obj, "raw", obj))).encode())
+        elif isinstance(obj, (int, float, str, tuple, list, dict)) and nm.isupper():
+            h.update(f"{nm}={obj!r}".encode())
+    return h.hexdigest()[:16]
+
+
+def read_manifest():
+    return json.loads(MANIFEST.read_text()) if MANIFEST.exists() else {}
+
+
+def record(key, fn):
+    m = read_manifest()
+    m[key] = {"oracle": oracle_fingerprint(), "leg": leg_fingerprint(fn)}
+    MANIFEST.write_text(json.dumps(dict(sorted(m.items())), indent=1) + "\n")
+
+
+def stale_reason(key, fn):
+    """None if the committed result of `key` was computed from today's oracle/ and leg source (or predates the manifest: no entry), else what changed"""
+    e = read_manifest().get(key)
+    if e is None:
+        return None
+    if e["oracle"] != oracle_fingerprint():
+        return "oracle/*.py changed since the result was written"
+    if e["leg"] != leg_fingerprint(fn):
+        return "the leg's source changed since the result was written"
+    return None
+
+
 # ------------------------------------------------------------------------------------------------ the decorator
 def _argstr(a):
     if isinstance(a, torch.dtype):
@@ -135,15 +209,17 @@ def oracle_leg(cases=((),)):
                 return memo[key]
             path = CACHE_DIR / f"{key}.npz"
             m = mode()
-            if m != "live" and path.exists():
+            why = stale_reason(key, fn) if (m != "live" and path.exists()) else None
+            if m != "live" and path.exists() and why is None:
                 res = load(path)
             else:
                 if m == "cache":
-                    print(f"[oracle_cache] {key}: no committed result, running the oracle live", file=sys.stderr, flush=True)
+                    print(f"[oracle_cache] {key}: {'STALE (' + why + ')' if why else 'no committed result'}, running the oracle live", file=sys.stderr, flush=True)
                 with torch.no_grad():
                     res = fn(*args)
                 if m == "write":
                     save(path, res)
+                    record(key, fn)
                     res = load(path)                     # what the tests will see
             memo[key] = res
             return res

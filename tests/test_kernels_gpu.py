@@ -450,6 +450,39 @@ def test_conv3x3_patch_mode(capi, dtype, monkeypatch, b, h, wd, cin, cout, res):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,hw,n,k,res", [(16, 4096, 320, 320, True), (48, 1024, 640, 640, True), (192, 256, 1280, 1280, False)])
+def test_gemm_dual_n_groupnorm_statistics(capi, dtype, monkeypatch, b, hw, n, k, res):
+    """the dual-N kernel as a GroupNorm producer (proj_out of the transformer blocks: 1x1 conv + residual whose output feeds the next ResnetBlock's
+    GroupNorm): per-channel sum / sum of squares of the stored output per 64-row block, against a pass over the output and, bit for bit, the ring kernel"""
+    lib = capi.load()
+    dt = capi.dtype_code(dtype)
+    m = b * hw
+    a, w = rnd(m, k, seed=1, dtype=dtype), rnd(n, k, seed=2, scale=k ** -0.5, dtype=dtype)
+    bias = rnd(n, seed=3) + 0.3
+    r_ = rnd(m, n, seed=4, dtype=dtype) if res else None
+    outs, parts = [], []
+    for on in ("1", "0"):
+        monkeypatch.setenv("ETAINV_DUALN", on)
+        out = torch.full((m, n), float("nan"), dtype=dtype, device="cuda")
+        part = torch.full((m // 16 * 2 * n,), float("nan"), device="cuda")
+        wm = C.c_int(-1)
+        capi.check(lib.etainv_op_gemm_gnstat(capi.ptr(a), capi.ptr(w), capi.ptr(bias), capi.ptr(r_), capi.ptr(out), capi.ptr(part), C.byref(wm), m, n, k, hw,
+                                             dt, capi.stream_ptr()))
+        torch.cuda.synchronize()
+        assert wm.value == 64
+        outs.append(out)
+        parts.append(part[: m // 64 * 2 * n].clone())
+    ref = a.float() @ w.float().t() + bias + (r_.float() if res else 0)
+    assert relerr(outs[0], ref) < TOL[dtype]
+    assert torch.equal(outs[0], outs[1])
+    st = parts[0].view(m // 64, 2, n)
+    xf = outs[0].float().view(m // 64, 64, n)
+    torch.testing.assert_close(st[:, 0], xf.sum(1), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(st[:, 1], (xf * xf).sum(1), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(parts[0], parts[1], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("b,h,wd,cin,cout,res", [(16, 64, 64, 320, 320, True), (16, 64, 64, 960, 320, False), (64, 32, 32, 640, 640, True),
                                                  (256, 16, 16, 1280, 1280, False), (48, 16, 32, 640, 640, True), (7, 48, 48, 320, 640, True)])
 def test_conv3x3_ping_pong_patch(capi, dtype, monkeypatch, b, h, wd, cin, cout, res):

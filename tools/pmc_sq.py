@@ -14,12 +14,28 @@ Only dispatches of the LAST `--last-frac` of the run are counted when given (the
 """
 import collections
 import csv
+import functools
 import json
 import re
 import sys
 
 
+@functools.lru_cache(maxsize=None)
 def short(name):
+    """readable kernel instantiation: rocprofv3 reports mangled names for templates, and neither c++filt nor the ROCm image's tools know the bf16 / f16
+    manglings (DF16b / DF16_), so the template arguments of this library's kernels are decoded here"""
+    m = re.match(r"^_ZN6etainv(?:12_GLOBAL__N_1)?(\d+)", name)
+    if m:
+        n = int(m.group(1))
+        start = m.end()
+        ident, rest = name[start:start + n], name[start + n:]
+        args = []
+        if rest.startswith("I"):
+            for tok in re.finditer(r"DF16b|DF16_|f|Li(\d+)E|Lb([01])E", rest[1:rest.find("EEv") + 1 if "EEv" in rest else len(rest)]):
+                t = tok.group(0)
+                args.append("bf16" if t == "DF16b" else "f16" if t == "DF16_" else "float" if t == "f" else tok.group(1) if t.startswith("Li") else
+                            ("true" if tok.group(2) == "1" else "false"))
+        return ident + ("<" + ", ".join(args) + ">" if args else "")
     name = re.sub(r"^void ", "", name)
     name = name.replace("etainv::", "").replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*$", "", name)
@@ -65,7 +81,12 @@ def main():
         e["raw"] = {c: x for c, x in sorted(v.items())}
         out.append(e)
     out.sort(key=lambda e: -e.get("share_of_gpu_cycles", 0.0))
-    print(json.dumps({"kernels": out}, indent=1))
+    # the implicit-GEMM family (what bench.py's roofline line is about): matrix-pipe busy share weighted by GPU cycles
+    fam = [e for e in out if any(t in e["kernel"] for t in ("igemm_kernel", "pp_conv_kernel", "pp_dualn_kernel", "pp_gemm_kernel")) and "mfma_busy_frac" in e]
+    w = sum(e["share_of_gpu_cycles"] for e in fam)
+    summary = {"igemm_family": {"share_of_gpu_cycles": w, "mfma_busy_frac": sum(e["mfma_busy_frac"] * e["share_of_gpu_cycles"] for e in fam) / w if w else None,
+                                "kernels": len(fam)}}
+    print(json.dumps({"summary": summary, "kernels": out}, indent=1))
 
 
 if __name__ == "__main__":
