@@ -5,7 +5,7 @@
 # Jobs:
 #   sq                         SQ counter passes over one 128-row UNet call -> pmc_sq_rows128.json        (tools/pmc_sq.py)
 #   traffic                    FETCH_SIZE / WRITE_SIZE passes -> pmc_traffic_rows128.json, pmc_per_shape_rows128.json
-#   shapes [rows]              event-timed per-shape breakdown of one UNet call -> unet_shapes_rows<rows>.log, launches_rows<rows>.json
+#   shapes [rows] [L]          event-timed per-shape breakdown of one UNet call (L = latent side, default 64) -> unet_shapes_rows<rows>[_L<L>].log, launches_*.json
 #   ops [only]                 per-shape micro-benchmark (tools/bench_ops.py --rows 128)
 #   opsenv <only> <envB>       same-box A/B of the default library: plain vs with VAR=value[,VAR=value] (tools/ab_ops.py)
 #   opslib <only> <variant>    same-box A/B: libetainv_hip.so vs libetainv_hip_<variant>.so (built by csrc/build.sh VARIANT=...)
@@ -48,9 +48,10 @@ run_job() {
       rm -rf $OUT/pmc_fetch $OUT/pmc_write
       head -c 400 $OUT/pmc_traffic_rows128.json; echo ;;
     shapes)
-      local rows="${1:-128}"
-      python tools/unet_call.py --rows $rows --calls 2 --shapes --dump $OUT/launches_rows$rows.json > $OUT/unet_shapes_rows$rows.log 2>&1
-      grep -E "^==|total" $OUT/unet_shapes_rows$rows.log ;;
+      local rows="${1:-128}" L="${2:-64}" sfx=""
+      [ "$L" != "64" ] && sfx="_L$L"
+      python tools/unet_call.py --rows $rows --L $L --calls 2 --shapes --dump $OUT/launches_rows$rows$sfx.json > $OUT/unet_shapes_rows$rows$sfx.log 2>&1
+      grep -E "^==|total" $OUT/unet_shapes_rows$rows$sfx.log ;;
     ops)
       python tools/bench_ops.py --rows 128 ${1:+--only "$1"} > $OUT/ops_rows128${1:+_$1}.log 2>&1; cat $OUT/ops_rows128${1:+_$1}.log ;;
     opsenv)

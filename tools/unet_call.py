@@ -14,17 +14,18 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=128)
 ap.add_argument("--calls", type=int, default=2)
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--L", type=int, default=64, help="latent side (64 = 512^2 images, 96 = 768^2: BASELINE config 5)")
 ap.add_argument("--shapes", action="store_true", help="event-time every launch of the last call and print time per distinct work size")
 ap.add_argument("--dump", default=None, help="with --shapes: write the igemm launches of the last call in launch order (ms, FLOPs, algorithmic bytes) as JSON")
 a = ap.parse_args()
 dt = {"fp16": torch.float16, "bf16": torch.bfloat16}[a.dtype]
 B = a.rows // 4
-eng = Engine(dtype=dt, max_unet_batch=a.rows, latent_size=64, max_img=B)
+eng = Engine(dtype=dt, max_unet_batch=a.rows, latent_size=a.L, max_img=max(B, 1))
 eng.load_synthetic(0)
 g = torch.Generator().manual_seed(0)
-x = torch.randn(2 * B, 4, 64, 64, generator=g).cuda()
+x = torch.randn(max(2 * B, 1) if a.rows >= 4 else a.rows, 4, a.L, a.L, generator=g).cuda()
 ctx = torch.randn(a.rows, 77, 768, generator=g).cuda()
-out = torch.empty(a.rows, 4, 64, 64, device="cuda")
+out = torch.empty(a.rows, 4, a.L, a.L, device="cuda")
 lib = _capi.load()
 for i in range(a.calls):
     if a.shapes and i == a.calls - 1:
