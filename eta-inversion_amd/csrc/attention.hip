@@ -922,7 +922,7 @@ static int launch_self40(const void* qkv, void* out, int b, int n, int heads, in
   static const int stagger = getenv("ETAINV_A40_STAGGER") ? atoi(getenv("ETAINV_A40_STAGGER")) : 0;
   static const size_t lds_pad = getenv("ETAINV_A40_LDSPAD") ? (size_t)atoi(getenv("ETAINV_A40_LDSPAD")) : 0;   // experiment: fewer resident blocks
   const size_t lds = A40_LDS + lds_pad;
-  if (lds_pad) {
+  if (lds_pad || lds > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn40_kernel<T, D, true, QB, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn40_kernel<T, D, false, QB, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
@@ -959,6 +959,10 @@ int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int hea
   static const bool v2_80 = !env_on("ETAINV_ATT80_OLD");   // A/B: head_dim 80 on the 32x32x16 kernel (one 32-query block per wave)
   if (d == 80 && self_attn40_v2_enabled() && v2_80) {
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 80, 1, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s, first_row, head_major)));
+  }
+  static const bool v2_160 = env_flag("ETAINV_ATT160_V2", true);   // A/B: head_dim 160 (the (L/4)^2 level) on the 32x32x16 kernel too: one 32-query block per wave,
+  if (d == 160 && self_attn40_v2_enabled() && v2_160 && !head_major) {   // one block per CU (104 KB of K / V tiles, ~300 registers)
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 160, 1, 1>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s, first_row, head_major)));
   }
   // (the generic kernel takes pre-scaled queries with scale 1: ETAINV_ATT80_OLD sends head_dim 80 here while the engine still folds the scale into to_q)
   ETAINV_DISPATCH_HALF(dtype, T, switch (d) {

@@ -799,6 +799,30 @@ def test_self_attention_d80(capi, dtype, n, b, heads, gain):
     assert relerr(out, ref_self_attention(qkv, heads)) < TOL[dtype] * (2 if gain > 1 else 1)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,b,heads,gain,mode", [(256, 4, 8, 1.0, 0), (64, 2, 8, 1.0, 0), (144, 1, 4, 1.0, 0), (200, 3, 4, 3.0, 0), (1024, 1, 8, 0.05, 0),
+                                                 (256, 8, 8, 1.0, 1), (256, 8, 8, 1.0, 2)])
+def test_self_attention_d160(capi, dtype, n, b, heads, gain, mode):
+    """head_dim 160 (the (L/4)^2 level) on the same 32x32x16 kernel: six 32-row tiles of O^T, eleven K slices per score tile, one block per CU; ragged last
+    key tiles, the remap modes (n_img = 2), large and small score scales.  ETAINV_ATT160_V2=0 is the generic 16x16x32 kernel it replaces there."""
+    lib = capi.load()
+    d, n_img = 160, 2 if mode else 1
+    qkv = rnd(b, n, 3 * heads * d, seed=n + b + 2, dtype=dtype)
+    qkv[..., : 2 * heads * d] *= gain
+    out = torch.empty(b, n, heads * d, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_self_attention(capi.ptr(qkv), capi.ptr(out), b, n, heads, d, mode, n_img, capi.dtype_code(dtype), capi.stream_ptr()))
+    ident = torch.arange(b)
+    qm, km, vm = ident.clone(), ident.clone(), ident.clone()
+    for img in range(n_img if mode else 0):
+        u_s, u_t, c_s, c_t = img, n_img + img, 2 * n_img + img, 3 * n_img + img
+        if mode == 1:
+            qm[c_t], km[c_t] = c_s, c_s
+        else:
+            km[u_t], vm[u_t], km[c_t], vm[c_t] = u_s, u_s, c_s, c_s
+    assert torch.isfinite(out).all()
+    assert relerr(out, ref_self_attention(qkv, heads, qm, km, vm)) < TOL[dtype] * (2 if gain > 1 else 1)
+
+
 def test_self_attention_d40_maximum_jumps_late(capi):
     """A key whose score exceeds everything before it by far more than the deferral threshold, placed in a LATE tile, for a few queries
     only (the branch is wave-uniform, the update per query), plus a first tile whose scores are all very negative for other queries."""
