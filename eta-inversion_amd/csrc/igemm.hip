@@ -1454,6 +1454,14 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   ETAINV_CHECK(!p.ln_stat || (!p.out_f32 && !p.out_nchw), "folded LayerNorm: the consumer stores the compute dtype, row-major (the fp32 / NCHW epilogues do not apply mean / rstd)");
   ETAINV_CHECK(!p.hm_heads || igemm_hm_ok(p, dtype), "head-major QKV output: not available for this launch (ask igemm_hm_ok first)");
   if (p.hm_heads) p.hm_magic = (int)(((1ull << 38) + (unsigned)p.hm_tokens - 1) / (unsigned)p.hm_tokens);   // m0 / hm_tokens == (m0 * magic) >> 38 for m0 < 2^24, hm_tokens <= 2^14
+  static const bool trace = env_on("ETAINV_TRACE_IGEMM");   // one line per launch on stderr, in launch order (tools/unet_call.py --shapes joins it with the event times)
+  if (trace) {
+    const bool ring = !p.geglu && !p.ups && p.N % 160 == 0 && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 160) >= 192;
+    fprintf(stderr, "igemm M=%d N=%d c1=%d c2=%d taps=%d stride=%d ups=%d H=%d W=%d geglu=%d ln=%d stat=%d res=%d rowvec=%d hm=%d route=%s\n", p.M, p.N, p.c1, p.c2, p.taps,
+            p.stride, p.ups, p.H, p.W, (int)p.geglu, p.ln_stat ? 1 : 0, p.stat_out ? p.stat_kind : 0, p.residual ? 1 : 0, p.rowvec ? 1 : 0, p.hm_heads,
+            pp_conv_applicable(p, dtype) ? "ppconv" : pp_dualn_applicable(p, dtype) ? "dualn" : pp_gemm_applicable(p, dtype) ? "ppgemm" : xs_gemm_applicable(p, dtype) ? "xs" :
+            p.ups == 2 ? "ring-ups4" : ring ? "ring" : "other");
+  }
   if (pp_conv_applicable(p, dtype)) {    // ping-pong PATCH conv3x3 (ppconv.hip)
     ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(9 * p.c1), s, igemm_algo_bytes(p));
     return launch_pp_conv(p, dtype, s, stat_P);

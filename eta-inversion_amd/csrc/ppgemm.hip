@@ -475,7 +475,13 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
     n0 = (v - tm * tiles_n) * BN2;
   };
   const int total_steps = my_tiles * nk;
-  const bool no_dma = p.debug & 1, no_epi = p.debug & 2;
+  const bool no_dma = p.debug & 1, no_epi = p.debug & 2, no_store = p.debug & 8, no_gelu = p.debug & 16;   // (timing-only ablations, tools/pp_check.py ablate)
+  const bool fake_store = p.debug & 64;
+  const bool defer = !(p.debug & 32) && !no_store;  // (bit 32, ETAINV_DUALN_DEFER=0: every phase 3 waits with vmcnt(0), the form before the deferred store wait)
+  // output stores one wave issues per epilogue, counted from below (16-byte stores cannot be merged further; statistics stores and residual loads come on
+  // top and only make the wait stricter): per 16-row group and half, GEGLU one 16-byte store, the 160-column halves two 16-byte stores and one of 8 bytes
+  constexpr int EPI_STORES = PMT * 2 * (EPI == 3 ? 1 : 3);
+  static_assert(EPI_STORES <= 48, "vmcnt is a 6-bit counter");
   const bool has_bias = p.bias != nullptr;
 
   // ---- issue side: two cursors (the activation pieces of a K tile go out four phases before its weight pieces)
@@ -584,7 +590,17 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
   // >= hm_d of the span belong to the next head, whose plane starts hm_skip elements further on
   auto store_blocks = [&](T* prow, auto& po, auto nb_tag, int hm_d, int hm_skip) __attribute__((always_inline)) {
     constexpr int NB = decltype(nb_tag)::value;
+    if (no_store) return;
     auto at = [&](int col) __attribute__((always_inline)) { return prow + col + (col >= hm_d ? hm_skip : 0); };
+    if (fake_store) {   // timing only (debug bit 64): the same number of 16-byte stores, each instruction one contiguous KB inside the tile's output rows
+#pragma unroll
+      for (int k = 0; k + 1 < NB; k += 2) {
+        const u32x4 v = {po[k][0], po[k][1], po[k + 1][0], po[k + 1][1]};
+        *reinterpret_cast<u32x4*>(prow + (k >> 1) * 512) = v;
+      }
+      if constexpr (NB & 1) *reinterpret_cast<u32x2*>(prow + (NB >> 1) * 512) = po[NB - 1];
+      return;
+    }
 #pragma unroll
     for (int k = 0; k + 1 < NB; k += 2) {
       const auto lo = __builtin_amdgcn_permlane16_swap(po[k][0], po[k + 1][0], false, false);
@@ -619,7 +635,8 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
           g = (g - st[0] * *reinterpret_cast<const f32x4*>(ts + j * 16 + WN / 2)) * st[1];
           a += *reinterpret_cast<const f32x4*>(tb + j * 16);
           g += *reinterpret_cast<const f32x4*>(tb + j * 16 + WN / 2);
-          const gelu_f32x2 g01 = gelu_pair((gelu_f32x2){g[0], g[1]}), g23 = gelu_pair((gelu_f32x2){g[2], g[3]});
+          gelu_f32x2 g01 = {g[0], g[1]}, g23 = {g[2], g[3]};
+          if (!no_gelu) { g01 = gelu_pair(g01); g23 = gelu_pair(g23); }
           T o[4] = {from_f32<T>(a[0] * g01[0]), from_f32<T>(a[1] * g01[1]), from_f32<T>(a[2] * g23[0]), from_f32<T>(a[3] * g23[1])};
           po[j] = *reinterpret_cast<u32x2*>(o);
         }
@@ -743,7 +760,9 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
           T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
           po[j] = *reinterpret_cast<u32x2*>(o);
         }
-        if constexpr (EPI == 2)
+        if (fake_store)
+          store_blocks(out + (int64_t)m0 * N + wid * 10240 + (NH * PMT + i) * 1536 + lane * 8, po, std::integral_constant<int, NT>{}, 1 << 30, 0);
+        else if constexpr (EPI == 2)
           store_blocks(plane + (int64_t)(mrow + i * 16 - hm_tok0) * p.hm_dim, po, std::integral_constant<int, NT>{}, p.hm_dim, (p.hm_tokens - 1) * p.hm_dim);
         else
           store_blocks(out + lane_off + (int64_t)i * 16 * N, po, std::integral_constant<int, NT>{}, 1 << 30, 0);
@@ -803,12 +822,25 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
   for (int s = 0; s < total_steps; ++s) {
     const int slot = s & 1;
     const bool next = s + 1 < total_steps;          // a K tile s + 1 exists: its weight pieces go out in phases 0 .. 2 of this K tile
+    // The stores of an epilogue count in vmcnt with the DMA pieces, in issue order (no separate store counter on CDNA): a vmcnt(0) behind them waits for
+    // the whole tile's write-back (timing ablation on MI355X, 256 x 320 tile at K = 320: 16.7 of 38.2 kcycles per tile, the HBM write rate of the whole chip
+    // bursting at once while the matrix pipes idle).  So the weight pieces of this tile's K tile 1 go out IN FRONT of the epilogue (their LDS rows were
+    // last read in phase 3 of the K tile before, two barriers ago for either wave group), phases 0 .. 2 issue nothing, and phase 3 waits with
+    // vmcnt(EPI_STORES): everything older than the stores -- both K tile 1 operands -- has landed, the stores drain under K tiles 0 and 1.
+    // (nk >= 3: with two K tiles the weight cursor would enter tile t + 2 here and overwrite the bias / s / statistics ring entry this epilogue reads.)
+    bool early = false;
     if (s > 0 && ct_kt == 0 && !no_epi) {           // the previous K tile finished an output tile: both halves, in front of this tile's first cluster
+      if (defer && next && nk >= 3) {
+        issue_b(I0{}, std::integral_constant<int, PASSES>{});
+        early = true;
+        __builtin_amdgcn_sched_barrier(0);
+      }
       epilogue_half(I0{}, ct_tile - 1);
       epilogue_half(I1{}, ct_tile - 1);
     }
+    const bool issue_w = next && !early;
     // ---- phase 0: (kk 0, half 0)
-    if (next) issue_b(I0{}, std::integral_constant<int, QA>{});
+    if (issue_w) issue_b(I0{}, std::integral_constant<int, QA>{});
     read_a(slot, I0{});
     read_b(slot, I0{}, I0{});
     PP_LGKMCNT0();
@@ -817,7 +849,7 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
     cluster(I0{});
     __builtin_amdgcn_s_barrier();
     // ---- phase 1: (kk 0, half 1)
-    if (next) issue_b(std::integral_constant<int, QA>{}, std::integral_constant<int, QB>{});
+    if (issue_w) issue_b(std::integral_constant<int, QA>{}, std::integral_constant<int, QB>{});
     read_b(slot, I0{}, I1{});
     PP_LGKMCNT0();
     __builtin_amdgcn_sched_barrier(0);
@@ -825,7 +857,7 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
     cluster(I1{});
     __builtin_amdgcn_s_barrier();
     // ---- phase 2: (kk 1, half 0)
-    if (next) issue_b(std::integral_constant<int, QB>{}, std::integral_constant<int, PASSES>{});
+    if (issue_w) issue_b(std::integral_constant<int, QB>{}, std::integral_constant<int, PASSES>{});
     read_a(slot, I1{});
     read_b(slot, I1{}, I0{});
     PP_LGKMCNT0();
@@ -834,7 +866,7 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
     cluster(I0{});
     __builtin_amdgcn_s_barrier();
     // ---- phase 3: (kk 1, half 1): K tile s + 1 has landed (for this wave); the activation pieces of K tile s + 2 go into the rows just read
-    PP_VMCNT(0);
+    if (early) { PP_VMCNT(EPI_STORES); } else { PP_VMCNT(0); }
     if (s + 2 < total_steps) issue_a();
     read_b(slot, I1{}, I1{});
     PP_LGKMCNT0();
@@ -912,10 +944,12 @@ int launch_pp_dualn(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat
   IGemmParams p = p_in;
   const int kind = dualn_kind(p, dtype);
   ETAINV_CHECK(kind >= 0, "not a dual-N launch (ask pp_dualn_applicable first)");
+  if (!env_flag("ETAINV_DUALN_DEFER", true)) p.debug |= 32;
   if (p.stat_out) p.stat_P = p.stat_kind == 1 ? 64 : p.N / 80;   // GroupNorm: rows per partial block; LayerNorm: partials per row
   if (stat_P) *stat_P = p.stat_out ? p.stat_P : 0;
   const int tiles = (p.M / PBM) * (p.N / (kind == 3 ? 256 : 320));
-  const int grid = std::min(tiles, 256);
+  static const int grid_cap = getenv("ETAINV_DUALN_GRID") ? atoi(getenv("ETAINV_DUALN_GRID")) : 256;   // (experiments: fewer persistent blocks than CUs)
+  const int grid = std::min(tiles, grid_cap);
   ETAINV_DISPATCH_HALF(dtype, T, {
     if (kind == 3) launch_dualn_t<T, 128, 3, false, 0>(p, grid, s);
     else if (kind == 2) launch_dualn_t<T, 160, 2, false, 0>(p, grid, s);

@@ -121,12 +121,21 @@ def test_s50_b32_batch_invariance(kind):
     dt = {"fp16": torch.float16, "bf16": torch.bfloat16}[kind]
     small = native_run(dt, S, L, 2)[0]
     big = native_run(dt, S, L, 2, batch=32)[0]
+    from tests.parity_s50 import compare
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
     floor = ref["floors"][kind]["final_edit_rel_l2"]
     e_small, e_big = rel(small["out"][1], ref["out"][1]), rel(big["out"][1], ref["out"][1])
-    agree = int((big["best"] == ref["best"]).sum())
+    cmp_big = compare(big, ref)
+    flips = cmp_big["best_of_n_flips"]
     print(f"{kind}: S = 50 edited latent vs the fp32 oracle: B = 2 run {e_small:.2e}, image 0 of the B = 32 run {e_big:.2e} (floor {floor:.2e}); "
-          f"best-of-n {agree}/{S}; source row {rel(big['out'][0], ref['out'][0]):.2e}")
-    assert agree == S
-    assert e_big <= 1.5 * floor and e_big <= 1.5 * e_small
+          f"best-of-n {cmp_big['best_of_n_agree']}/{S} {flips}; source row {rel(big['out'][0], ref['out'][0]):.2e}")
+    # The B = 2 and B = 32 calls run on different kernels (tile forms chosen by the launch's size: not bit-identical), so a best-of-n choice may differ from
+    # the oracle's -- but, as in tests/test_realsize_gpu.py, only where the oracle's own two candidates nearly tie (relative loss gap below the rounding
+    # of the compute dtype); up to the first such fork the trajectory must stay inside the floor, and without a fork so must the result
+    assert all(f["oracle_rel_loss_gap"] < (2e-2 if kind == "bf16" else 2e-3) for f in flips), flips
+    first_fork = min([f["bwd_step"] for f in flips], default=S + 1)
+    before = [r for r in cmp_big["per_step"] if r["step"] < first_fork]
+    assert before and all(r["edit_rel_l2"] <= 1.5 * floor for r in before), [(r["step"], r["edit_rel_l2"]) for r in before]
+    if not flips:
+        assert e_big <= 1.5 * floor and e_big <= 1.5 * e_small
     assert rel(big["out"][0], ref["out"][0]) <= 1e-5

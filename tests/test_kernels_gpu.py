@@ -487,8 +487,11 @@ def test_gemm_dual_n_groupnorm_statistics(capi, dtype, monkeypatch, b, hw, n, k,
                                                  (256, 16, 16, 1280, 1280, False), (48, 16, 32, 640, 640, True), (7, 48, 48, 320, 640, True)])
 def test_conv3x3_ping_pong_patch(capi, dtype, monkeypatch, b, h, wd, cin, cout, res):
     """ppconv.hip (default for conv3x3 stride 1 on 16-pixel-aligned images): the PATCH-mode K loop with the wave groups in anti-phase and a lean issue side.
-    Against F.conv2d, bit for bit against igemm.hip's PATCH ring (same accumulation order), and the GroupNorm partials of the stored output (per channel
-    sum / sum of squares over every 64-row block) against a pass over the output; image borders, several tiles per block, an odd tile count, non-square"""
+    Three kernels on the same input: the dual-M form (two 16 x 16 patches per tile, 32-channel chunks; default where the patch count is even and the last
+    round of tiles is full enough), the 256-pixel form (ETAINV_PPCONV2=0) and igemm.hip's PATCH ring (ETAINV_PPCONV=0).  Against F.conv2d; the 256-pixel
+    form bit for bit against the ring (same accumulation order), the dual-M form within a rounding of it (K order (32-channel chunk, tap)); the GroupNorm
+    partials of the stored output (per channel sum / sum of squares over every 64-row block) against a pass over that output; image borders, several
+    tiles per block, an odd tile count, non-square"""
     lib = capi.load()
     dt = capi.dtype_code(dtype)
     x = rnd(b, cin, h, wd, seed=1, dtype=dtype)
@@ -500,8 +503,9 @@ def test_conv3x3_ping_pong_patch(capi, dtype, monkeypatch, b, h, wd, cin, cout, 
         ref = ref + r.float().permute(0, 3, 1, 2)
     x_nhwc, wk = x.permute(0, 2, 3, 1).contiguous(), w.permute(0, 2, 3, 1).contiguous()
     outs, parts, wms = [], [], []
-    for on in ("1", "0"):
-        monkeypatch.setenv("ETAINV_PPCONV", on)
+    for pp, pp2 in (("1", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("ETAINV_PPCONV", pp)
+        monkeypatch.setenv("ETAINV_PPCONV2", pp2)
         out = torch.full((b, h, wd, cout), float("nan"), dtype=dtype, device="cuda")
         part = torch.full((b * h * wd // 16 * 2 * cout,), float("nan"), device="cuda")
         wm = C.c_int(-1)
@@ -515,18 +519,25 @@ def test_conv3x3_ping_pong_patch(capi, dtype, monkeypatch, b, h, wd, cin, cout, 
         capi.check(lib.etainv_op_conv3x3(capi.ptr(x_nhwc), None, cin, 0, capi.ptr(wk), capi.ptr(bias), capi.ptr(rowvec), capi.ptr(r), capi.ptr(out2), b, h, wd, cout,
                                          1, 0, 9, dt, capi.stream_ptr()))
         assert torch.equal(out, out2)
-    assert relerr(outs[0].permute(0, 3, 1, 2), ref) < TOL[dtype]
-    d = (outs[0].float() - ref.permute(0, 2, 3, 1)).reshape(b * h, -1).norm(dim=1) / ref.permute(0, 2, 3, 1).reshape(b * h, -1).norm(dim=1)
-    assert float(d.max()) < 3 * TOL[dtype]                 # per image row: a misplaced patch row hides in a global norm
-    assert torch.equal(outs[0], outs[1]), "ping-pong and ring PATCH kernels accumulate in the same order"
-    assert wms[0] == wms[1] == 64
-    # partials: blocks of 64 VIRTUAL rows (patches of 16 x 16 pixels enumerated image-major, 4 patch rows per block) -> compare per image
     n_blk = b * h * wd // 64
-    st = parts[0][: n_blk * 2 * cout].view(b, h * wd // 64, 2, cout).sum(1)
-    xf = outs[0].float().reshape(b, h * wd, cout)
-    torch.testing.assert_close(st[:, 0], xf.sum(1), rtol=1e-4, atol=1e-2)
-    torch.testing.assert_close(st[:, 1], (xf * xf).sum(1), rtol=1e-4, atol=1e-2)
-    torch.testing.assert_close(parts[0][: n_blk * 2 * cout], parts[1][: n_blk * 2 * cout], rtol=1e-6, atol=1e-6)
+    for o, pt in zip(outs[:2], parts[:2]):
+        assert relerr(o.permute(0, 3, 1, 2), ref) < TOL[dtype]
+        d = (o.float() - ref.permute(0, 2, 3, 1)).reshape(b * h, -1).norm(dim=1) / ref.permute(0, 2, 3, 1).reshape(b * h, -1).norm(dim=1)
+        assert float(d.max()) < 3 * TOL[dtype]             # per image row: a misplaced patch row hides in a global norm
+        # partials: blocks of 64 VIRTUAL rows (patches of 16 x 16 pixels enumerated image-major, 4 patch rows per block) -> compare per image
+        st = pt[: n_blk * 2 * cout].view(b, h * wd // 64, 2, cout).sum(1)
+        xf = o.float().reshape(b, h * wd, cout)
+        torch.testing.assert_close(st[:, 0], xf.sum(1), rtol=1e-4, atol=1e-2)
+        torch.testing.assert_close(st[:, 1], (xf * xf).sum(1), rtol=1e-4, atol=1e-2)
+    assert torch.equal(outs[1], outs[2]), "the 256-pixel ping-pong kernel and the ring PATCH kernel accumulate in the same order"
+    torch.testing.assert_close(parts[1][: n_blk * 2 * cout], parts[2][: n_blk * 2 * cout], rtol=1e-6, atol=1e-6)
+    assert wms[0] == wms[1] == wms[2] == 64
+    # dual-M vs the ring: the same products summed in another order -- a rounding of the stored type at most, in a small share of the elements
+    differ = outs[0] != outs[2]
+    assert float(differ.float().mean()) < 0.12
+    assert relerr(outs[0], outs[2]) < 0.25 * TOL[dtype]
+    one_ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
+    assert float(((outs[0].float() - outs[2].float()).abs() / outs[2].float().abs().clamp_min(0.25)).max()) <= 1.01 * one_ulp
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

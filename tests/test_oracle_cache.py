@@ -29,7 +29,10 @@ def _compare(live, cached, tol):
         if isinstance(x, torch.Tensor):
             assert x.shape == y.shape and x.dtype == y.dtype, k
             if x.is_floating_point():
-                err = float((x.double() - y.double()).norm() / y.double().norm().clamp_min(1e-30))
+                # (NaN entries -- the unused slots of the optimiser legs' loss tables -- must sit at the same places; the norm runs over the rest)
+                assert torch.equal(torch.isnan(x), torch.isnan(y)), f"{k}: NaN pattern differs"
+                x, y = torch.nan_to_num(x.double(), nan=0.0), torch.nan_to_num(y.double(), nan=0.0)
+                err = float((x - y).norm() / y.norm().clamp_min(1e-30))
                 assert err <= tol, f"{k}: live oracle and committed result differ by {err:.2e}"
             else:
                 assert torch.equal(x, y), k

@@ -6,6 +6,7 @@
 #   sq                         SQ counter passes over one 128-row UNet call -> pmc_sq_rows128.json        (tools/pmc_sq.py)
 #   traffic                    FETCH_SIZE / WRITE_SIZE passes -> pmc_traffic_rows128.json, pmc_per_shape_rows128.json
 #   shapes [rows] [L]          event-timed per-shape breakdown of one UNet call (L = latent side, default 64) -> unet_shapes_rows<rows>[_L<L>].log, launches_*.json
+#   routes [rows]              per-(shape, kernel family) table of one UNet call: launch trace joined with event times -> launch_table_rows<rows>.log
 #   ops [only]                 per-shape micro-benchmark (tools/bench_ops.py --rows 128)
 #   opsenv <only> <envB>       same-box A/B of the default library: plain vs with VAR=value[,VAR=value] (tools/ab_ops.py)
 #   opslib <only> <variant>    same-box A/B: libetainv_hip.so vs libetainv_hip_<variant>.so (built by csrc/build.sh VARIANT=...)
@@ -52,6 +53,11 @@ run_job() {
       [ "$L" != "64" ] && sfx="_L$L"
       python tools/unet_call.py --rows $rows --L $L --calls 2 --shapes --dump $OUT/launches_rows$rows$sfx.json > $OUT/unet_shapes_rows$rows$sfx.log 2>&1
       grep -E "^==|total" $OUT/unet_shapes_rows$rows$sfx.log ;;
+    routes)
+      local rows="${1:-128}"
+      ETAINV_TRACE_IGEMM=1 python tools/unet_call.py --rows $rows --calls 2 --shapes --dump $OUT/launches_routes_rows$rows.json > $OUT/routes_shapes.log 2> $OUT/routes_trace.txt
+      python tools/launch_table.py $OUT/launches_routes_rows$rows.json $OUT/routes_trace.txt > $OUT/launch_table_rows$rows.log 2>&1; rm -f $OUT/routes_trace.txt
+      cat $OUT/launch_table_rows$rows.log ;;
     ops)
       python tools/bench_ops.py --rows 128 ${1:+--only "$1"} > $OUT/ops_rows128${1:+_$1}.log 2>&1; cat $OUT/ops_rows128${1:+_$1}.log ;;
     opsenv)

@@ -99,4 +99,39 @@ if "ln" in sys.argv:
         fl = 2.0 * m * n_out * c
         print(f"LN consumer M={m} C={c} N={n_out} geglu={geglu}: ring {ms['0']:.3f} ms {fl / ms['0'] / 1e9:7.1f} TF | dual-N {ms['1']:.3f} ms {fl / ms['1'] / 1e9:7.1f} TF | "
               f"ratio {ms['1'] / ms['0']:.3f} | elements that differ {ndiff} of {out.numel()} (max abs {maxd:.2e}) | rel err vs fp32 {err:.2e}", flush=True)
+if "ablate" in sys.argv:
+    # timing-only ablations of the dual-N LayerNorm consumers (ETAINV_IGEMM_DEBUG: 1 = no DMA in the loop, 2 = no epilogue): what the epilogue costs per tile
+    os.environ[SWITCH] = "1"
+    for m, c, n_out, geglu in ((524288, 320, 2560, 1), (131072, 640, 5120, 1), (32768, 1280, 10240, 1), (524288, 320, 960, 0), (524288, 320, 320, 0)):
+        x = (torch.randn(m, c, device="cuda", generator=g) * 0.5 + 0.3).to(dt)
+        wp = (torch.randn(n_out, c, device="cuda", generator=g) * c ** -0.5).to(dt)
+        s_vec, c_vec = torch.randn(n_out, device="cuda", generator=g), torch.randn(n_out, device="cuda", generator=g)
+        stat = torch.empty(m, 2, device="cuda")
+        _capi.check(lib.etainv_op_row_stats(_capi.ptr(x), _capi.ptr(stat), m, c, 1e-5, code, st))
+        out = torch.empty(m, n_out // 2 if geglu else n_out, dtype=dt, device="cuda")
+        fn = lambda: _capi.check(lib.etainv_op_gemm_ln(_capi.ptr(x), _capi.ptr(wp), _capi.ptr(c_vec), _capi.ptr(s_vec), _capi.ptr(stat), None, _capi.ptr(out), None, None,
+                                                        m, n_out, c, geglu, code, st))
+        tiles = (m // 256) * (n_out // (256 if geglu else 320)) / float(os.environ.get("ETAINV_DUALN_GRID", "256"))
+        for dbg, name in ((0, "full"), (2, "no epilogue"), (1, "no DMA"), (3, "no DMA, no epilogue"), (8, "no stores"), (16, "no GELU"), (24, "no stores, no GELU"), (64, "contiguous-KB stores"), (32, "vmcnt(0) everywhere")):
+            os.environ["ETAINV_IGEMM_DEBUG"] = str(dbg)
+            ms = min(timeit(fn) for _ in range(3))
+            print(f"M={m} C={c} N={n_out} geglu={geglu} {name:22s} {ms:7.3f} ms = {ms * 1e-3 / tiles * 2.1e9:8.0f} cycles per tile at 2.1 GHz ({tiles:.0f} tiles per CU)", flush=True)
+        os.environ["ETAINV_IGEMM_DEBUG"] = "0"
+if "convablate" in sys.argv:
+    # timing-only ablations of the ping-pong PATCH conv (an ablation build of ppconv.hip: see the note at its debug bits; ETAINV_LIB points at it)
+    for rows, side, cin, cout in ((128, 64, 320, 320), (128, 32, 640, 640), (128, 32, 1280, 640), (128, 16, 1280, 1280)):
+        x = (torch.randn(rows, side, side, cin, device="cuda", generator=g) * 0.5).to(dt)
+        w = (torch.randn(cout, 9, cin, device="cuda", generator=g) * (9 * cin) ** -0.5).to(dt)
+        bias = torch.randn(cout, device="cuda", generator=g)
+        out = torch.empty(rows, side, side, cout, dtype=dt, device="cuda")
+        fn = lambda: _capi.check(lib.etainv_op_conv3x3(_capi.ptr(x), None, cin, 0, _capi.ptr(w), _capi.ptr(bias), None, None, _capi.ptr(out),
+                                                        rows, side, side, cout, 1, 0, 9, code, st))
+        steps = (rows * side * side // 256) * (cout // 160) * (9 * cin // 64) / 256.0    # 256 x 160 x 64 K steps per CU (the dual-M kernel: two of its steps)
+        for dbg, name in ((0, "full"), (2, "no epilogue"), (1 | 2, "no DMA, no epilogue"), (4 | 2, "no MFMA, no epilogue"), (8 | 2, "no fragment reads, no epilogue"),
+                          (1 | 8 | 2, "MFMA + barriers only"), (4 | 8 | 2, "DMA + barriers only"), (1 | 4 | 2, "reads + barriers only")):
+            os.environ["ETAINV_IGEMM_DEBUG"] = str(dbg)
+            ms = min(timeit(fn) for _ in range(3))
+            print(f"conv {cin}->{cout} @{side} x{rows} {name:32s} {ms:7.3f} ms = {ms * 1e-3 / steps * 2.1e9:6.0f} cycles per K step at 2.1 GHz "
+                  f"(1280 MFMA cycles; {2.0 * rows * side * side * cout * 9 * cin / ms / 1e9:7.1f} TF-equivalent)", flush=True)
+        os.environ["ETAINV_IGEMM_DEBUG"] = "0"
 print("MISMATCHES:", bad)
