@@ -436,7 +436,7 @@ def main():
                                                f"{6 * S_STEPS * F_UNET_TFLOP:.1f}",
                        "sharding": f"batch-shard x{world}, final all_gather of latents"},
             "end_to_end_mfma_frac": value / world * exec_tflop_per_image / MFMA_PEAK_TFLOPS,
-            "roofline": {"bound": "mfma", "kernel": "implicit-GEMM family: pp_conv_kernel (conv3x3, PATCH ping-pong), pp_dualn_kernel (1x1 / Linear / GEGLU, dual-N "
+            "roofline": {"bound": "mfma", "kernel": "implicit-GEMM family: pp_conv2_kernel / pp_conv_kernel (conv3x3, PATCH ping-pong, dual-M / 256-pixel tiles), pp_dualn_kernel (1x1 / Linear / GEGLU, dual-N "
                                                     "ping-pong), igemm_kernel (strided / upsampling / small launches)", "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_busy_src,

@@ -477,11 +477,6 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
   const int total_steps = my_tiles * nk;
   const bool no_dma = p.debug & 1, no_epi = p.debug & 2, no_store = p.debug & 8, no_gelu = p.debug & 16;   // (timing-only ablations, tools/pp_check.py ablate)
   const bool fake_store = p.debug & 64;
-  const bool defer = !(p.debug & 32) && !no_store;  // (bit 32, ETAINV_DUALN_DEFER=0: every phase 3 waits with vmcnt(0), the form before the deferred store wait)
-  // output stores one wave issues per epilogue, counted from below (16-byte stores cannot be merged further; statistics stores and residual loads come on
-  // top and only make the wait stricter): per 16-row group and half, GEGLU one 16-byte store, the 160-column halves two 16-byte stores and one of 8 bytes
-  constexpr int EPI_STORES = PMT * 2 * (EPI == 3 ? 1 : 3);
-  static_assert(EPI_STORES <= 48, "vmcnt is a 6-bit counter");
   const bool has_bias = p.bias != nullptr;
 
   // ---- issue side: two cursors (the activation pieces of a K tile go out four phases before its weight pieces)
@@ -822,23 +817,16 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
   for (int s = 0; s < total_steps; ++s) {
     const int slot = s & 1;
     const bool next = s + 1 < total_steps;          // a K tile s + 1 exists: its weight pieces go out in phases 0 .. 2 of this K tile
-    // The stores of an epilogue count in vmcnt with the DMA pieces, in issue order (no separate store counter on CDNA): a vmcnt(0) behind them waits for
-    // the whole tile's write-back (timing ablation on MI355X, 256 x 320 tile at K = 320: 16.7 of 38.2 kcycles per tile, the HBM write rate of the whole chip
-    // bursting at once while the matrix pipes idle).  So the weight pieces of this tile's K tile 1 go out IN FRONT of the epilogue (their LDS rows were
-    // last read in phase 3 of the K tile before, two barriers ago for either wave group), phases 0 .. 2 issue nothing, and phase 3 waits with
-    // vmcnt(EPI_STORES): everything older than the stores -- both K tile 1 operands -- has landed, the stores drain under K tiles 0 and 1.
-    // (nk >= 3: with two K tiles the weight cursor would enter tile t + 2 here and overwrite the bias / s / statistics ring entry this epilogue reads.)
-    bool early = false;
+    // (Tried and removed, round 5: waiting LATER for an epilogue's stores -- the next K tile's weight pieces issued in front of the epilogue and phase 3
+    // waiting with vmcnt(<stores>) instead of vmcnt(0) -- and, for GEGLU, holding the converted outputs in registers and storing them two per K tile
+    // under the next tile's main loop.  Both bit-identical, both +-0 %: the waves are held at the ISSUE of the stores and the store path is in order
+    // with the DMA pieces either way; profiles/r05_dualn_store_ablation.log.)
     if (s > 0 && ct_kt == 0 && !no_epi) {           // the previous K tile finished an output tile: both halves, in front of this tile's first cluster
-      if (defer && next && nk >= 3) {
-        issue_b(I0{}, std::integral_constant<int, PASSES>{});
-        early = true;
-        __builtin_amdgcn_sched_barrier(0);
-      }
       epilogue_half(I0{}, ct_tile - 1);
       epilogue_half(I1{}, ct_tile - 1);
     }
-    const bool issue_w = next && !early;
+    const bool issue_w = next;
+    // (Order inside a MEM phase -- DMA issue first or fragment reads first -- measured both ways on MI355X: +-2-4 % per shape, +-0 on the benchmark.)
     // ---- phase 0: (kk 0, half 0)
     if (issue_w) issue_b(I0{}, std::integral_constant<int, QA>{});
     read_a(slot, I0{});
@@ -866,7 +854,7 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
     cluster(I0{});
     __builtin_amdgcn_s_barrier();
     // ---- phase 3: (kk 1, half 1): K tile s + 1 has landed (for this wave); the activation pieces of K tile s + 2 go into the rows just read
-    if (early) { PP_VMCNT(EPI_STORES); } else { PP_VMCNT(0); }
+    PP_VMCNT(0);
     if (s + 2 < total_steps) issue_a();
     read_b(slot, I1{}, I1{});
     PP_LGKMCNT0();
@@ -944,7 +932,6 @@ int launch_pp_dualn(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat
   IGemmParams p = p_in;
   const int kind = dualn_kind(p, dtype);
   ETAINV_CHECK(kind >= 0, "not a dual-N launch (ask pp_dualn_applicable first)");
-  if (!env_flag("ETAINV_DUALN_DEFER", true)) p.debug |= 32;
   if (p.stat_out) p.stat_P = p.stat_kind == 1 ? 64 : p.N / 80;   // GroupNorm: rows per partial block; LayerNorm: partials per row
   if (stat_P) *stat_P = p.stat_out ? p.stat_P : 0;
   const int tiles = (p.M / PBM) * (p.N / (kind == 3 ? 256 : 320));

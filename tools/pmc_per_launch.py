@@ -15,7 +15,7 @@ import sys
 
 
 def igemm_dispatches(path, counter):
-    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and any(t in r["Kernel_Name"] for t in ("igemm_kernel", "pp_conv_kernel", "pp_dualn_kernel", "pp_gemm_kernel"))]
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and any(t in r["Kernel_Name"] for t in ("igemm_kernel", "pp_conv_kernel", "pp_conv2_kernel", "pp_dualn_kernel", "pp_gemm_kernel"))]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return [float(r["Counter_Value"]) for r in rows]
 

@@ -82,7 +82,7 @@ def main():
         out.append(e)
     out.sort(key=lambda e: -e.get("share_of_gpu_cycles", 0.0))
     # the implicit-GEMM family (what bench.py's roofline line is about): matrix-pipe busy share weighted by GPU cycles
-    fam = [e for e in out if any(t in e["kernel"] for t in ("igemm_kernel", "pp_conv_kernel", "pp_dualn_kernel", "pp_gemm_kernel")) and "mfma_busy_frac" in e]
+    fam = [e for e in out if any(t in e["kernel"] for t in ("igemm_kernel", "pp_conv_kernel", "pp_conv2_kernel", "pp_dualn_kernel", "pp_gemm_kernel")) and "mfma_busy_frac" in e]
     w = sum(e["share_of_gpu_cycles"] for e in fam)
     summary = {"igemm_family": {"share_of_gpu_cycles": w, "mfma_busy_frac": sum(e["mfma_busy_frac"] * e["share_of_gpu_cycles"] for e in fam) / w if w else None,
                                 "kernels": len(fam)}}

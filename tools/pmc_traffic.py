@@ -11,7 +11,7 @@ calls = collections.defaultdict(lambda: collections.defaultdict(int))
 for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
-        cls = "igemm" if any(t in k for t in ("igemm_kernel", "pp_conv_kernel", "pp_dualn_kernel", "pp_gemm_kernel")) else "self_attn" if "self_attn" in k else "cross_attn" if "cross_attn" in k else \
+        cls = "igemm" if any(t in k for t in ("igemm_kernel", "pp_conv_kernel", "pp_conv2_kernel", "pp_dualn_kernel", "pp_gemm_kernel")) else "self_attn" if "self_attn" in k else "cross_attn" if "cross_attn" in k else \
               "groupnorm" if "gn_" in k else "layernorm" if ("layernorm" in k or "ln_finalize" in k or "row_stats" in k) else "other"
         agg[cls][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[cls][r["Counter_Name"]] += 1
