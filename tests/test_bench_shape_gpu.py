@@ -112,6 +112,48 @@ def test_backward_layouts_b32_vs_single_image_calls(big_engines, name, skip_us, 
     assert worst < 3e-3                                                      # two fp16 executions of the same arithmetic on different tilings
 
 
+def test_config5_rows_b8_masactrl_vs_single_image_calls():
+    """BASELINE config 5 at its real batch (etainv + masactrl, 768^2: L = 96, B = 8 -> 32 UNet rows [u_s, u_t, c_s, c_t] x 8; the engine takes the row-skipping
+    layouts with prompt-to-prompt only, and config 5 has eta > 0 at every step anyway), MasaCtrl active from block 10 on, per-image inputs: every probed image
+    against the B = 1 call of the same image.  At these
+    sizes the call runs the dual-M conv at 96^2 and 48^2 (an odd number of patches per image row: tile pairs straddle patch rows and images), the ring at
+    24^2 / 12^2, head-major self-attention at N = 9216 with the K / V batch remap.  Reference: modules/utils/masactrl.py:56-72, eta_inversion.py:207-273."""
+    from etainv.engine import AttnControl, Engine
+    from etainv import _capi
+    L5, B = 96, 8
+    e = Engine(dtype=torch.float16, max_unet_batch=4 * B, latent_size=L5, max_img=B)
+    e.load_synthetic(0)
+    try:
+        g = torch.Generator().manual_seed(905)
+        lat = (0.9 * torch.randn(2 * B, 4, L5, L5, generator=g)).cuda()      # [src x B, tgt x B]
+        ctx = torch.randn(4 * B, 77, 768, generator=g).cuda()                # [u_s, u_t, c_s, c_t] x B
+
+        def call(imgs):
+            n = len(imgs)
+            idx = torch.tensor(imgs, device="cuda")
+            role = lambda r: ctx[r * B + idx]
+            src, tgt = lat[idx], lat[B + idx]
+            ctrl = AttnControl(mode=_capi.ATTN_MASA, n_img=n, store_maps=True, masa_active=True, masa_first_block=10)
+            x, c = torch.cat([src, tgt]), torch.cat([role(0), role(1), role(2), role(3)])
+            out = torch.empty(c.shape[0], 4, L5, L5, device="cuda")
+            e.maps_reset()
+            e.unet(x.contiguous(), 481, c.contiguous(), ctrl, out=out)
+            torch.cuda.synchronize()
+            return out.reshape(c.shape[0] // n, n, 4, L5, L5)
+
+        full = call(list(range(B)))
+        assert torch.isfinite(full).all()
+        worst = 0.0
+        for b in (0, 5, 7):
+            one = call([b])
+            for r in range(one.shape[0]):
+                worst = max(worst, relerr(full[r, b], one[r, 0]))
+        print(f"config 5 rows: B = 8 vs single-image calls at L = 96, worst rel L2 over roles and images {worst:.2e}")
+        assert worst < 3e-3                                                  # two fp16 executions of the same arithmetic on different tilings
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("kind", ["bf16"])
 def test_s50_b32_batch_invariance(kind):
     """the benchmark step itself (etainv + ptp, S = 50, B = 32, bf16) with the oracle-traced pair 0 as image 0"""
