@@ -749,7 +749,44 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
   __syncthreads();
 
   // a block stages K / V^T once and then walks several 64*QT-query blocks (grid.x < N / (64*QT) at large N)
-  for (int qb = blockIdx.x; qb * (64 * QT) < N; qb += gridDim.x)
+  // The query fragments of the NEXT 64 QT-query block are requested before the current one is computed (D <= 80: the d = 160 instantiations have no
+  // registers for it).  Each wave's chain -- load 16 queries, 10 MFMAs, softmax over 80 keys, 9 MFMAs, store -- otherwise starts with a global-load
+  // latency: at 4096 tokens the kernel ran at 2 TB/s of its 0.67 GB with 16 waves per CU waiting on one load each.
+  constexpr bool QPF = D <= 80;
+  u32x4 qn[QPF ? QT : 1][QPF ? 2 : 1][QPF ? KS : 1];       // [query tile][0 = this row, 1 = the source row (EDIT)][k step]
+  auto load_q = [&](int qb, int qt, int brow, u32x4 (&dst)[QPF ? KS : 1]) __attribute__((always_inline)) {
+    int query = qb * (64 * QT) + wid * (16 * QT) + qt * 16 + fr;
+    query = query < N ? query : N - 1;
+    const T* qp = q + ((int64_t)brow * N + query) * C + h * D;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = ks * 32 + q4 * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (d0 < D) v = *reinterpret_cast<const u32x4*>(qp + d0);
+      dst[ks] = v;
+    }
+  };
+  auto load_block = [&](int qb) __attribute__((always_inline)) {
+    if constexpr (QPF) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        load_q(qb, qt, b, qn[qt][0]);
+        if (do_edit) load_q(qb, qt, bs, qn[qt][1]);
+      }
+    }
+  };
+  if (blockIdx.x * (64 * QT) < N) load_block(blockIdx.x);
+  for (int qb = blockIdx.x; qb * (64 * QT) < N; qb += gridDim.x) {
+  u32x4 qc[QPF ? QT : 1][QPF ? 2 : 1][QPF ? KS : 1];
+  if constexpr (QPF) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qc[qt][e][ks] = qn[qt][e][ks];
+    if ((qb + (int)gridDim.x) * (64 * QT) < N) load_block(qb + gridDim.x);
+  }
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     const int q_base = qb * (64 * QT) + wid * (16 * QT);
@@ -768,7 +805,8 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
       for (int ks = 0; ks < KS; ++ks) {
         const int d0 = ks * 32 + q4 * 8;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (d0 < D) v = *reinterpret_cast<const u32x4*>(qp + d0);
+        if constexpr (QPF) v = qc[qt][brow == b ? 0 : 1][ks];
+        else if (d0 < D) v = *reinterpret_cast<const u32x4*>(qp + d0);
         v8 qf = *reinterpret_cast<v8*>(&v);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
@@ -883,6 +921,7 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
         }
       }
     }
+  }
   }
 }
 
