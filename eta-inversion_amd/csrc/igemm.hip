@@ -212,11 +212,19 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
     } else if (UPS == 2) {
       // conv3x3 behind a nearest-2x upsample as four 2x2 phase convs on the source image (launch_pack_ups4, IGemmParams::ups == 2).  Virtual rows
       // are image-major, then phase (2 py + px), then source pixel: a tile lies inside one phase block (launch_igemm: H * W % BM == 0)
+      // (ups_pm: phase-major -- [phase][image][pixel], M / 4 rows per phase: a tile lies inside one phase, its rows may belong to several images)
       const int HWs = p.H * p.W;
-      const int blk = m0 / HWs, ph = blk & 3, b = blk >> 2;
+      const int PHs = p.M >> 2;
+      const int blk = m0 / HWs;
+      const int ph = p.ups_pm ? m0 / PHs : blk & 3;
 #pragma unroll
       for (int q = 0; q < A_LOADS; ++q) {
-        const int r = m0 - blk * HWs + (tid >> 3) + RP * q;
+        int b = blk >> 2, r = m0 - blk * HWs + (tid >> 3) + RP * q;
+        if (p.ups_pm) {
+          const int rr = m0 - ph * PHs + (tid >> 3) + RP * q;
+          b = rr / HWs;
+          r = rr - b * HWs;
+        }
         const int ys = r / p.W, xs = r - ys * p.W;
         a_b[q] = b;
         a_y[q] = ys + (ph >> 1) - 1;             // source pixel of tap (0, 0)
@@ -265,7 +273,7 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
         woff = img * wbs;
         it_boff = img * kp->bias_batch_stride;
       }
-      if constexpr (UPS == 2) woff = (int64_t)((m0 / (p.H * p.W)) & 3) * p.N * (4 * cin);   // the phase's 2x2 kernel
+      if constexpr (UPS == 2) woff = (int64_t)(p.ups_pm ? m0 / (p.M >> 2) : (m0 / (p.H * p.W)) & 3) * p.N * (4 * cin);   // the phase's 2x2 kernel
     }
 #pragma unroll
     for (int q = 0; q < B_LOADS; ++q) {
@@ -430,14 +438,20 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
       int um0 = 0, uph = 0;
       if constexpr (UPS == 2) {   // virtual row -> output pixel (2 ys + py, 2 xs + px) of image b
         const int HWs = p.H * p.W, blk = m0 / HWs;
-        uph = blk & 3;
-        um0 = (blk >> 2) * (4 * HWs);          // first output row of the image
+        uph = p.ups_pm ? m0 / (p.M >> 2) : blk & 3;
+        um0 = (blk >> 2) * (4 * HWs);          // first output row of the image (image-major order: the tile lies inside one image)
       }
       auto row_m = [&](int i) __attribute__((always_inline)) {
         if constexpr (UPS == 2) {
           const int HWs = p.H * p.W;
-          const int r = (mw + i * 16 + fr) % HWs, ys = r / p.W, xs = r - ys * p.W;
-          return um0 + (2 * ys + (uph >> 1)) * (2 * p.W) + 2 * xs + (uph & 1);
+          int r = (mw + i * 16 + fr) % HWs, im0 = um0;
+          if (p.ups_pm) {
+            const int rr = mw + i * 16 + fr - uph * (p.M >> 2), b = rr / HWs;
+            r = rr - b * HWs;
+            im0 = b * (4 * HWs);
+          }
+          const int ys = r / p.W, xs = r - ys * p.W;
+          return im0 + (2 * ys + (uph >> 1)) * (2 * p.W) + 2 * xs + (uph & 1);
         }
         return PATCH ? pm0 + i * p.W + fr : mw + i * 16 + fr;
       };
@@ -556,7 +570,13 @@ __global__ void __launch_bounds__(WAVES_M * 128, 2) igemm_kernel(IGemmParams p) 
           // image x WN channels) and channel: this lane's MT rows, then the 16 pixel lanes of the DPP row -> stat_out[row tile][0 / 1][channel]
           // (fixed order: deterministic); norm.hip gn_finalize_kernel adds row tiles and channels of a group.  Replaces the statistics pass over x.
           float* gs = ln_args()->stat_out;
-          const int64_t rt = mw / WM;
+          int64_t rt = mw / WM;
+          if constexpr (UPS == 2) {
+            if (p.ups_pm) {   // the partials stay image-major -- [image][phase][64-row block] -- for norm.hip's finalize (H * W % 64 == 0: a wave tile lies inside one image)
+              const int HWs = p.H * p.W, ph = mw / (p.M >> 2), rr = mw - ph * (p.M >> 2), b = rr / HWs;
+              rt = ((int64_t)b * 4 + ph) * (HWs / WM) + (rr - b * HWs) / WM;
+            }
+          }
           if (m0 + BM > p.M) {   // (wave-uniform) ragged last M tile: rows past M count as zero
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -1413,7 +1433,9 @@ static int ring_min_tiles() {
 // one phase block of one image, GroupNorm-producer or plain epilogue
 bool igemm_ups4_ok(const IGemmParams& p, int dtype) {
   if (dtype == ETAINV_F32 || p.taps != 4 || p.stride != 1 || p.a2 || p.geglu || p.residual || p.rowvec || p.ln_stat || p.out_f32 || p.out_nchw || p.w_batch_stride || p.pad0) return false;
-  if (p.N % 160 != 0 || (p.H * p.W) % 256 != 0 || p.Ho != 2 * p.H || p.Wo != 2 * p.W || p.M % (4 * p.H * p.W) != 0 || p.rows_per_batch != 4 * p.H * p.W) return false;
+  if (p.N % 160 != 0 || p.Ho != 2 * p.H || p.Wo != 2 * p.W || p.M % (4 * p.H * p.W) != 0 || p.rows_per_batch != 4 * p.H * p.W) return false;
+  // whole 256-row tiles per (image, phase) -- or, in phase-major row order, per phase with 64-row wave tiles inside one image (8 x 8, 24 x 24 sources)
+  if ((p.H * p.W) % 256 != 0 && ((p.M >> 2) % 256 != 0 || (p.H * p.W) % 64 != 0 || !env_flag("ETAINV_UPS4_PM", true))) return false;
   if (p.stat_out && p.stat_kind != 1) return false;
   if (env_on("ETAINV_NO_RING") || !env_flag("ETAINV_UPS4", true)) return false;
   return (int64_t)cdiv(p.M, 256) * cdiv(p.N, 160) >= ring_min_tiles();
@@ -1498,6 +1520,7 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   // images/s.  ETAINV_RING_MIN_TILES tunes it)
   static const int ring_min = getenv("ETAINV_RING_MIN_TILES") ? atoi(getenv("ETAINV_RING_MIN_TILES")) : 192;
   if (!p.geglu && p.ups == 2) {
+    p.ups_pm = (p.H * p.W) % 256 != 0;
     // conv3x3 behind a nearest-2x upsample as four 2 x 2 phase convs (4 / 9 of the FLOPs): its own instantiation of the ring (row decode, output scatter)
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_igemm_t<T, 256, 160, 4, 3, 2, 0>(p, s, stat_P)));
   } else if (!p.geglu && p.ups == 1 && p.N % 160 == 0 && huge_tiles >= ring_min && !env_on("ETAINV_NO_RING")) {

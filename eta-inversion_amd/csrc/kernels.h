@@ -33,6 +33,8 @@ struct IGemmParams {
   int H = 1, W = 1;           // source spatial dims (before the fused upsample)
   int Ho = 1, Wo = 1;         // output spatial dims
   int stride = 1, ups = 0, taps = 1;
+  int ups_pm = 0;                   // ups == 2: virtual rows ordered phase-major [phase][image][source pixel] (filled in by launch_igemm: source images that are not
+                                    // whole 256-row tiles -- 8 x 8, 24 x 24 -- where [image][phase][pixel] would put two phases' kernels into one tile)
   int geglu = 0;
   int xcd_gn = 1;             // XCD grid along N for the tile order (1, 2, 4 or 8; chosen by launch_igemm_t from a traffic model, see there)
   int ksplit = 1;             // split-K parts (filled in by launch_igemm for small M*N with deep K)
