@@ -1489,7 +1489,7 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
     return launch_pp_conv(p, dtype, s, stat_P);
   }
   if (pp_dualn_applicable(p, dtype)) {   // dual-N ping-pong kernel (ppgemm.hip)
-    ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)p.c1, s, igemm_algo_bytes(p));
+    ProfScope prof(PROF_IGEMM, 2.0 * (double)p.M * (double)p.N * (double)(p.c1 + p.c2), s, igemm_algo_bytes(p));
     return launch_pp_dualn(p, dtype, s, stat_P);
   }
   if (pp_gemm_applicable(p, dtype)) {

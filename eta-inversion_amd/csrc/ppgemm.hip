@@ -441,7 +441,9 @@ template <int HN> struct DualN {
   static constexpr int OFF_BIAS = 2 * SLOT, OFF_S = OFF_BIAS + 2 * BN2 * 4, OFF_STAT = OFF_S + 2 * BN2 * 4, LDS = OFF_STAT + 2 * PBM * 2 * 4;
 };
 
-template <typename T, int HN, int EPI, bool RES, int STAT>   // STAT: 0 none, 1 LayerNorm row statistics, 2 GroupNorm channel statistics of the stored output
+// A2: two activation sources [M][c1] | [M][c2] (the 1x1 shortcut of an up-block resnet reads the concatenation of the hidden state and the skip tensor without
+// materialising it: K tiles 0 .. c1 / 64 - 1 come from a1, the rest from a2; the weight rows are [N][c1 + c2])
+template <typename T, int HN, int EPI, bool RES, int STAT, bool A2 = false>   // STAT: 0 none, 1 LayerNorm row statistics, 2 GroupNorm channel statistics of the stored output
 __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
   typedef typename PMfma<T>::frag frag;
   typedef DualN<HN> D;
@@ -460,8 +462,8 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
   const int fr = lane & 15, fq = lane >> 4;
   const bool late = wid >= 4;
 
-  const int K = p.c1, N = p.N;
-  const int nk = K / PBK;
+  const int K1 = p.c1, K = A2 ? p.c1 + p.c2 : p.c1, N = p.N;
+  const int nk = K / PBK, nk1 = K1 / PBK;
   const int tiles_n = N / BN2;
   const int total_tiles = (p.M / PBM) * tiles_n;
   const int G = gridDim.x;
@@ -484,16 +486,26 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
   unsigned voff[PASSES];
 #pragma unroll
   for (int q = 0; q < PASSES; ++q) voff[q] = ((lrow + 64 * q) * (unsigned)K + (((tid & 7) ^ (lrow & 7)) << 3)) * 2u;
+  unsigned voa1[A2 ? 4 : 1], voa2[A2 ? 4 : 1];      // (A2) the activation pieces' lane offsets at the row pitches of the two sources
+  if constexpr (A2) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      voa1[q] = ((lrow + 64 * q) * (unsigned)K1 + (((tid & 7) ^ (lrow & 7)) << 3)) * 2u;
+      voa2[q] = ((lrow + 64 * q) * (unsigned)p.c2 + (((tid & 7) ^ (lrow & 7)) << 3)) * 2u;
+    }
+  }
   const int wrow_b = wid * 8 * PBK * 2;
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
   const char* a_base = nullptr;
+  const char* a_base2 = nullptr;
   const char* w_base = nullptr;
   int a_tile = 0, a_kt = 0, a_cnt = 0;              // activation cursor: (tile, K tile), K tiles issued
   int b_tile = 0, b_kt = 0, b_cnt = 0;              // weight cursor
   auto set_a = [&](int tile) __attribute__((always_inline)) {
     int m0, n0;
     tile_origin(tile, m0, n0);
-    a_base = reinterpret_cast<const char*>(p.a1) + (int64_t)m0 * K * 2;
+    a_base = reinterpret_cast<const char*>(p.a1) + (int64_t)m0 * K1 * 2;
+    if constexpr (A2) a_base2 = reinterpret_cast<const char*>(p.a2) + (int64_t)m0 * p.c2 * 2;
   };
   auto set_b = [&](int tile) __attribute__((always_inline)) {
     int m0, n0;
@@ -510,12 +522,22 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
   };
   auto issue_a = [&]() __attribute__((always_inline)) {      // the four activation pieces of the K tile at the activation cursor; the cursor moves on
     if (!no_dma) {
-      const char* g = a_base + a_kt * (PBK * 2);
       const unsigned d = lds0 + (a_cnt & 1) * D::SLOT + wrow_b;
+      if constexpr (A2) {
+        const bool second = a_kt >= nk1;
+        const char* g = second ? a_base2 + (a_kt - nk1) * (PBK * 2) : a_base + a_kt * (PBK * 2);
+        const unsigned v0 = second ? voa2[0] : voa1[0], v1 = second ? voa2[1] : voa1[1], v2 = second ? voa2[2] : voa1[2], v3 = second ? voa2[3] : voa1[3];
+        PP_DMA("global_load_lds_dwordx4", v0, g, d);
+        PP_DMA("global_load_lds_dwordx4", v1, g, d + 1 * (64 * PBK * 2));
+        PP_DMA("global_load_lds_dwordx4", v2, g, d + 2 * (64 * PBK * 2));
+        PP_DMA("global_load_lds_dwordx4", v3, g, d + 3 * (64 * PBK * 2));
+      } else {
+      const char* g = a_base + a_kt * (PBK * 2);
       PP_DMA("global_load_lds_dwordx4", voff[0], g, d);
       PP_DMA("global_load_lds_dwordx4", voff[1], g, d + 1 * (64 * PBK * 2));
       PP_DMA("global_load_lds_dwordx4", voff[2], g, d + 2 * (64 * PBK * 2));
       PP_DMA("global_load_lds_dwordx4", voff[3], g, d + 3 * (64 * PBK * 2));
+      }
     }
     ++a_cnt;
     if (++a_kt == nk) {
@@ -892,7 +914,9 @@ bool pp_gemm_applicable(const IGemmParams& p, int dtype) {
 // head-major QKV planes), 256 x 256 for the LayerNorm-consumer GEGLU projection; ETAINV_DUALN=0 switches it off.  Returns the epilogue kind or -1
 static int dualn_kind(const IGemmParams& p, int dtype) {
   if (!env_flag("ETAINV_DUALN", true) || (dtype != ETAINV_F16 && dtype != ETAINV_BF16)) return -1;
-  if (p.taps != 1 || p.a2 || p.rowvec || p.out_f32 || p.out_nchw || p.w_batch_stride || p.ksplit > 1) return -1;
+  if (p.taps != 1 || p.rowvec || p.out_f32 || p.out_nchw || p.w_batch_stride || p.ksplit > 1) return -1;
+  // two sources (the shortcut 1x1 over [hidden | skip]): the plain bias epilogue only
+  if (p.a2 && (p.geglu || p.ln_stat || p.residual || p.stat_out || p.hm_heads || p.c2 % PBK != 0 || p.c2 <= 0 || !env_flag("ETAINV_DUALN_A2", true))) return -1;
   if (p.stat_out && p.rows_per_batch % 64 != 0) return -1;     // (LayerNorm rows: partial index per wave tile; GroupNorm: whole wave tiles inside one image)
   if (p.M % PBM != 0 || p.c1 % PBK != 0 || p.c1 < 2 * PBK) return -1;
   int kind;
@@ -917,15 +941,15 @@ static int dualn_kind(const IGemmParams& p, int dtype) {
 bool pp_dualn_applicable(const IGemmParams& p, int dtype) { return dualn_kind(p, dtype) >= 0; }
 bool pp_dualn_hm_ok(const IGemmParams& p, int dtype) { return dualn_kind(p, dtype) == 2; }
 
-template <typename T, int HN, int EPI, bool RES, int STAT>
+template <typename T, int HN, int EPI, bool RES, int STAT, bool A2 = false>
 static void launch_dualn_t(const IGemmParams& p, int grid, hipStream_t s) {
   static bool attr_set[kMaxDevices] = {};
   const int dev = current_device();
   if (!attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<T, HN, EPI, RES, STAT>), hipFuncAttributeMaxDynamicSharedMemorySize, DualN<HN>::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pp_dualn_kernel<T, HN, EPI, RES, STAT, A2>), hipFuncAttributeMaxDynamicSharedMemorySize, DualN<HN>::LDS);
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((pp_dualn_kernel<T, HN, EPI, RES, STAT>), dim3(grid), dim3(512), DualN<HN>::LDS, s, p);
+  hipLaunchKernelGGL((pp_dualn_kernel<T, HN, EPI, RES, STAT, A2>), dim3(grid), dim3(512), DualN<HN>::LDS, s, p);
 }
 
 int launch_pp_dualn(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P) {
@@ -948,6 +972,7 @@ int launch_pp_dualn(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat
     } else {
       if (p.stat_out && p.stat_kind == 1) launch_dualn_t<T, 160, 0, false, 2>(p, grid, s);
       else if (p.stat_out) launch_dualn_t<T, 160, 0, false, 1>(p, grid, s);
+      else if (p.a2) launch_dualn_t<T, 160, 0, false, 0, true>(p, grid, s);
       else launch_dualn_t<T, 160, 0, false, 0>(p, grid, s);
     }
   });

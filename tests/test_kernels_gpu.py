@@ -546,6 +546,30 @@ def test_conv3x3_ping_pong_patch(capi, dtype, monkeypatch, b, h, wd, cin, cout, 
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,side,c1,c2,n", [(16, 64, 320, 320, 320), (16, 64, 640, 320, 320), (64, 32, 640, 640, 640), (48, 32, 1280, 640, 640), (256, 16, 1280, 1280, 1280)])
+def test_gemm_dual_n_two_sources(capi, dtype, monkeypatch, b, side, c1, c2, n):
+    """the 1x1 shortcut of an up-block resnet over [hidden | skip] without materialising the concatenation (reference: diffusers ResnetBlock2D.conv_shortcut
+    inside the UNet call of eta_inversion.py:321): dual-N kernel with two activation sources (K tiles 0 .. c1 / 64 - 1 from the first, the rest from the
+    second) against torch on the concatenated input and, bit for bit, against the ring kernel (ETAINV_DUALN_A2=0: same K order)"""
+    lib = capi.load()
+    dt = capi.dtype_code(dtype)
+    x1, x2 = rnd(b, side, side, c1, seed=1, dtype=dtype), rnd(b, side, side, c2, seed=2, dtype=dtype)
+    w = rnd(n, 1, c1 + c2, seed=3, scale=(c1 + c2) ** -0.5, dtype=dtype)
+    bias = rnd(n, seed=4)
+    outs = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("ETAINV_DUALN_A2", on)
+        out = torch.full((b, side, side, n), float("nan"), dtype=dtype, device="cuda")
+        capi.check(lib.etainv_op_conv3x3(capi.ptr(x1), capi.ptr(x2), c1, c2, capi.ptr(w), capi.ptr(bias), None, None, capi.ptr(out), b, side, side, n, 1, 0, 1, dt,
+                                         capi.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(out)
+    ref = torch.cat([x1, x2], -1).reshape(-1, c1 + c2)[:8192].float() @ w.reshape(n, -1).float().t() + bias
+    assert relerr(outs[0].reshape(-1, n)[:8192], ref) < TOL[dtype]
+    assert torch.equal(outs[0], outs[1]), "dual-N and ring accumulate the K tiles of the two sources in the same order"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("m,n,k,res,stat", [(65536, 320, 320, True, True), (65536, 320, 1280, True, True), (49152, 640, 640, True, False),
                                             (49152, 640, 2560, False, True), (49152, 1280, 5120, True, True), (98304, 320, 128, False, False),
                                             (131072 + 256 * 3, 320, 320, True, True)])
