@@ -398,18 +398,30 @@ def main():
     # --rows 128, FETCH_SIZE x2 per MI355X_MICROARCH.md, aggregated by tools/pmc_traffic.py), NOT measured by this run: the file is named
     # in the JSON and belongs to the kernels of the round it was taken in
     # (taken at 128 UNet rows = the default workload; null for the other configurations, whose launches have other sizes)
+    # A file is used only when its `kernel_src_sha16` (tools/srcstamp.py: hash of csrc/ + include/etainv.h, written by the aggregators) equals that of the
+    # sources this run was built from; otherwise the field is null and `*_source` says which file was stale.
+    sys.path.insert(0, str(ROOT / "tools"))
+    from srcstamp import kernel_src_sha16
+    src_sha = kernel_src_sha16()
     traffic, traffic_src = None, None
     for cand in (sorted((ROOT / "profiles").glob("r*_pmc_traffic_rows128.json"), reverse=True) if 4 * B == 128 else []):
-        traffic, traffic_src = json.load(open(cand))["igemm"]["hbm_bytes_per_launch"], f"profiles/{cand.name} (one 128-row UNet call)"
+        d = json.load(open(cand))
+        if d.get("kernel_src_sha16") == src_sha:
+            traffic, traffic_src = d["igemm"]["hbm_bytes_per_launch"], f"profiles/{cand.name} (one 128-row UNet call, same kernel sources {src_sha})"
+        else:
+            traffic_src = f"stale: profiles/{cand.name} was taken on kernel sources {d.get('kernel_src_sha16', 'unstamped')}, this run is {src_sha}"
         break
     # matrix-pipe busy share of the same kernels from the SQ counters (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE over tools/unet_call.py
     # --rows 128, aggregated by tools/pmc_sq.py): file-sourced like `traffic`, named in the JSON
     mfma_busy, mfma_busy_src = None, None
     for cand in (sorted((ROOT / "profiles").glob("r*_pmc_sq_rows128.json"), reverse=True) if 4 * B == 128 else []):
-        fam = json.load(open(cand)).get("summary", {}).get("igemm_family")
-        if fam and fam.get("mfma_busy_frac") is not None:
-            mfma_busy, mfma_busy_src = fam["mfma_busy_frac"], f"profiles/{cand.name} (one 128-row UNet call, cycle-weighted over the implicit-GEMM kernels)"
-            break
+        d = json.load(open(cand))
+        fam = d.get("summary", {}).get("igemm_family")
+        if d.get("kernel_src_sha16") != src_sha:
+            mfma_busy_src = f"stale: profiles/{cand.name} was taken on kernel sources {d.get('kernel_src_sha16', 'unstamped')}, this run is {src_sha}"
+        elif fam and fam.get("mfma_busy_frac") is not None:
+            mfma_busy, mfma_busy_src = fam["mfma_busy_frac"], f"profiles/{cand.name} (one 128-row UNet call, cycle-weighted over the implicit-GEMM kernels, same kernel sources {src_sha})"
+        break
     images = B * world * a.steps
     value = images / dt
     # MFMA FLOPs the kernels EXECUTED per image (implicit GEMMs + both attentions of the profiled step: the launchers record 2 M N K / 4 B h N^2 d

@@ -47,6 +47,9 @@ constexpr float NEG_BIG = -1.0e30f;
 #ifndef ATT_LAZY
 #define ATT_LAZY 0
 #endif
+#ifndef ATT_ABL
+#define ATT_ABL 0   // timing-only ablations of self_attn40_kernel (bit 0: no running maximum, 1: no exponentials, 2: no barrier, 3: no V fragment reads, 4: no K fragment reads): never in a product build
+#endif
 #ifndef ETAINV_QT40
 #define ETAINV_QT40 4
 #endif
@@ -389,6 +392,23 @@ template <int D> struct A32 {
 };
 constexpr float A40_THR = 8.0f;
 
+// maximum of the 32 scores a lane holds for one query block: four independent v_max3 chains of 8 elements (two per 32-key score tile, so the first two can run while the
+// second tile's MFMAs finish) and a 4-instruction combine -- 16 instructions, depth 6; the straight chain was 17 deep, each link waiting for the previous one's result
+__device__ __forceinline__ float max32(const f32x16 (&s)[2]) {
+  float c[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f32x16& t = s[k >> 1];
+    const int o = (k & 1) * 8;
+    float m = fmaxf(fmaxf(t[o], t[o + 1]), t[o + 2]);
+    m = fmaxf(fmaxf(m, t[o + 3]), t[o + 4]);
+    c[k] = fmaxf(fmaxf(m, t[o + 5]), t[o + 6]);
+  }
+  const float l = fmaxf(fmaxf(s[0][7], s[0][15]), s[1][7]);
+  const float m = fmaxf(fmaxf(c[0], c[1]), c[2]);
+  return fmaxf(fmaxf(m, c[3]), fmaxf(l, s[1][15]));
+}
+
 template <typename T, int D, bool XCD_REMAP, int QB, int OCC>
 __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads,
                                                                float q_scale, int mode, int n_img, int nqb, int stagger, int first_row, int hm_rows) {
@@ -479,36 +499,43 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
     }
   }
 
-  // ---- K / V staging through registers: 320 16-byte chunks each per tile (64 keys x 5 chunks), 2 per thread (threads >= 64 take one)
+  // ---- K / V staging through registers: KV * NCH 16-byte chunks per tensor and tile, chunk c = tid + 256 i (D = 40: 320, two per thread of wave 0, one for the others).
+  // Round 6: buffer loads with one descriptor per tensor -- per-lane byte offsets are computed once, the tile enters as the scalar offset, keys past N are out of the
+  // descriptor's range and load as zeros (finite, masked in the scores), and which chunk groups a wave carries is wave-uniform: no per-lane bounds test, no 64-bit
+  // address arithmetic, no zero fill and no divergent branch in the tile loop (that prologue was ~45 instructions and 8 branches in front of every tile's first MFMA).
   u32x4 rk[NLD], rv[NLD];
   const T* kbase = hm_rows ? qkv + ((int64_t)hm_rows * heads + (int64_t)bk * heads + hd) * N * D : qkv + (int64_t)bk * N * C3 + C + hd * D;
   const T* vbase = hm_rows ? qkv + ((int64_t)2 * hm_rows * heads + (int64_t)bv * heads + hd) * N * D : qkv + (int64_t)bv * N * C3 + 2 * C + hd * D;
-  int st_row[NLD], st_ch[NLD];
+  // range of both descriptors: every byte of a key < N lies inside, every byte of a key >= N outside (row-major: the V plane's start is the larger one, (hd + 1) D <= C)
+  const unsigned nrec = hm_rows ? (unsigned)N * D * 2u : (unsigned)N * C3 * 2u - (unsigned)(2 * C + hd * D) * 2u;
+  const unsigned tile_bytes = hm_rows ? (unsigned)KV * D * 2u : (unsigned)KV * C3 * 2u;
+  const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(kbase), 0, nrec, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(vbase), 0, nrec, 0x00020000);
+  const int wv = __builtin_amdgcn_readfirstlane(wid);
+  unsigned goff[NLD];
+  int ldk[NLD], ldv[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
-    const int c = tid + 256 * i;
-    st_row[i] = c / NCH;
-    st_ch[i] = c - st_row[i] * NCH;
+    const int c = tid + 256 * i, row = c / NCH, ch = c - row * NCH;
+    goff[i] = hm_rows ? (unsigned)c * 16u : (unsigned)row * C3 * 2u + (unsigned)ch * 16u;
+    ldk[i] = row * KROW + ch * 8;
+    ldv[i] = row * VROW + ch * 8;
   }
-  auto load_kv = [&](int kv0) {
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      u32x4 a = {0u, 0u, 0u, 0u}, c = {0u, 0u, 0u, 0u};
-      if (tid + 256 * i < KV * NCH && kv0 + st_row[i] < N) {        // keys past N: zeros (finite), masked in the scores
-        const int64_t off = hm_rows ? ((int64_t)kv0 * NCH + (tid + 256 * i)) * 8 : (int64_t)(kv0 + st_row[i]) * C3 + st_ch[i] * 8;
-        a = *reinterpret_cast<const u32x4*>(kbase + off);
-        c = *reinterpret_cast<const u32x4*>(vbase + off);
-      }
-      rk[i] = a;
-      rv[i] = c;
-    }
-  };
-  auto store_kv = [&](int bufi) {
+  auto load_kv = [&](int tile) __attribute__((always_inline)) {
+    const unsigned soff = (unsigned)tile * tile_bytes;
 #pragma unroll
     for (int i = 0; i < NLD; ++i)
-      if (tid + 256 * i < KV * NCH) {
-        *reinterpret_cast<u32x4*>(sK + bufi * KBUF + st_row[i] * KROW + st_ch[i] * 8) = rk[i];
-        *reinterpret_cast<u32x4*>(sV + bufi * VBUF + st_row[i] * VROW + st_ch[i] * 8) = rv[i];
+      if (wv * 64 + 256 * i < KV * NCH) {        // wave-uniform
+        rk[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_k, goff[i], soff, 0));
+        rv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, goff[i], soff, 0));
+      }
+  };
+  auto store_kv = [&](int bufi) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      if (wv * 64 + 256 * i < KV * NCH) {
+        *reinterpret_cast<u32x4*>(sK + bufi * KBUF + ldk[i]) = rk[i];
+        *reinterpret_cast<u32x4*>(sV + bufi * VBUF + ldv[i]) = rv[i];
       }
   };
 
@@ -538,7 +565,7 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
   auto tile_body = [&](int j, auto ragged_tag) {
     constexpr bool RAGGED = decltype(ragged_tag)::value;
     const int kv0 = j * KV, cur = j & 1;
-    if (j + 1 < ntiles) load_kv(kv0 + KV);
+    if (j + 1 < ntiles) load_kv(j + 1);
     const T* tK = sK + cur * KBUF + kA;
     // V^T row tiles of 32 dims: lanes with vg = 1 read dims 32 dt + 16 .. + 31, which lie past the row for the last tile of D = 40
     // (rows 48 .. 63 of V^T are zero: read from the zero image)
@@ -549,13 +576,32 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
       if (dt * 32 + 16 >= VROW && vg) tV[dt] = sZ + vA - 16;
     }
 
+    v8 vf[4][DT];
+    auto read_v = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const T* vp_ = tV[dt] + ks * 16 * VROW;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp_));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp_ + 8 * VROW));
+          vf[ks][dt] = __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#if ATT_ABL & 8   // timing only: no V fragment reads
+          vf[ks][dt] = qf[0][(ks + dt) % KS];
+#endif
+        }
+    };
+
     // ---- S'^T = K Q^T - m' : s[qb][kb] register i = key kb*32 + (i&3) + 8(i>>2) + 4h, query r
     f32x16 s[QB][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int st = 0; st < KS; ++st) {
-        const v8 kf = *reinterpret_cast<const v8*>(tK + kb * 32 * KROW + st * 16);
+        v8 kf = *reinterpret_cast<const v8*>(tK + kb * 32 * KROW + st * 16);
+#if ATT_ABL & 16   // timing only: no K fragment reads
+        kf = qf[QB - 1][(st + kb) % KS];
+#endif
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
           if (st == 0) {
@@ -580,12 +626,12 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
 
     // ---- reference maximum: moves only when a query exceeds it by 2^THR (or on the first tile)
     float mx[QB];
+#if ATT_ABL & 1
+    if (j == 0)
+#endif
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-      float m = fmaxf(fmaxf(s[qb][0][0], s[qb][0][1]), s[qb][0][2]);
-#pragma unroll
-      for (int e = 3; e + 1 < 32; e += 2) m = fmaxf(fmaxf(m, s[qb][e >> 4][e & 15]), s[qb][(e + 1) >> 4][(e + 1) & 15]);
-      m = fmaxf(m, s[qb][1][15]);
+      const float m = max32(s[qb]);
       // the other 32 keys of the query live in lane ^ 32: v_permlane32_swap exchanges lanes 32-63 of the first operand with lanes 0-31 of
       // the second (VALU, no LDS).  Inline asm: with this toolchain the builtin's SECOND result comes back as a copy of the first
       // (hipcc 7.2 folds max(sw[0], sw[1]) to sw[0]), which left a maximum over half of the keys -- still a valid softmax reference, but
@@ -595,7 +641,11 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
       mx[qb] = fmaxf(ma, mb);   // both key halves of the query
     }
     const bool first = j == 0;
+#if ATT_ABL & 1   // timing only: no running maximum after the first tile
+    if (first) {
+#else
     if (first || __builtin_amdgcn_ballot_w64(fmaxf(mx[0], mx[QB - 1]) > A40_THR) != 0) {
+#endif
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
         const float d = first ? mx[qb] : fmaxf(mx[qb], 0.f);
@@ -619,16 +669,8 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
 
     // ---- V^T fragments of the tile (shared by the query blocks), requested BEFORE the exponentials: 16 transposed reads whose LDS latency
     // is then covered by ~300 cycles of v_exp instead of standing in front of every MFMA
-    v8 vf[4][DT];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const T* vp_ = tV[dt] + ks * 16 * VROW;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp_));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp_ + 8 * VROW));
-        vf[ks][dt] = __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-      }
+    // (all 22 LDS reads of the tile requested in front of the S MFMAs instead: 3.493 vs 3.476 ms, no gain -- the partner wave already covers the LDS latency)
+    read_v();
     __builtin_amdgcn_sched_barrier(0);   // keep the reads up here (the scheduler otherwise sinks each pair to just before its MFMA)
     // ---- P = exp2(S') packed straight into the PV operands, O^T += V^T P^T
     v8 pf[QB][4];
@@ -637,7 +679,11 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
+#if ATT_ABL & 2   // timing only: no exponentials
+        for (int e = 0; e < 8; ++e) pf[qb][ks][e] = (T)(s[qb][ks >> 1][(ks & 1) * 8 + e]);
+#else
         for (int e = 0; e < 8; ++e) pf[qb][ks][e] = (T)__builtin_amdgcn_exp2f(s[qb][ks >> 1][(ks & 1) * 8 + e]);
+#endif
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -645,7 +691,11 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
     }
 
     if (j + 1 < ntiles) store_kv(cur ^ 1);   // buffer cur^1 was last read in iteration j-1, a barrier ago
+#if ATT_ABL & 4   // timing only: no barrier (races)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     __syncthreads();
+#endif
   };
   for (int j = 0; j < nfull; ++j) tile_body(j, std::false_type{});
   if (nfull < ntiles) tile_body(nfull, std::true_type{});
@@ -961,9 +1011,12 @@ static int launch_self40(const void* qkv, void* out, int b, int n, int heads, in
   static const int stagger = getenv("ETAINV_A40_STAGGER") ? atoi(getenv("ETAINV_A40_STAGGER")) : 0;
   static const size_t lds_pad = getenv("ETAINV_A40_LDSPAD") ? (size_t)atoi(getenv("ETAINV_A40_LDSPAD")) : 0;   // experiment: fewer resident blocks
   const size_t lds = A40_LDS + lds_pad;
-  if (lds_pad || lds > 64 * 1024) {
+  static bool attr_set[kMaxDevices] = {};   // per device and instantiation (T, D, QB, OCC); the LDSPAD experiment changes the size per process only
+  const int dev = current_device();
+  if ((lds_pad || lds > 64 * 1024) && !attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn40_kernel<T, D, true, QB, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn40_kernel<T, D, false, QB, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set[dev] = true;
   }
   if (remap)
     hipLaunchKernelGGL((self_attn40_kernel<T, D, true, QB, OCC>), dim3(nqb * heads * b), dim3(256), lds, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb, stagger, first_row, hm_rows);
@@ -992,7 +1045,8 @@ int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int hea
   ETAINV_CHECK(!q_prescaled || d == 40 || d == 80, "pre-scaled queries: head_dim 40 / 80 only");
   ETAINV_CHECK(!q_prescaled || self_attn40_v2_enabled(), "pre-scaled queries need the d = 40 kernel");
   if (d == 40 && self_attn40_v2_enabled()) {
-    // two 32-query blocks per wave, 2 waves per SIMD (measured: one block per wave with 3 or 4 waves per SIMD is 10-13 % slower)
+    // two 32-query blocks per wave, 2 waves per SIMD (one block per wave with 3 / 4 waves per SIMD: +10 % / +52 % time, re-measured in round 6 on the lean staging:
+    // profiles/r06_attention_experiments.log)
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 40, 2, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s, first_row, head_major)));
   }
   static const bool v2_80 = !env_on("ETAINV_ATT80_OLD");   // A/B: head_dim 80 on the 32x32x16 kernel (one 32-query block per wave)

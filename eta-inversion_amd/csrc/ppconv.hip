@@ -819,6 +819,9 @@ bool pp_conv_applicable(const IGemmParams& p, int dtype) {
   if (p.M != (p.M / (p.H * p.W)) * p.H * p.W || p.rows_per_batch != p.H * p.W) return false;
   if (p.stat_out && p.stat_kind != 1) return false;
   if (p.rowvec && p.rowvec_stride < p.N) return false;
+  // both ping-pong convs address with 32-bit byte offsets (buffer descriptors per image, int patch bases): larger tensors go to the ring
+  const int64_t cmax = std::max(p.c1, p.N);
+  if ((int64_t)p.M * cmax * 2 >= (1ll << 31) || (int64_t)p.H * p.W * cmax * 2 >= (1ll << 31)) return false;
   static const int min_tiles = getenv("ETAINV_PPCONV_MIN_TILES") ? atoi(getenv("ETAINV_PPCONV_MIN_TILES")) : 192;
   return (int64_t)(p.M / 256) * (p.N / CBN) >= min_tiles;
 }

@@ -901,7 +901,7 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
 // allocator spill 130-270 registers (plain loads compile to 245 registers but are waited for with vmcnt(0), which drains the DMA queue four times per
 // tile).  The RES / STAT instantiations below are therefore refused by the predicate (ETAINV_PP_FORCE_ALL=1 lets them through: spilling, 4-7x slower -- evidence only).
 bool pp_gemm_applicable(const IGemmParams& p, int dtype) {
-  static const int mode = getenv("ETAINV_PP_FORCE_ALL") ? 2 : 1;
+  static const int mode = env_on("ETAINV_PP_FORCE_ALL") ? 2 : 1;
   if (!env_on("ETAINV_PP") || (dtype != ETAINV_F16 && dtype != ETAINV_BF16)) return false;
   if (mode < 2 && (p.residual || p.stat_out)) return false;
   if (p.taps != 1 || p.a2 || p.geglu || p.rowvec || p.out_f32 || p.out_nchw || p.ln_stat || p.w_batch_stride || p.ksplit > 1 || p.hm_heads) return false;
@@ -959,7 +959,7 @@ int launch_pp_dualn(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat
   if (p.stat_out) p.stat_P = p.stat_kind == 1 ? 64 : p.N / 80;   // GroupNorm: rows per partial block; LayerNorm: partials per row
   if (stat_P) *stat_P = p.stat_out ? p.stat_P : 0;
   const int tiles = (p.M / PBM) * (p.N / (kind == 3 ? 256 : 320));
-  static const int grid_cap = getenv("ETAINV_DUALN_GRID") ? atoi(getenv("ETAINV_DUALN_GRID")) : 256;   // (experiments: fewer persistent blocks than CUs)
+  static const int grid_cap = getenv("ETAINV_DUALN_GRID") ? std::max(1, atoi(getenv("ETAINV_DUALN_GRID"))) : 256;   // (experiments: fewer persistent blocks than CUs)
   const int grid = std::min(tiles, grid_cap);
   ETAINV_DISPATCH_HALF(dtype, T, {
     if (kind == 3) launch_dualn_t<T, 128, 3, false, 0>(p, grid, s);

@@ -11,7 +11,7 @@ def update_alpha_time_word(alpha, bounds, prompt_ind, word_inds=None):
     rows = alpha.shape[0]
     window = torch.zeros(rows, dtype=alpha.dtype)
     window[int(lo * rows):int(hi * rows)] = 1
-    cols = torch.arange(alpha.shape[2]) if word_inds is None else word_inds
+    cols = torch.arange(alpha.shape[2]) if word_inds is None else torch.as_tensor(word_inds)   # (get_word_inds returns a numpy array, reference :326)
     alpha[:, prompt_ind, cols] = window[:, None].expand(rows, len(cols)) if cols.dim() else window
     return alpha
 

@@ -41,6 +41,17 @@ def test_prompt_tables_match_reference_goldens(golden):
         seq_aligner.get_replacement_mapper(["a cat", "a very big cat"], tok)
 
 
+def test_update_alpha_time_word_takes_the_numpy_word_inds_the_reference_passes():
+    # reference ptp_utils.py:326-336 is called with get_word_inds' numpy array (and with a scalar tensor index); both must keep working
+    from modules.utils import ptp_utils
+    ref = torch.zeros(11, 1, 77)
+    ref[1:5, 0, [2, 3]] = 1
+    for inds in (np.array([2, 3]), torch.tensor([2, 3]), [2, 3]):
+        np.testing.assert_array_equal(ptp_utils.update_alpha_time_word(torch.zeros(11, 1, 77), (0.1, 0.5), 0, inds).numpy(), ref.numpy())
+    full = ptp_utils.update_alpha_time_word(torch.zeros(11, 1, 77), 0.4, 0)
+    assert full[:4].eq(1).all() and full[4:].eq(0).all()
+
+
 def test_schedule_tables_match_reference_goldens(golden):
     from etainv.pipeline import alphas_cumprod, eta_table, EtaLoop
     from modules.schedulers import DDIMScheduler

@@ -9,6 +9,9 @@
 #   routes [rows]              per-(shape, kernel family) table of one UNet call: launch trace joined with event times -> launch_table_rows<rows>.log
 #   ops [only]                 per-shape micro-benchmark (tools/bench_ops.py --rows 128)
 #   opsenv <only> <envB>       same-box A/B of the default library: plain vs with VAR=value[,VAR=value] (tools/ab_ops.py)
+#   pmcop <name> <only> <ctrs..>  one --pmc pass over tools/bench_ops.py --only <only>, per-kernel summary -> pmcop_<name>.json
+#   counters                   rocprofv3 -L -> counters.txt
+#   opsenv2 <only> <envA> <envB> same-box A/B of the default library under two environments
 #   opslib <only> <variant>    same-box A/B: libetainv_hip.so vs libetainv_hip_<variant>.so (built by csrc/build.sh VARIANT=...)
 #   bench [args]               python bench.py [args] (default invocation when no args) -> bench<sanitised args>.json
 #   benchenv <envB> [n]        bench A/B (--steps 2 --warmup 1 --no-cpu-baseline), n alternations (default 2)
@@ -63,6 +66,23 @@ run_job() {
     opsenv)
       python tools/ab_ops.py --a $LIB/libetainv_hip.so --b $LIB/libetainv_hip.so --only "$1" --env-b "$2" > "$OUT/opsenv_$1_${2//[^A-Za-z0-9_=]/_}.log" 2>&1
       echo "A = default, B = $2"; cat "$OUT/opsenv_$1_${2//[^A-Za-z0-9_=]/_}.log" ;;
+    pmcop)
+      # pmcop <name> <only> <counter> [counter ...]: one rocprofv3 --pmc pass over the micro-benchmark of one op, aggregated per kernel by tools/pmc_sq.py
+      local name="$1" only="$2"; shift 2
+      rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmcop_$name -- python3 tools/bench_ops.py --rows 128 --only "$only" > $OUT/pmcop_$name.log 2>&1
+      python tools/pmc_sq.py $(find $OUT/pmcop_$name -name "*counter_collection.csv") > $OUT/pmcop_$name.json 2> $OUT/pmcop_$name.err
+      rm -rf $OUT/pmcop_$name; tail -3 $OUT/pmcop_$name.log; cat $OUT/pmcop_$name.err
+      python -c "
+import json,sys
+d=json.load(open('$OUT/pmcop_$name.json'))
+for k in d['kernels'][:3]:
+    print(k['kernel'], k['launches']); print({a:b for a,b in k.items() if a not in ('kernel','raw','launches')}); print(k['raw'])
+" ;;
+    counters)
+      rocprofv3 -L > $OUT/counters.txt 2>&1; grep -c . $OUT/counters.txt ;;
+    opsenv2)
+      python tools/ab_ops.py --a $LIB/libetainv_hip.so --b $LIB/libetainv_hip.so --only "$1" --env-a "$2" --env-b "$3" > "$OUT/opsenv2_$1_${3//[^A-Za-z0-9_=]/_}.log" 2>&1
+      echo "A = $2, B = $3"; cat "$OUT/opsenv2_$1_${3//[^A-Za-z0-9_=]/_}.log" ;;
     opslib)
       python tools/ab_ops.py --a $LIB/libetainv_hip.so --b $LIB/libetainv_hip_$2.so --only "$1" > $OUT/opslib_$1_$2.log 2>&1
       echo "A = default, B = variant $2"; cat $OUT/opslib_$1_$2.log ;;

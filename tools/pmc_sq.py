@@ -18,6 +18,10 @@ import functools
 import json
 import re
 import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from srcstamp import kernel_src_sha16  # noqa: E402
 
 
 @functools.lru_cache(maxsize=None)
@@ -86,7 +90,7 @@ def main():
     w = sum(e["share_of_gpu_cycles"] for e in fam)
     summary = {"igemm_family": {"share_of_gpu_cycles": w, "mfma_busy_frac": sum(e["mfma_busy_frac"] * e["share_of_gpu_cycles"] for e in fam) / w if w else None,
                                 "kernels": len(fam)}}
-    print(json.dumps({"summary": summary, "kernels": out}, indent=1))
+    print(json.dumps({"kernel_src_sha16": kernel_src_sha16(), "summary": summary, "kernels": out}, indent=1))
 
 
 if __name__ == "__main__":

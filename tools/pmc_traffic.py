@@ -5,6 +5,10 @@ import collections
 import csv
 import json
 import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from srcstamp import kernel_src_sha16  # noqa: E402
 
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(lambda: collections.defaultdict(int))
@@ -22,4 +26,5 @@ for cls, v in agg.items():
     write = v.get("WRITE_SIZE", 0.0) * 1024
     out[cls] = {"launches": n, "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / n,
                 "hbm_bytes_per_launch": (fetch + write) / n}
+out["kernel_src_sha16"] = kernel_src_sha16()
 print(json.dumps(out, indent=1))
