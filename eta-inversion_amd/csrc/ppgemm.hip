@@ -843,6 +843,9 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
     // waiting with vmcnt(<stores>) instead of vmcnt(0) -- and, for GEGLU, holding the converted outputs in registers and storing them two per K tile
     // under the next tile's main loop.  Both bit-identical, both +-0 %: the waves are held at the ISSUE of the stores and the store path is in order
     // with the DMA pieces either way; profiles/r05_dualn_store_ablation.log.)
+    // (Tried and removed, round 6: both groups' epilogues in the SAME barrier interval -- E waits one barrier for L's last cluster, L one barrier behind its
+    // epilogue -- so that two waves per SIMD issue the ~1000 epilogue instructions side by side instead of one after the other: bit-identical, 1-3 % SLOWER
+    // on every GEGLU / Linear shape (profiles/r06_dualn_concurrent_epilogue_ab.log): the epilogue is not bound by the single-wave issue rate.)
     if (s > 0 && ct_kt == 0 && !no_epi) {           // the previous K tile finished an output tile: both halves, in front of this tile's first cluster
       epilogue_half(I0{}, ct_tile - 1);
       epilogue_half(I1{}, ct_tile - 1);

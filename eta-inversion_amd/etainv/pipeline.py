@@ -227,6 +227,7 @@ class EtaLoop:
             else:
                 e.maps_reset()
         ctx3 = eps3 = ctx3x = eps3x = None
+        losses = torch.zeros(B, self.n_cand, dtype=torch.float32, device=dev) if trace is not None else None   # per-candidate losses of the best-of-n step (traces only)
         eps_t = torch.empty(B, 4, L, L, dtype=torch.float32, device=dev)
         st = _capi.stream_ptr()
         with e.cached_context():                               # one unchanged context tensor for all S calls
@@ -301,13 +302,13 @@ class EtaLoop:
                 _capi.check(self.lib.etainv_eta_backward_step_ex(
                     _capi.ptr(x), _capi.ptr(eps_all), self.g_bwd, _capi.ptr(lat_inv[S - 1 - i]), _capi.ptr(noise[i]), self.n_cand,
                     float(self.etas[t]), _capi.ptr(mask_map), float(self.mask_thres or 0.0), mask_mode, a_t, a_p, var, B, 4, L * L,
-                    _capi.ptr(x_new), None, _capi.ptr(best), None, _capi.ptr(scratch), _capi.F32, float(self.target_dirinv or 0.0), _capi.ptr(dmap), st))
+                    _capi.ptr(x_new), None, _capi.ptr(best), _capi.ptr(losses), _capi.ptr(scratch), _capi.F32, float(self.target_dirinv or 0.0), _capi.ptr(dmap), st))
                 x, x_new = x_new, x
                 if ptp is not None and ptp.blend_alpha is not None and (i + 1) > int(0.2 * S):
                     e.local_blend(x, B, ptp.blend_alpha, 0.3)                       # LocalBlend, reference ptp.py:31-47
                 if trace is not None:
                     trace.append({"t": t, "latent": x.clone(), "best": best.clone(), "eps_all": eps_all.clone(), "eps_rows": eps_all.clone(),
-                                  "layout": "u_s,u_t,c_s,c_t"})
+                                  "layout": "u_s,u_t,c_s,c_t", "losses": losses.clone()})
         return x
 
 

@@ -90,9 +90,10 @@ def oracle_worker(a):
 
 
 # ------------------------------------------------------------------------------------------------ native runs
-def native_run(dtype, S, L, n_pairs, batch=None):
+def native_run(dtype, S, L, n_pairs, batch=None, select=None, engine=None):
     """batch (>= n_pairs): the n_pairs oracle-traced pairs are images 0 .. n_pairs-1 of a `batch`-image call; the other images cycle through the same
-    prompt pairs with latents / contexts of their own (tests/test_bench_shape_gpu.py: the benchmark's B = 32).  Returns the runs of ALL images."""
+    prompt pairs with latents / contexts of their own (tests/test_bench_shape_gpu.py: the benchmark's B = 32).  Returns the runs of ALL images.
+    select: run only these images of that input set (a smaller call on the same inputs); engine: reuse an Engine instead of building one."""
     from oracle import ptp as optp                       # host-side table builders only (checker infrastructure, like the tests)
     from etainv.engine import Engine
     from etainv.pipeline import EtaLoop, PtpTables, noise_table
@@ -107,6 +108,9 @@ def native_run(dtype, S, L, n_pairs, batch=None):
         xt[:, 0] = xs[:, 0]
         ctx_src, ctx_tgt = torch.cat([ctx_src, xs]), torch.cat([ctx_tgt, xt])
         B = batch
+    if select is not None:
+        sel = list(select)
+        pairs, z0, ctx_src, ctx_tgt, B = [pairs[i] for i in sel], z0[sel], ctx_src[sel], ctx_tgt[sel], len(sel)
     tok = optp.WordTokenizer()
     W = max(len(s.split(" ")) for s, _ in pairs)
     tokens = torch.ones(B, W, dtype=torch.int32)
@@ -120,8 +124,10 @@ def native_run(dtype, S, L, n_pairs, batch=None):
         eq.append(optp.equalizer(tgt, (tw,), (2,), tok))
         ba.append(optp.blend_alpha_layers([src, tgt], ((bw,), (tw,)), tok))
         ca.append(optp.time_words_alpha([src, tgt], S, {"default_": .4}, tok)[:, 0])
-    eng = Engine(dtype=dtype, max_unet_batch=4 * B, latent_size=L, max_img=B)
-    eng.load_synthetic(0)
+    eng = engine
+    if eng is None:
+        eng = Engine(dtype=dtype, max_unet_batch=4 * B, latent_size=L, max_img=B)
+        eng.load_synthetic(0)
     ptp = PtpTables(np.stack(mp), np.stack(al), np.stack(ca, 1), 0.6, S, equalizer=np.stack(eq), blend_alpha=np.stack(ba))
     loop = EtaLoop(eng, S=S, eta=ETA, use_mask=True)
     nz = noise_table(S, 10, L, seed=0)
@@ -138,8 +144,11 @@ def native_run(dtype, S, L, n_pairs, batch=None):
         runs.append({"steps": ks, "inv": torch.stack([lat[s, b] for s in ks]), "map": inv["maps_mean"][b, 1].cpu(),
                      "bwd": torch.stack([torch.stack([trace[s - 1]["latent"][b].cpu(), trace[s - 1]["latent"][B + b].cpu()]) for s in ks]),
                      "best": torch.tensor([int(t["best"][b]) for t in trace]), "out": torch.stack([out[b].cpu(), out[B + b].cpu()]),
+                     # the native per-candidate losses of every best-of-n step (zeros at the eta = 0 steps, which choose nothing)
+                     "losses": torch.stack([t["losses"][b].cpu() if t.get("losses") is not None else torch.zeros(10) for t in trace]),
                      "seconds": secs})
-    eng.close()
+    if engine is None:
+        eng.close()
     return runs
 
 

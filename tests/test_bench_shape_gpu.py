@@ -154,34 +154,71 @@ def test_config5_rows_b8_masactrl_vs_single_image_calls():
         e.close()
 
 
-@pytest.mark.parametrize("kind", ["bf16"])
+# two units in the last place of the compute dtype: a best-of-n choice may only differ from another execution's where the two candidates' losses are closer
+# than that (the largest gap observed at a fork in round 5 was 1.8e-3, bf16)
+NEAR_TIE = {"bf16": 2 * 2.0 ** -8, "fp16": 2 * 2.0 ** -10}
+
+
+@pytest.mark.parametrize("kind", ["bf16", "fp16"])
 def test_s50_b32_batch_invariance(kind):
-    """the benchmark step itself (etainv + ptp, S = 50, B = 32, bf16) with the oracle-traced pair 0 as image 0"""
-    from tests.parity_s50 import native_run
-    S = 50
-    ref = load(CACHE_DIR / "s50_pair0.npz")
+    """the benchmark step itself (etainv + ptp, S = 50, B = 32) with the oracle-traced pairs 0 and 1 as images 0 and 1, and EVERY image against the B = 2 call
+    of the same two inputs.  The argmin over ten noise candidates (reference eta_inversion.py:330-375) is discontinuous: the B = 32 and B = 2 calls run on
+    different tile forms (not bit-identical), so a choice may flip where two candidates nearly tie, and the edited latent then differs by O(1) from there on.
+    Asserted: every first fork is such a near-tie (relative loss gap <= 2 ulp of the dtype, measured with the B = 2 run's own losses, and with the oracle's for
+    images 0 / 1); images without a fork end within the reference-precision floor of their B = 2 run; the number of forked images is printed and bounded."""
+    from etainv.engine import Engine
+    from tests.parity_s50 import native_run, compare
+    S, B = 50, 32
+    refs = [load(CACHE_DIR / "s50_pair0.npz"), load(CACHE_DIR / "s50_pair1.npz")]
     dt = {"fp16": torch.float16, "bf16": torch.bfloat16}[kind]
-    small = native_run(dt, S, L, 2)[0]
-    big = native_run(dt, S, L, 2, batch=32)[0]
-    from tests.parity_s50 import compare
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
-    floor = ref["floors"][kind]["final_edit_rel_l2"]
-    e_small, e_big = rel(small["out"][1], ref["out"][1]), rel(big["out"][1], ref["out"][1])
-    cmp_big = compare(big, ref)
-    flips = cmp_big["best_of_n_flips"]
-    print(f"{kind}: S = 50 edited latent vs the fp32 oracle: B = 2 run {e_small:.2e}, image 0 of the B = 32 run {e_big:.2e} (floor {floor:.2e}); "
-          f"best-of-n {cmp_big['best_of_n_agree']}/{S} {flips}; source row {rel(big['out'][0], ref['out'][0]):.2e}")
-    # The B = 2 and B = 32 calls run on different kernels (tile forms chosen by the launch's size: not bit-identical), so a best-of-n choice may differ from
-    # the oracle's -- but, as in tests/test_realsize_gpu.py, only where the oracle's own two candidates nearly tie (relative loss gap below the rounding
-    # of the compute dtype); up to the first such fork the trajectory must stay inside the floor, and without a fork so must the result
-    assert all(f["oracle_rel_loss_gap"] < (2e-2 if kind == "bf16" else 2e-3) for f in flips), flips
-    first_fork = min([f["bwd_step"] for f in flips], default=S + 1)
-    # (checkpoints by STEP NUMBER: the committed trace keeps steps 1, 5, 10, 25, 50, the run more -- `compare`'s per_step rows pair them by position)
-    before = {s: rel(big["bwd"][big["steps"].index(s)][1], ref["bwd"][list(ref["steps"]).index(s)][1]) for s in ref["steps"] if s < first_fork and s in big["steps"]}
-    inv_err = {s: rel(big["inv"][big["steps"].index(s)], ref["inv"][list(ref["steps"]).index(s)]) for s in ref["steps"] if s in big["steps"]}
-    print(f"    edited latent vs the oracle at the checkpoints before the first fork: {before}; inversion trajectory: {inv_err}")
-    assert before and all(v <= 1.5 * floor for v in before.values()), before
-    assert all(v <= 1.5 * floor for v in inv_err.values()), inv_err      # the forward pass has no choices: it must track the oracle to the end
-    if not flips:
-        assert e_big <= 1.5 * floor and e_big <= 1.5 * e_small
-    assert rel(big["out"][0], ref["out"][0]) <= 1e-5
+    floor = refs[0]["floors"][kind]["final_edit_rel_l2"]      # (the emulated reference-precision run exists for pair 0 only: tests/test_s50_gpu.py uses it for both)
+    eng = Engine(dtype=dt, max_unet_batch=4 * B, latent_size=L, max_img=B)
+    eng.load_synthetic(0)
+    try:
+        big = native_run(dt, S, L, 2, batch=B, engine=eng)
+        small = []
+        for k in range(0, B, 2):
+            small += native_run(dt, S, L, 2, batch=B, select=[k, k + 1], engine=eng)
+    finally:
+        eng.close()
+    forked, worst_gap, worst_unforked = [], 0.0, 0.0
+    for b in range(B):
+        diff = (big[b]["best"] != small[b]["best"]).nonzero().flatten().tolist()
+        if diff:
+            i = diff[0]                                          # the first fork: everything after it is another trajectory
+            ls = small[b]["losses"][i]
+            gap = float(abs(ls[int(big[b]["best"][i])] - ls[int(small[b]["best"][i])]) / ls[int(small[b]["best"][i])])
+            forked.append((b, i + 1, gap))
+            worst_gap = max(worst_gap, gap)
+        else:
+            worst_unforked = max(worst_unforked, rel(big[b]["out"][1], small[b]["out"][1]))
+        assert rel(big[b]["out"][0], small[b]["out"][0]) <= 1e-5   # the replayed source row
+    print(f"{kind}: S = 50, B = 32 vs the B = 2 calls of the same inputs: {len(forked)} of {B} images fork (image, backward step, relative loss gap of the two "
+          f"candidates in the B = 2 run): {[(b, st, f'{g:.1e}') for b, st, g in forked]}; images without a fork: edited latent within {worst_unforked:.2e} "
+          f"of their B = 2 run (floor {floor:.2e})")
+    assert worst_gap <= NEAR_TIE[kind], forked
+    assert worst_unforked <= 1.5 * floor
+    # How many images fork is a property of the precision, not of a kernel: measured in round 6 (MI355X), fp16 3 of 32 (gaps <= 4.6e-5), bf16 29 of 32 (gaps
+    # <= 2.5e-3 = a third of one bf16 ulp; ten candidates' losses lie within ~1 % of each other, and two bf16 executions of the UNet differ by ~1.2 x the
+    # reference-precision floor).  The fp16 count is bounded as a guard against a systematic difference; the bf16 count is reported.
+    if kind == "fp16":
+        assert len(forked) <= B // 4, forked
+    # ---- images 0 and 1 against the fp32 oracle traces
+    for b, ref in enumerate(refs):
+        e_small, e_big = rel(small[b]["out"][1], ref["out"][1]), rel(big[b]["out"][1], ref["out"][1])
+        cmp_big = compare(big[b], ref)
+        flips = cmp_big["best_of_n_flips"]
+        fl = floor
+        print(f"    image {b} vs the fp32 oracle: B = 2 run {e_small:.2e}, B = 32 run {e_big:.2e} (floor {fl:.2e}); best-of-n {cmp_big['best_of_n_agree']}/{S} {flips}")
+        first_fork = min([f["bwd_step"] for f in flips], default=S + 1)
+        assert all(f["oracle_rel_loss_gap"] <= NEAR_TIE[kind] for f in flips if f["bwd_step"] == first_fork), flips
+        # (checkpoints by STEP NUMBER: the committed trace keeps steps 1, 5, 10, 25, 50, the run more -- `compare`'s per_step rows pair them by position)
+        before = {s_: rel(big[b]["bwd"][big[b]["steps"].index(s_)][1], ref["bwd"][list(ref["steps"]).index(s_)][1])
+                  for s_ in ref["steps"] if s_ < first_fork and s_ in big[b]["steps"]}
+        inv_err = {s_: rel(big[b]["inv"][big[b]["steps"].index(s_)], ref["inv"][list(ref["steps"]).index(s_)]) for s_ in ref["steps"] if s_ in big[b]["steps"]}
+        assert before and all(v <= 1.5 * fl for v in before.values()), before
+        assert all(v <= 1.5 * fl for v in inv_err.values()), inv_err      # the forward pass has no choices: it must track the oracle to the end
+        if not flips:
+            assert e_big <= 1.5 * fl and e_big <= 1.5 * max(e_small, 0.5 * fl)
+        assert rel(big[b]["out"][0], ref["out"][0]) <= 1e-5
