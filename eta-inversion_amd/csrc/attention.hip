@@ -50,6 +50,9 @@ constexpr float NEG_BIG = -1.0e30f;
 #ifndef ATT_ABL
 #define ATT_ABL 0   // timing-only ablations of self_attn40_kernel (bit 0: no running maximum, 1: no exponentials, 2: no barrier, 3: no V fragment reads, 4: no K fragment reads): never in a product build
 #endif
+#ifndef ATT_SPEC_MAX
+#define ATT_SPEC_MAX 1   // A/B: 0 = the running maximum in every tile (rounds 2-5)
+#endif
 #ifndef ETAINV_QT40
 #define ETAINV_QT40 4
 #endif
@@ -547,21 +550,12 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
 
   float mref[QB];
   f32x16 o[QB][DT];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    mref[qb] = 0.f;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) o[qb][dt][i] = 0.f;
-  }
-
   const int ntiles = (N + KV - 1) / KV;
   const int nfull = N / KV;
-  load_kv(0);
-  store_kv(0);
-  __syncthreads();
 
+  // track = false (tiles after the first of the speculative pass, see below): no maximum, no decision -- m' stays what the first tile set.  A wave-uniform
+  // run-time flag (one scalar branch per tile): a compile-time variant of the tile body per pass made six copies of it and hipcc spilled 65 registers
+  bool track = true;
   auto tile_body = [&](int j, auto ragged_tag) {
     constexpr bool RAGGED = decltype(ragged_tag)::value;
     const int kv0 = j * KV, cur = j & 1;
@@ -625,6 +619,7 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
     }
 
     // ---- reference maximum: moves only when a query exceeds it by 2^THR (or on the first tile)
+    if (track || j == 0) {
     float mx[QB];
 #if ATT_ABL & 1
     if (j == 0)
@@ -667,6 +662,8 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
       }
     }
 
+    }   // track
+
     // ---- V^T fragments of the tile (shared by the query blocks), requested BEFORE the exponentials: 16 transposed reads whose LDS latency
     // is then covered by ~300 cycles of v_exp instead of standing in front of every MFMA
     // (all 22 LDS reads of the tile requested in front of the S MFMAs instead: 3.493 vs 3.476 ms, no gain -- the partner wave already covers the LDS latency)
@@ -697,8 +694,35 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
     __syncthreads();
 #endif
   };
-  for (int j = 0; j < nfull; ++j) tile_body(j, std::false_type{});
-  if (nfull < ntiles) tile_body(nfull, std::true_type{});
+  // Pass 0 is speculative: only tile 0 computes its maximum (m' = the exact maximum of the first 64 keys); the later tiles skip the 34 v_max3 + swap + ballot +
+  // branch per wave and tile (the round-6 ablation priced them at 7.5 % of the kernel: every instruction of this loop costs its issue time) and exponentiate
+  // against that m' whatever they hold.  That is exact as long as nothing overflows: P keeps its relative precision at any magnitude (bf16: up to 2^127; fp16: up
+  // to 2^16 above m'), O and the denominators accumulate in fp32.  If a score exceeds the first tile's maximum by more than that, P (fp16) or the sums overflow,
+  // the denominator row comes out non-finite, and the whole block repeats the pass with the running maximum of rounds 2-5 (pass 1): correct for every input,
+  // twice the time on the blocks that need it (attention rows of SD1.x: none seen; the jump tests of tests/test_kernels_gpu.py take this path).  Where the
+  // tracked pass would never have moved m', both passes are the same instructions on the same data.
+  for (int pass = (ATT_SPEC_MAX && ntiles >= 8) ? 0 : 1; pass < 2; ++pass) {   // (a few tiles: the tracked pass at once -- N = 256, d = 160: 0.132 vs 0.140 ms)
+    track = pass == 1;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      mref[qb] = 0.f;
+      if (h == GEO::MH) qf[qb][GEO::MS][0] = (T)0.f;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[qb][dt][i] = 0.f;
+    }
+    load_kv(0);
+    store_kv(0);
+    __syncthreads();
+    for (int j = 0; j < nfull; ++j) tile_body(j, std::false_type{});
+    if (nfull < ntiles) tile_body(nfull, std::true_type{});
+    if (pass == 1) break;
+    bool bad = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) bad |= !(fabsf(o[qb][GEO::LT][GEO::LI]) < 1.0e30f);   // (lanes that do not hold row D: another row's sum of the same P)
+    if (!__syncthreads_or(bad)) break;
+  }
 
   // ---- normalise and store: lane (query r, half h) holds dims (i&3) + 8(i>>2) + 4h (+32); the denominator is row 40 = tile 1, register 4, h = 0
 #pragma unroll

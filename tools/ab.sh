@@ -78,6 +78,20 @@ d=json.load(open('$OUT/pmcop_$name.json'))
 for k in d['kernels'][:3]:
     print(k['kernel'], k['launches']); print({a:b for a,b in k.items() if a not in ('kernel','raw','launches')}); print(k['raw'])
 " ;;
+    kstats)
+      # kstats <rows> [calls]: rocprofv3 --kernel-trace --stats of tools/unet_call.py at <rows> rows -> kernel_stats_rows<rows>.csv (per-kernel durations without event overhead)
+      local rows="${1:-4}" calls="${2:-20}"
+      rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_$rows -- python3 tools/unet_call.py --rows $rows --calls $calls --dtype fp16 > $OUT/kstats_$rows.log 2>&1
+      find $OUT/kstats_$rows -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_rows$rows.csv \;
+      rm -rf $OUT/kstats_$rows; python - <<PYEOF
+import csv
+rows=list(csv.DictReader(open("$OUT/kernel_stats_rows$rows.csv")))
+tot=sum(float(r["TotalDurationNs"]) for r in rows)
+print("kernels %d calls: total %.3f ms per call over $calls calls" % (sum(int(r["Calls"]) for r in rows), tot/1e6/$calls))
+for r in rows[:28]:
+    print("%7.1f us/call-of-unet %6d calls  avg %8.1f us  %5.1f%%  %s" % (float(r["TotalDurationNs"])/1e3/$calls, int(r["Calls"]), float(r["AverageNs"])/1e3, 100*float(r["TotalDurationNs"])/tot, r["Name"][:150]))
+PYEOF
+      ;;
     counters)
       rocprofv3 -L > $OUT/counters.txt 2>&1; grep -c . $OUT/counters.txt ;;
     opsenv2)
