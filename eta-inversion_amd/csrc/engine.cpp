@@ -1447,6 +1447,10 @@ extern "C" int etainv_op_layernorm(const void* x, const float* gamma, const floa
   return launch_layernorm(x, gamma, beta, out, rows, c, eps, dtype, (hipStream_t)stream);
 }
 
+#ifdef ETAINV_EXPERIMENTS
+extern "C" int etainv_experiments_built = 1;   // data symbol (not part of the ABI of include/etainv.h): tests of the opt-in experiments look for it
+#endif
+
 extern "C" int etainv_op_self_attention(const void* qkv, void* out, int b, int n, int heads, int d, int mode, int n_img, int dtype,
                                         void* stream) {
   return launch_self_attention_mode(qkv, out, b, n, heads, d, mode, n_img, dtype, (hipStream_t)stream);

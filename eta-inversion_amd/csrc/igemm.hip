@@ -1423,6 +1423,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p) {
   }
 }
 
+#ifndef ETAINV_EXPERIMENTS   // xsgemm.hip (stationary-activation GEMM, measured 22 % slower: profiles/HISTORY.md) is built by `EXPERIMENTS=1 build.sh` only
+bool xs_gemm_applicable(const IGemmParams&, int) { return false; }
+int launch_xs_gemm(const IGemmParams&, int, hipStream_t) { ETAINV_FAIL("xsgemm.hip is an experiment: build with EXPERIMENTS=1"); }
+#endif
+
 static int ring_min_tiles() {
   static const int v = getenv("ETAINV_RING_MIN_TILES") ? atoi(getenv("ETAINV_RING_MIN_TILES")) : 192;
   return v;

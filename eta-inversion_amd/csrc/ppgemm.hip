@@ -1,3 +1,5 @@
+// THE PRODUCT KERNEL OF THIS FILE IS pp_dualn_kernel (second half: "Dual-N ping-pong GEMM").  The first half documents and -- under EXPERIMENTS=1 only -- builds its
+// round-5 predecessor, the double-accumulator ping-pong GEMM (3-10 % on a class it no longer serves; measurements: profiles/HISTORY.md, r05_pp_gemm_check.log):
 // Ping-pong GEMM for the short-K 1x1 / Linear layers of the transformer blocks (gfx950): the 256 x 160 x 64 tile of igemm.hip's ring with
 //   (1) its two wave groups in ANTI-PHASE, one fragment set per wave, and
 //   (2) TWO accumulator sets: the epilogue of tile t runs in slices inside the memory phases of tile t + 1.
@@ -59,6 +61,9 @@ template <> struct PMfma<bf16> {
 #define PP_LGKMCNT0() __builtin_amdgcn_s_waitcnt(0xC07F)
 #define PP_GLDS(src, dst, bytes) \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), bytes, 0, 0)
+// one LDS-DMA piece: scalar base + a per-lane 32-bit byte offset, M0 = the LDS destination written in the statement that uses it (see pp_gemm_kernel's issue side)
+#define PP_DMA(BYTES_INSN, voff32, sbase, ldsaddr) \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t" BYTES_INSN " %0, %1" : : "v"(voff32), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(ldsaddr)) : "memory")
 
 constexpr int PBM = 256, PBN = 160, PBK = 64;
 constexpr int PMT = 4, PNT = 5;                 // wave tile 64 x 80 (4 x 2 waves)
@@ -66,6 +71,7 @@ constexpr int PA_BYTES = PBM * PBK * 2, PB_BYTES = PBN * PBK * 2;   // one ring 
 constexpr int POFF_B = 3 * PA_BYTES, POFF_DUMMY = POFF_B + 3 * PB_BYTES, POFF_BIAS = POFF_DUMMY + 1024;
 constexpr int PLDS = POFF_BIAS + 4 * PBN * 4;
 
+#ifdef ETAINV_EXPERIMENTS   // the double-accumulator kernel of the header comment: opt-in experiment, built by `EXPERIMENTS=1 build.sh` only
 // ---- the slice schedule and the counted waits derived from it.  Slice i (row group i of the previous tile) rides in MEM phase ph = i of the next tile:
 //   [residual: five 8-byte loads of the row group]  [the phase's DMA pieces]  [wait: the loads have landed, the pieces stay in flight]  [bias, residual,
 //   convert, lane swap, three stores (+ one for the LayerNorm row statistics)]  [fragment reads]
@@ -119,8 +125,6 @@ __global__ void __launch_bounds__(512, 2) pp_gemm_kernel(IGemmParams p) {
   // hipcc's loop optimisations widen the lane offsets to 64-bit register pairs and rebuild a 64-bit address per piece -- 10 more registers and, once those
   // spill, scratch reloads with vmcnt(0) inside the loop.)  No register destination: nothing for the compiler to mis-time; M0 is written in the statement
   // that uses it and nothing else in this kernel uses M0.
-#define PP_DMA(BYTES_INSN, voff32, sbase, ldsaddr) \
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t" BYTES_INSN " %0, %1" : : "v"(voff32), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(ldsaddr)) : "memory")
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
   const char* a_base = nullptr;
   const char* w_base = nullptr;
@@ -399,6 +403,8 @@ __global__ void __launch_bounds__(512, 2) pp_gemm_kernel(IGemmParams p) {
   if (!late) __builtin_amdgcn_s_barrier();
 }
 
+
+#endif   // ETAINV_EXPERIMENTS
 
 // ============================================================================================================================================================
 // Dual-N ping-pong GEMM: 256 x 320 output tile as TWO 160-column halves that share one activation K tile.
@@ -898,6 +904,7 @@ __global__ void __launch_bounds__(512, 2) pp_dualn_kernel(IGemmParams p) {
 
 }  // namespace
 
+#ifdef ETAINV_EXPERIMENTS
 // 1x1 / Linear launches on whole tiles with K >= 320 and a bias-only epilogue.  OPT-IN (ETAINV_PP=1), measured on MI355X (profiles/r05_pp_gemm_check.log):
 // bit-identical to the ring kernel and 3-10 % faster on the shapes it takes -- but the layers that matter carry a residual (+ LayerNorm statistics), and
 // the residual needs register-destination loads that hipcc must not count: every form of inline asm with a VGPR output inside the slice makes the
@@ -912,6 +919,10 @@ bool pp_gemm_applicable(const IGemmParams& p, int dtype) {
   if (p.M % PBM != 0 || p.N % PBN != 0 || p.c1 % PBK != 0 || p.c1 < 5 * PBK) return false;
   return (int64_t)(p.M / PBM) * (p.N / PBN) >= 512;   // at least two tiles per block: the overlapped epilogue is the point
 }
+
+#else
+bool pp_gemm_applicable(const IGemmParams&, int) { return false; }   // (the default library does not carry the double-accumulator experiment)
+#endif
 
 // dual-N kernel: 1x1 / Linear on whole tiles -- 256 x 320 with bias (+ residual) (+ LayerNorm row statistics) or as a LayerNorm consumer (row-major or
 // head-major QKV planes), 256 x 256 for the LayerNorm-consumer GEGLU projection; ETAINV_DUALN=0 switches it off.  Returns the epilogue kind or -1
@@ -983,6 +994,7 @@ int launch_pp_dualn(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat
   return 0;
 }
 
+#ifdef ETAINV_EXPERIMENTS
 int launch_pp_gemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P) {
   IGemmParams p = p_in;
   if (p.stat_out) p.stat_P = p.N / 80;              // one (mean, M2) partial per row and wave-tile column, as the ring kernel
@@ -1013,5 +1025,9 @@ int launch_pp_gemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_
   ETAINV_LAUNCH_CHECK();
   return 0;
 }
+
+#else
+int launch_pp_gemm(const IGemmParams&, int, hipStream_t, int*) { ETAINV_FAIL("pp_gemm_kernel is an experiment: build with EXPERIMENTS=1"); }
+#endif
 
 }  // namespace etainv

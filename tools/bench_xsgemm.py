@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B of the K = 320 LayerNorm-consumer projections (GEGLU ff.net.0, fused QKV) on csrc/xsgemm.hip vs the ring kernel of csrc/igemm.hip, same box,
 same process (ETAINV_XSGEMM is read per launch).  GPU box only.
-    python tools/bench_xsgemm.py [--rows 128] [--dtype bf16]"""
+    python tools/bench_xsgemm.py [--rows 128] [--dtype bf16]
+(round 6: xsgemm.hip is in the EXPERIMENTS=1 library only: ETAINV_LIB=eta-inversion_amd/etainv/lib/libetainv_hip_experiments.so python tools/bench_xsgemm.py)"""
 import argparse
 import os
 import sys

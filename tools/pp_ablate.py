@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Timing-only ablations of the ping-pong GEMM vs the ring (ETAINV_IGEMM_DEBUG bits: 1 no DMA in the loop, 2 no epilogue, 4 no MFMA; 256 no fragment reads existed in the round-5 prototype that produced profiles/r05_pp_ablation.log)."""
+"""Timing-only ablations of the ping-pong GEMM vs the ring (ETAINV_IGEMM_DEBUG bits: 1 no DMA in the loop, 2 no epilogue, 4 no MFMA; 256 no fragment reads existed in the round-5 prototype that produced profiles/r05_pp_ablation.log).
+(round 6: pp_gemm_kernel is in the EXPERIMENTS=1 library only: run with ETAINV_LIB=eta-inversion_amd/etainv/lib/libetainv_hip_experiments.so)"""
 import os
 import sys
 from pathlib import Path

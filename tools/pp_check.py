@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Ping-pong GEMM (ppgemm.hip, opt-in: ETAINV_PP=1; ETAINV_PP_FORCE_ALL=1 also takes the residual / statistics variants, which spill) against the ring kernel on the same inputs: equality and time.  GPU box only.
-    python tools/pp_check.py [dualn] [res] [stat]     # dualn: the dual-N kernel (ETAINV_DUALN) instead; which epilogue variants to include"""
+    python tools/pp_check.py [dualn] [res] [stat]     # dualn: the dual-N kernel (ETAINV_DUALN) instead; which epilogue variants to include
+(round 6: pp_gemm_kernel (ETAINV_PP=1) is in the EXPERIMENTS=1 library only (ETAINV_LIB=.../libetainv_hip_experiments.so); the dual-N modes run on the default library)"""
 import ctypes as C
 import os
 import sys
