@@ -7,6 +7,8 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG; mkdir -p $O
 python bench.py > $O/bench_default_invocation.json 2> $O/bench_default.err
 bash tools/ab.sh $TAG stats -- shapes 128 -- routes 128 -- traffic -- sq
+# the single-image path (BASELINE config 2: UNet calls of 1 .. 4 rows) and config 5's shapes (32 rows at L = 96): per-launch tables and kernel-level durations
+bash tools/ab.sh $TAG routes 4 -- routes 1 -- kstats 4 20 -- kstats 1 20 -- shapes 32 96 -- shapes 32 -- ops self-attn
 python bench.py --config 5 --no-cpu-baseline > $O/bench_cfg5.json 2>/dev/null
 python bench.py --config 2 --no-cpu-baseline > $O/bench_cfg2.json 2>/dev/null
 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_cfg3_again.json 2>/dev/null
