@@ -76,6 +76,25 @@ __global__ void __launch_bounds__(512) k(float* out, long long* cyc, int iters) 
         REP8(MF_A(acc0)) MF_A(acc1) MF_A(acc1) MF_A(acc1) MF_A(acc1)
         REP8(MF_A(acc0) VALU6)
       }
+    } else if (MODE >= 20 && MODE <= 24) {   // INDEPENDENT fillers (sources never written): per MFMA  MODE 20: 2 exp + 1 cvt; 21: 3 exp + 1 cvt; 22: 2 exp + 1 cvt + 1 max3; 23: 9 exp + 4 cvt per 4 MFMAs (the d = 40 ratio); 24: 32 independent exps, no MFMA
+#define EXI(d, s_) "v_exp_f32 %" #d ", %" #s_ "\n"
+      float b0 = a[0], b1 = a[1], b2 = a[2], b3 = a[3], b4 = a[4], b5 = a[5], b6 = a[6], b7 = a[7];
+      float c0, c1, c2, c3, c4, c5, c6, c7, c8;
+      if (MODE == 20) {
+        REP8(MF_V(acc0) asm volatile("v_exp_f32 %0, %3\n v_exp_f32 %1, %4\n v_cvt_pk_bf16_f32 %2, %5, %6" : "=v"(c0), "=v"(c1), "=v"(c2) : "v"(b0), "v"(b1), "v"(b2), "v"(b3));)
+      } else if (MODE == 21) {
+        REP8(MF_V(acc0) asm volatile("v_exp_f32 %0, %4\n v_exp_f32 %1, %5\n v_exp_f32 %2, %6\n v_cvt_pk_bf16_f32 %3, %7, %4" : "=v"(c0), "=v"(c1), "=v"(c2), "=v"(c3) : "v"(b0), "v"(b1), "v"(b2), "v"(b3));)
+      } else if (MODE == 22) {
+        REP8(MF_V(acc0) asm volatile("v_exp_f32 %0, %4\n v_exp_f32 %1, %5\n v_cvt_pk_bf16_f32 %2, %6, %7\n v_max3_f32 %3, %4, %5, %6" : "=v"(c0), "=v"(c1), "=v"(c2), "=v"(c3) : "v"(b0), "v"(b1), "v"(b2), "v"(b3));)
+      } else if (MODE == 23) {
+        REP8(MF_V(acc0) asm volatile("v_exp_f32 %0, %3\n v_exp_f32 %1, %4\n v_cvt_pk_bf16_f32 %2, %5, %6" : "=v"(c0), "=v"(c1), "=v"(c2) : "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+             MF_V(acc1) asm volatile("v_exp_f32 %0, %3\n v_exp_f32 %1, %4\n v_cvt_pk_bf16_f32 %2, %5, %6" : "=v"(c3), "=v"(c4), "=v"(c5) : "v"(b4), "v"(b5), "v"(b6), "v"(b7));
+             MF_V(acc0) asm volatile("v_exp_f32 %0, %3\n v_exp_f32 %1, %4\n v_cvt_pk_bf16_f32 %2, %5, %6" : "=v"(c0), "=v"(c1), "=v"(c2) : "v"(b1), "v"(b2), "v"(b3), "v"(b4));
+             MF_V(acc1) asm volatile("v_exp_f32 %0, %4\n v_exp_f32 %1, %5\n v_exp_f32 %2, %6\n v_cvt_pk_bf16_f32 %3, %7, %4" : "=v"(c5), "=v"(c6), "=v"(c7), "=v"(c8) : "v"(b5), "v"(b6), "v"(b7), "v"(b0));)
+      } else {
+        REP8(asm volatile("v_exp_f32 %0, %4\n v_exp_f32 %1, %5\n v_exp_f32 %2, %6\n v_exp_f32 %3, %7" : "=v"(c0), "=v"(c1), "=v"(c2), "=v"(c3) : "v"(b0), "v"(b1), "v"(b2), "v"(b3));)
+      }
+      a[0] += 0.f;
     } else if (MODE == 9) {   // per MFMA: 1 v_exp + 6 plain VALU
       REP8(acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc0, 0, 0, 0);
            asm volatile("v_exp_f32 %0, %0\n v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n v_fma_f32 %7, %7, %7, %7\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));)
@@ -129,6 +148,11 @@ int main() {
     run<5>("8 x (MFMA + 4 v_exp + 2 v_cvt_pk)", 8, threads);
     run<6>("8 x (MFMA + 2 v_exp + 1 v_cvt_pk)", 8, threads);
     run<9>("8 x (MFMA + 1 v_exp + 6 v_fma)", 8, threads);
+    run<24>("32 INDEPENDENT v_exp_f32", 32, threads);
+    run<20>("8 x (MFMA + 2 exp + 1 cvt), independent", 8, threads);
+    run<21>("8 x (MFMA + 3 exp + 1 cvt), independent", 8, threads);
+    run<22>("8 x (MFMA + 2 exp + 1 cvt + 1 max3), independent", 8, threads);
+    run<23>("32 x (MFMA + 2.25 exp + 1 cvt), independent (d = 40 ratio)", 32, threads);
     if (threads == 512) {
       run<10>("waves 0-3: 8 MFMA | waves 4-7: 32 exp + 16 cvt", 1, threads);
       run<11>("waves 0-3: 8 MFMA | waves 4-7: 32 fma", 1, threads);
