@@ -95,6 +95,23 @@ __global__ void __launch_bounds__(512) k(float* out, long long* cyc, int iters) 
         REP8(asm volatile("v_exp_f32 %0, %4\n v_exp_f32 %1, %5\n v_exp_f32 %2, %6\n v_exp_f32 %3, %7" : "=v"(c0), "=v"(c1), "=v"(c2), "=v"(c3) : "v"(b0), "v"(b1), "v"(b2), "v"(b3));)
       }
       a[0] += 0.f;
+    } else if (MODE == 25 || MODE == 26) {   // the P V chain of the attention tile: 8 exp -> 4 cvt_pk -> the B operand of 2 MFMAs; 25: in that order, 26: the next group's exps between the converts and the MFMAs
+      float b0 = a[0], b1 = a[1], b2 = a[2], b3 = a[3], b4 = a[4], b5 = a[5], b6 = a[6], b7 = a[7];
+      float e0, e1, e2, e3, e4, e5, e6, e7;
+      typedef unsigned u4 __attribute__((ext_vector_type(4)));
+      u4 pk;
+#define EXP8 asm volatile("v_exp_f32 %0, %8\n v_exp_f32 %1, %9\n v_exp_f32 %2, %10\n v_exp_f32 %3, %11\n v_exp_f32 %4, %12\n v_exp_f32 %5, %13\n v_exp_f32 %6, %14\n v_exp_f32 %7, %15" \
+                          : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(e4), "=&v"(e5), "=&v"(e6), "=&v"(e7) : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(b4), "v"(b5), "v"(b6), "v"(b7));
+#define CVT4 asm volatile("v_cvt_pk_bf16_f32 %0, %4, %5\n v_cvt_pk_bf16_f32 %1, %6, %7\n v_cvt_pk_bf16_f32 %2, %8, %9\n v_cvt_pk_bf16_f32 %3, %10, %11" \
+                          : "=&v"(pk[0]), "=&v"(pk[1]), "=&v"(pk[2]), "=&v"(pk[3]) : "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(e4), "v"(e5), "v"(e6), "v"(e7));
+#define MF2P asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n v_mfma_f32_32x32x16_bf16 %1, %2, %3, %1" : "+v"(acc0), "+v"(acc1) : "v"(y), "v"(pk));
+      if (MODE == 25) {
+        EXP8 CVT4 MF2P  EXP8 CVT4 MF2P  EXP8 CVT4 MF2P  EXP8 CVT4 MF2P
+      } else {
+        if (it == 0) { EXP8 }
+        CVT4 EXP8 MF2P  CVT4 EXP8 MF2P  CVT4 EXP8 MF2P  CVT4 EXP8 MF2P
+      }
+      a[0] += e0 * 0.f;
     } else if (MODE == 9) {   // per MFMA: 1 v_exp + 6 plain VALU
       REP8(acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc0, 0, 0, 0);
            asm volatile("v_exp_f32 %0, %0\n v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n v_fma_f32 %7, %7, %7, %7\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));)
@@ -153,6 +170,8 @@ int main() {
     run<21>("8 x (MFMA + 3 exp + 1 cvt), independent", 8, threads);
     run<22>("8 x (MFMA + 2 exp + 1 cvt + 1 max3), independent", 8, threads);
     run<23>("32 x (MFMA + 2.25 exp + 1 cvt), independent (d = 40 ratio)", 32, threads);
+    run<25>("8 MFMAs fed by 32 exp -> 16 cvt (P V chain, program order)", 8, threads);
+    run<26>("8 MFMAs fed by 32 exp -> 16 cvt (next group's exps in front of the MFMAs)", 8, threads);
     if (threads == 512) {
       run<10>("waves 0-3: 8 MFMA | waves 4-7: 32 exp + 16 cvt", 1, threads);
       run<11>("waves 0-3: 8 MFMA | waves 4-7: 32 fma", 1, threads);
