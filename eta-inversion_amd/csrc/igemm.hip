@@ -1429,7 +1429,7 @@ int launch_xs_gemm(const IGemmParams&, int, hipStream_t) { ETAINV_FAIL("xsgemm.h
 #endif
 
 static int ring_min_tiles() {
-  static const int v = getenv("ETAINV_RING_MIN_TILES") ? atoi(getenv("ETAINV_RING_MIN_TILES")) : 192;
+  static const int v = getenv("ETAINV_RING_MIN_TILES") ? atoi(getenv("ETAINV_RING_MIN_TILES")) : 144;
   return v;
 }
 
@@ -1483,7 +1483,7 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   if (p.hm_heads) p.hm_magic = (int)(((1ull << 38) + (unsigned)p.hm_tokens - 1) / (unsigned)p.hm_tokens);   // m0 / hm_tokens == (m0 * magic) >> 38 for m0 < 2^24, hm_tokens <= 2^14
   static const bool trace = env_on("ETAINV_TRACE_IGEMM");   // one line per launch on stderr, in launch order (tools/unet_call.py --shapes joins it with the event times)
   if (trace) {
-    const bool ring = !p.geglu && !p.ups && p.N % 160 == 0 && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 160) >= 192;
+    const bool ring = !p.geglu && !p.ups && p.N % 160 == 0 && (int64_t)cdiv(p.M, 256) * cdiv(p.N, 160) >= ring_min_tiles();
     fprintf(stderr, "igemm M=%d N=%d c1=%d c2=%d taps=%d stride=%d ups=%d H=%d W=%d geglu=%d ln=%d stat=%d res=%d rowvec=%d hm=%d route=%s\n", p.M, p.N, p.c1, p.c2, p.taps,
             p.stride, p.ups, p.H, p.W, (int)p.geglu, p.ln_stat ? 1 : 0, p.stat_out ? p.stat_kind : 0, p.residual ? 1 : 0, p.rowvec ? 1 : 0, p.hm_heads,
             pp_conv_applicable(p, dtype) ? "ppconv" : pp_dualn_applicable(p, dtype) ? "dualn" : pp_gemm_applicable(p, dtype) ? "ppgemm" : xs_gemm_applicable(p, dtype) ? "xs" :
@@ -1523,7 +1523,9 @@ int launch_igemm(const IGemmParams& p_in, int dtype, hipStream_t s, int* stat_P)
   // (ring from `ring_min` 256 x 160 tiles on.  256 = one per CU was the round-2 threshold; the 96-row backward calls of round 3 bring 192 tiles at the
   // 8 x 8 level, where the ring on 3/4 of the CUs still beats the two-slot 128 x 160 kernel: same-box bench 4.897 (256) / 4.937 (192) / 4.910 (128)
   // images/s.  ETAINV_RING_MIN_TILES tunes it)
-  static const int ring_min = getenv("ETAINV_RING_MIN_TILES") ? atoi(getenv("ETAINV_RING_MIN_TILES")) : 192;
+  // Round 6: 144.  Config 5's 12 x 12 level at 32 rows is 18 x 8 = 144 tiles (1280 -> 1280 convs with 180 K tiles: 599 TFLOP/s on the two-slot kernel): same-box
+  // bench config 5 0.7583 (192) / 0.7697 (144) / 0.7674 (128) / 0.7677 (96) images/s, config 3 5.801 (192) / 5.797 (128): profiles/r06_ring_min_tiles_ab.log)
+  static const int ring_min = ring_min_tiles();
   if (!p.geglu && p.ups == 2) {
     p.ups_pm = (p.H * p.W) % 256 != 0;
     // conv3x3 behind a nearest-2x upsample as four 2 x 2 phase convs (4 / 9 of the FLOPs): its own instantiation of the ring (row decode, output scatter)
