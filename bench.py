@@ -401,27 +401,16 @@ def main():
     # A file is used only when its `kernel_src_sha16` (tools/srcstamp.py: hash of csrc/ + include/etainv.h, written by the aggregators) equals that of the
     # sources this run was built from; otherwise the field is null and `*_source` says which file was stale.
     sys.path.insert(0, str(ROOT / "tools"))
-    from srcstamp import kernel_src_sha16
+    from srcstamp import kernel_src_sha16, stamped_figure
     src_sha = kernel_src_sha16()
-    traffic, traffic_src = None, None
-    for cand in (sorted((ROOT / "profiles").glob("r*_pmc_traffic_rows128.json"), reverse=True) if 4 * B == 128 else []):
-        d = json.load(open(cand))
-        if d.get("kernel_src_sha16") == src_sha:
-            traffic, traffic_src = d["igemm"]["hbm_bytes_per_launch"], f"profiles/{cand.name} (one 128-row UNet call, same kernel sources {src_sha})"
-        else:
-            traffic_src = f"stale: profiles/{cand.name} was taken on kernel sources {d.get('kernel_src_sha16', 'unstamped')}, this run is {src_sha}"
-        break
-    # matrix-pipe busy share of the same kernels from the SQ counters (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE over tools/unet_call.py
-    # --rows 128, aggregated by tools/pmc_sq.py): file-sourced like `traffic`, named in the JSON
-    mfma_busy, mfma_busy_src = None, None
-    for cand in (sorted((ROOT / "profiles").glob("r*_pmc_sq_rows128.json"), reverse=True) if 4 * B == 128 else []):
-        d = json.load(open(cand))
-        fam = d.get("summary", {}).get("igemm_family")
-        if d.get("kernel_src_sha16") != src_sha:
-            mfma_busy_src = f"stale: profiles/{cand.name} was taken on kernel sources {d.get('kernel_src_sha16', 'unstamped')}, this run is {src_sha}"
-        elif fam and fam.get("mfma_busy_frac") is not None:
-            mfma_busy, mfma_busy_src = fam["mfma_busy_frac"], f"profiles/{cand.name} (one 128-row UNet call, cycle-weighted over the implicit-GEMM kernels, same kernel sources {src_sha})"
-        break
+    traffic = traffic_src = mfma_busy = mfma_busy_src = None
+    if 4 * B == 128:
+        traffic, traffic_src = stamped_figure(ROOT / "profiles", "r*_pmc_traffic_rows128.json", src_sha, lambda d: d.get("igemm", {}).get("hbm_bytes_per_launch"),
+                                              "fabric bytes per implicit-GEMM launch of one 128-row UNet call")
+        # matrix-pipe busy share of the same kernels from the SQ counters (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE over tools/unet_call.py
+        # --rows 128, aggregated by tools/pmc_sq.py): file-sourced like `traffic`, named in the JSON
+        mfma_busy, mfma_busy_src = stamped_figure(ROOT / "profiles", "r*_pmc_sq_rows128.json", src_sha, lambda d: (d.get("summary", {}).get("igemm_family") or {}).get("mfma_busy_frac"),
+                                                  "cycle-weighted MFMA-busy share of the implicit-GEMM kernels over one 128-row UNet call")
     images = B * world * a.steps
     value = images / dt
     # MFMA FLOPs the kernels EXECUTED per image (implicit GEMMs + both attentions of the profiled step: the launchers record 2 M N K / 4 B h N^2 d

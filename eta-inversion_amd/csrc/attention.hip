@@ -1068,6 +1068,10 @@ int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int hea
   }
   ETAINV_CHECK(!q_prescaled || d == 40 || d == 80, "pre-scaled queries: head_dim 40 / 80 only");
   ETAINV_CHECK(!q_prescaled || self_attn40_v2_enabled(), "pre-scaled queries need the d = 40 kernel");
+  if (d == 40 && self_attn40_v2_enabled() && (int64_t)cdiv(n, 256) * heads * b <= 256 && n > 128) {
+    // few blocks (single-image calls: N = 4096, 8 heads, 1 row = 128 blocks of 256 queries on 256 CUs): one 32-query block per wave, twice the blocks
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 40, 1, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s, first_row, head_major)));
+  }
   if (d == 40 && self_attn40_v2_enabled()) {
     // two 32-query blocks per wave, 2 waves per SIMD (one block per wave with 3 / 4 waves per SIMD: +10 % / +52 % time, re-measured in round 6 on the lean staging:
     // profiles/r06_attention_experiments.log)

@@ -60,3 +60,26 @@ def test_launch_table_joins_the_trace_with_the_event_times(tmp_path):
     assert "x  2" in lines[1] and "2000.0 TF/s" in lines[1] and lines[1].endswith("route=ppconv")
     assert any(l.startswith("route ppconv") and "80.0%" in l for l in lines)
     assert any(l.startswith("route dualn") and "20.0%" in l for l in lines)
+
+
+def test_counter_figures_are_reported_only_for_the_sources_they_were_taken_on(tmp_path):
+    """bench.py's `roofline.traffic` / `mfma_busy_frac` are read from committed PMC summaries; a summary taken on other kernel sources must come back as
+    null + a `stale:` note, never as a number (tools/srcstamp.py)."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    from srcstamp import kernel_src_sha16, stamped_figure
+    sha = kernel_src_sha16()
+    assert len(sha) == 16 and sha == kernel_src_sha16()
+    pick = lambda d: d.get("igemm", {}).get("hbm_bytes_per_launch")
+    (tmp_path / "r01_pmc_traffic_rows128.json").write_text(json.dumps({"igemm": {"hbm_bytes_per_launch": 1.0}, "kernel_src_sha16": sha}))
+    assert stamped_figure(tmp_path, "r*_pmc_traffic_rows128.json", sha, pick, "x")[0] == 1.0
+    (tmp_path / "r02_pmc_traffic_rows128.json").write_text(json.dumps({"igemm": {"hbm_bytes_per_launch": 2.0}, "kernel_src_sha16": "0" * 16}))
+    v, note = stamped_figure(tmp_path, "r*_pmc_traffic_rows128.json", sha, pick, "x")     # the NEWEST file decides: no silent fall-back to an older round's number
+    assert v is None and note.startswith("stale: profiles/r02_pmc_traffic_rows128.json")
+    (tmp_path / "r03_pmc_traffic_rows128.json").write_text(json.dumps({"igemm": {"hbm_bytes_per_launch": 3.0}}))
+    v, note = stamped_figure(tmp_path, "r*_pmc_traffic_rows128.json", sha, pick, "x")
+    assert v is None and "unstamped" in note
+    assert stamped_figure(tmp_path, "nothing*.json", sha, pick, "x") == (None, None)
+    # the aggregators stamp their output
+    _counter_csv(tmp_path / "p1.csv", lambda busy: {"GRBM_GUI_ACTIVE": 8000.0, "SQ_VALU_MFMA_BUSY_CYCLES": busy * 1024.0})
+    out = subprocess.run([sys.executable, str(ROOT / "tools" / "pmc_sq.py"), str(tmp_path / "p1.csv")], capture_output=True, text=True, check=True)
+    assert json.loads(out.stdout)["kernel_src_sha16"] == sha
