@@ -886,6 +886,37 @@ def test_self_attention_d40_maximum_jumps_late(capi):
     assert relerr(out[0, [5, 130, 200]], ref[0, [5, 130, 200]]) < 2 * TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_self_attention_d40_speculative_maximum(capi, dtype):
+    """Round 6: from 8 key tiles on, only tile 0 computes the reference maximum; later tiles exponentiate against it, and a block whose denominators come out
+    non-finite repeats its pass with the running maximum (attention.hip, self_attn40_kernel).  N = 2048 (32 tiles), four regimes in ONE launch, each in its own
+    (batch row, head) so that blocks of both kinds run side by side:  row 0 plain;  row 1: late keys 2^6 .. 2^12 above the first tile's maximum for some queries
+    (the tracked pass would move m', the speculative one keeps P large: no overflow in either dtype);  row 2: one late key ~2^40 above it (fp16 P overflows ->
+    fallback; bf16 stays finite);  row 3: the first tile far BELOW everything else for every query (all of P large)."""
+    lib = capi.load()
+    b, heads, n, d = 4, 8, 2048, 40
+    qkv = rnd(b, n, 3 * heads * d, seed=123, dtype=dtype)
+    q, k = qkv[..., : heads * d], qkv[..., heads * d: 2 * heads * d]
+    sc = 1.0 / (d ** 0.5)
+    def boost(row, head, key, query, log2_gain):
+        # make score(query, key) of (row, head) ~ log2_gain * ln 2 above that query's typical maximum: k := q * t with t = gain / (|q|^2 * scale)
+        qv = q[row, query, head * d:(head + 1) * d].float()
+        t = (log2_gain * 0.6931 + 6.0) / (float(qv @ qv) * sc)
+        k[row, key, head * d:(head + 1) * d] = (qv * t).to(dtype)
+    for i, (key, g) in enumerate([(700, 6), (1300, 9), (2000, 12), (1999, 8)]):
+        boost(1, i % heads, key, 64 * i + 7, g)
+    boost(2, 3, 1500, 300, 40)
+    k[3, :64] = (k[3, :64] * 0.02).to(dtype)
+    q[3] = (q[3] * 3).to(dtype)                      # sharper rows: the first tile's maximum sits well below the later tiles'
+    out = torch.empty(b, n, heads * d, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_self_attention(capi.ptr(qkv), capi.ptr(out), b, n, heads, d, 0, 1, capi.dtype_code(dtype), capi.stream_ptr()))
+    ref = ref_self_attention(qkv, heads)
+    assert torch.isfinite(out).all()
+    for row in range(b):
+        assert relerr(out[row], ref[row]) < 1.5 * TOL[dtype], row
+    assert relerr(out[2, 300, 3 * d:4 * d], ref[2, 300, 3 * d:4 * d]) < 2 * TOL[dtype]     # the query whose key forced the fallback pass in fp16
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_self_attention_d40_remaps(capi, mode, dtype):
