@@ -771,7 +771,19 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, q4 = lane >> 4;
-  const int b = row0 + blockIdx.z, h = blockIdx.y;
+  // block -> (query-block lane bx of gx, head, batch row).  p.xcd_gx > 0: a 1-D grid whose ids are dealt so that the eight heads of one (row, query range) have the
+  // same id modulo 8, i.e. run on ONE XCD (round-robin dispatch) at about the same time: a head's q / out rows are 80-byte (head_dim 40) pieces of 640-byte token rows,
+  // and with the heads on eight XCDs every L2 fetched every line (PMC: 661 MB per launch at the fabric, twice the algorithmic bytes).  Speed only.
+  int bx = blockIdx.x, gxn = gridDim.x, h = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_gx > 0) {
+    const int lin = blockIdx.x, xcd = lin & 7, t = lin >> 3;
+    h = t % p.heads;
+    const int c = (t / p.heads) * 8 + xcd;
+    gxn = p.xcd_gx;
+    bx = c % gxn;
+    bz = c / gxn;
+  }
+  const int b = row0 + bz;
   const int N = p.N, C = p.heads * D, C2 = 2 * C;
 
   int img = 0, role = -1, is_cond = 0;
@@ -849,8 +861,8 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
       }
     }
   };
-  if (blockIdx.x * (64 * QT) < N) load_block(blockIdx.x);
-  for (int qb = blockIdx.x; qb * (64 * QT) < N; qb += gridDim.x) {
+  if (bx * (64 * QT) < N) load_block(bx);
+  for (int qb = bx; qb * (64 * QT) < N; qb += gxn) {
   u32x4 qc[QPF ? QT : 1][QPF ? 2 : 1][QPF ? KS : 1];
   if constexpr (QPF) {
 #pragma unroll
@@ -859,7 +871,7 @@ __global__ void __launch_bounds__(256) cross_attn_kernel(const T* __restrict__ q
       for (int e = 0; e < 2; ++e)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qc[qt][e][ks] = qn[qt][e][ks];
-    if ((qb + (int)gridDim.x) * (64 * QT) < N) load_block(qb + gridDim.x);
+    if ((qb + gxn) * (64 * QT) < N) load_block(qb + gxn);
   }
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
@@ -1112,10 +1124,17 @@ static int launch_cross_t(const void* q, const void* kv, void* out, int b, const
   const int nqb = cdiv(p.N, 64 * QT);
   auto launch = [&](bool edit, int row0, int rows) {
     const int gx = std::max(1, std::min(nqb, cdiv(2048, rows * p.heads)));   // ~2048+ blocks in flight, K/V staging amortised
+    static const bool xcd_heads = env_flag("ETAINV_CROSS_XCD", true);
+    CrossParams pl = p;
+    dim3 grid(gx, p.heads, rows);
+    if (xcd_heads && (gx * rows) % 8 == 0) {   // the heads of a (row, query range) on one XCD (see the kernel)
+      pl.xcd_gx = gx;
+      grid = dim3(gx * p.heads * rows);
+    }
     if (edit)
-      hipLaunchKernelGGL((cross_attn_kernel<T, D, QT, true>), dim3(gx, p.heads, rows), dim3(256), lds_edit, s, (const T*)q, (const T*)kv, (T*)out, p, row0);
+      hipLaunchKernelGGL((cross_attn_kernel<T, D, QT, true>), grid, dim3(256), lds_edit, s, (const T*)q, (const T*)kv, (T*)out, pl, row0);
     else
-      hipLaunchKernelGGL((cross_attn_kernel<T, D, QT, false>), dim3(gx, p.heads, rows), dim3(256), lds_plain, s, (const T*)q, (const T*)kv, (T*)out, p, row0);
+      hipLaunchKernelGGL((cross_attn_kernel<T, D, QT, false>), grid, dim3(256), lds_plain, s, (const T*)q, (const T*)kv, (T*)out, pl, row0);
   };
   if (p.edit && p.layout == 2) {          // rows [u_s, u_t, c_s, c_t] x n_img: only the last quarter (cond target) is edited
     const int edit0 = 3 * p.n_img - p.first_row;   // first cond-target row of this call

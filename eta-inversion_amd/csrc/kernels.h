@@ -145,6 +145,7 @@ struct CrossParams {
   const float* equalizer = nullptr;
   const float* cross_alpha = nullptr;
   float* maps_acc = nullptr;
+  int xcd_gx = 0;      // > 0: 1-D grid with the heads of one (row, query range) on one XCD; the value = query-block lanes per (row, head) (attention.hip)
 };
 int launch_cross_attention_p(const void* q, const void* kv, void* out, int b, int d, const CrossParams& p, int dtype, hipStream_t s);
 
