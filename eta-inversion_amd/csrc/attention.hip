@@ -1124,7 +1124,7 @@ static int launch_cross_t(const void* q, const void* kv, void* out, int b, const
   const int nqb = cdiv(p.N, 64 * QT);
   auto launch = [&](bool edit, int row0, int rows) {
     const int gx = std::max(1, std::min(nqb, cdiv(2048, rows * p.heads)));   // ~2048+ blocks in flight, K/V staging amortised
-    static const bool xcd_heads = env_flag("ETAINV_CROSS_XCD", true);
+    const bool xcd_heads = env_flag("ETAINV_CROSS_XCD", true);   // (read per launch: tests/test_kernels_gpu.py compares the two placements in one process)
     CrossParams pl = p;
     dim3 grid(gx, p.heads, rows);
     if (xcd_heads && (gx * rows) % 8 == 0) {   // the heads of a (row, query range) on one XCD (see the kernel)

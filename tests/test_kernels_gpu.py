@@ -887,6 +887,21 @@ def test_self_attention_d40_maximum_jumps_late(capi):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_self_attention_d40_single_row_call_equals_the_row_of_a_batch(capi, dtype):
+    """Round 6: a launch of <= 256 blocks (single-image calls) runs one 32-query block per wave instead of two -- the same arithmetic per query block: a row
+    computed alone must be bit-equal to the same row inside a 16-row call."""
+    lib = capi.load()
+    b, heads, n, d = 16, 8, 4096, 40
+    qkv = rnd(b, n, 3 * heads * d, seed=9, dtype=dtype)
+    out = torch.empty(b, n, heads * d, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_self_attention(capi.ptr(qkv), capi.ptr(out), b, n, heads, d, 0, 1, capi.dtype_code(dtype), capi.stream_ptr()))
+    one_in, one = qkv[3:4].contiguous(), torch.empty(1, n, heads * d, dtype=dtype, device="cuda")
+    capi.check(lib.etainv_op_self_attention(capi.ptr(one_in), capi.ptr(one), 1, n, heads, d, 0, 1, capi.dtype_code(dtype), capi.stream_ptr()))
+    assert torch.equal(one[0], out[3])
+    assert relerr(one, ref_self_attention(one_in, heads)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_self_attention_d40_speculative_maximum(capi, dtype):
     """Round 6: from 8 key tiles on, only tile 0 computes the reference maximum; later tiles exponentiate against it, and a block whose denominators come out
     non-finite repeats its pass with the running maximum (attention.hip, self_attn40_kernel).  N = 2048 (32 tiles), four regimes in ONE launch, each in its own
@@ -1034,6 +1049,31 @@ def test_cross_attention_ptp_edit_and_store(capi, dtype, n, d):
     if store:
         assert relerr(maps[3].cpu(), 2 * ref_maps) < 1e-3
         assert float(maps[0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cross_attention_xcd_head_placement_is_bit_identical(capi, dtype, monkeypatch):
+    """Round 6: the launch deals its block ids so that the eight heads of a (row, query range) run on one XCD (CrossParams::xcd_gx) -- placement only: the prompt-to-prompt call of
+    the test above (plain launch over three row groups + edit launch over the cond-target rows, with the map store) must give the same bits as the round-5 placement."""
+    lib = capi.load()
+    n_img, heads, n, d = 4, 8, 1024, 80
+    b, c = 4 * n_img, heads * d
+    q = rnd(b, n, c, seed=11, dtype=dtype)
+    kv = rnd(b, 77, 2 * c, seed=12, dtype=dtype)
+    mapper, alphas, eq, ca = _ptp_tables(n_img)
+    outs, stores = [], []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ETAINV_CROSS_XCD", flag)
+        out = torch.empty(b, n, c, dtype=dtype, device="cuda")
+        maps = torch.zeros(5, n_img, 2, heads, n, 77, dtype=torch.float32, device="cuda")
+        ctrl = capi.AttnCtrl(mode=capi.ATTN_PTP, n_img=n_img, store_maps=1, mapper=capi.ptr(mapper), alphas=capi.ptr(alphas), equalizer=capi.ptr(eq), cross_alpha=capi.ptr(ca))
+        capi.check(lib.etainv_op_cross_attention(capi.ptr(q), capi.ptr(kv), capi.ptr(out), b, n, heads, d, 77, C.byref(ctrl), 2, n_img, capi.ptr(maps), capi.dtype_code(dtype),
+                                                 capi.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(out)
+        stores.append(maps)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(stores[0], stores[1])
+    assert float(stores[0][2].abs().max()) > 0.0
 
 
 def test_cross_attention_store_layout_forward(capi):
