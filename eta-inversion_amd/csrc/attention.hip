@@ -1123,7 +1123,13 @@ static int launch_cross_t(const void* q, const void* kv, void* out, int b, const
   ProfScope prof(PROF_CROSS_ATTN, 4.0 * (double)b * p.heads * (double)p.N * (double)p.n_ctx * D, s);
   const int nqb = cdiv(p.N, 64 * QT);
   auto launch = [&](bool edit, int row0, int rows) {
-    const int gx = std::max(1, std::min(nqb, cdiv(2048, rows * p.heads)));   // ~2048+ blocks in flight, K/V staging amortised
+    // blocks per (row, head): a block stages its head's 77 keys and values once (49 KB at head_dim 160, with 2-byte transposing LDS stores) and then walks its share of the
+    // query blocks.  Few tokens (N <= 1024): as few blocks as fill the chip -- at N = 256 a second block per (row, head) halves the work that amortises a staging and the
+    // launch was 0.105 ms, 0.078 with one.  Many tokens (N = 4096): the staging is small beside 32 query blocks, more blocks balance better (0.231 -> 0.224 ms).
+    // (round 6, profiles/r06_cross_attention_xcd_heads_ab.log; ETAINV_CROSS_BLOCKS overrides the target)
+    static const int target_env = getenv("ETAINV_CROSS_BLOCKS") ? std::max(64, atoi(getenv("ETAINV_CROSS_BLOCKS"))) : 0;
+    const int target = target_env ? target_env : p.N >= 2048 ? (edit ? 2048 : 6144) : 1024;   // (the edit launch stages two key sets and its tables: fewer, longer blocks at every N)
+    const int gx = std::max(1, std::min(nqb, cdiv(target, rows * p.heads)));
     const bool xcd_heads = env_flag("ETAINV_CROSS_XCD", true);   // (read per launch: tests/test_kernels_gpu.py compares the two placements in one process)
     CrossParams pl = p;
     dim3 grid(gx, p.heads, rows);
