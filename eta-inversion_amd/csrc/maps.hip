@@ -83,10 +83,27 @@ __global__ void __launch_bounds__(256) word_maps_kernel(const float* __restrict_
 }
 
 // grid n_img, 256 threads.  x [2*n_img][4][L][L] fp32 in place.
-__global__ void __launch_bounds__(256) local_blend_kernel(const float* __restrict__ acc, int n_layers, int n_img_cap, int heads, int res,
-                                                          int L, float* __restrict__ x, int n_img,
-                                                          const float* __restrict__ blend_alpha, float thres) {
-  extern __shared__ float sm[];  // [2][RR] maps, [2][RR] pooled, [8] scratch
+// LocalBlend phase 1 (round 6): t[img][role][pix][l * heads + h] = sum_k acc[l][img][role][h][pix][k] * alpha[img][role][k], k in order -- one block per (layer-head, role,
+// image), thread = pixel, each block streams one contiguous [pix][77] plane.  One block per image walking all 40 planes read 202 MB at 0.47 TB/s (B = 32: 432 us per call);
+// the partials are summed in the (layer, head) order of that loop by local_blend_kernel: the same bits.
+__global__ void __launch_bounds__(256) blend_partials_kernel(const float* __restrict__ acc, int n_img_cap, int heads, int RR, const float* __restrict__ blend_alpha,
+                                                             float* __restrict__ tpart, int P) {
+  const int lh = blockIdx.x, role = blockIdx.y, img = blockIdx.z;
+  const int l = lh / heads, h = lh - l * heads;
+  const float* al = blend_alpha + ((int64_t)img * 2 + role) * 77;
+  for (int pix = threadIdx.x; pix < RR; pix += blockDim.x) {
+    const float* a = acc + (((((int64_t)l * n_img_cap + img) * 2 + role) * heads + h) * RR + pix) * 77;
+    float t = 0.f;
+    for (int k = 0; k < 77; ++k) t += a[k] * al[k];
+    tpart[(((int64_t)img * 2 + role) * RR + pix) * P + lh] = t;
+  }
+}
+
+// Phase 2: 1024 threads per image; `tpart` != nullptr: the partial dot products come from blend_partials_kernel (summed here in the old order); else computed here.
+__global__ void __launch_bounds__(1024) local_blend_kernel(const float* __restrict__ acc, int n_layers, int n_img_cap, int heads, int res,
+                                                           int L, float* __restrict__ x, int n_img,
+                                                           const float* __restrict__ blend_alpha, float thres, const float* __restrict__ tpart) {
+  extern __shared__ float sm[];  // [2][RR] maps, [2][RR] pooled, [32] scratch
   const int img = blockIdx.x;
   const int RR = res * res;
   float* mp = sm;
@@ -99,6 +116,15 @@ __global__ void __launch_bounds__(256) local_blend_kernel(const float* __restric
     for (int k = threadIdx.x; k < 2 * 77; k += blockDim.x) any |= blend_alpha[(int64_t)img * 2 * 77 + k] != 0.f;
     if (!__syncthreads_or(any)) return;
   }
+  const int P = n_layers * heads;
+  if (tpart) {
+    for (int idx = threadIdx.x; idx < 2 * RR; idx += blockDim.x) {
+      const float* tp = tpart + ((int64_t)img * 2 * RR + idx) * P;
+      float s = 0.f;
+      for (int lh = 0; lh < P; ++lh) s += tp[lh];     // (layer, head) order of the single-thread loop below
+      mp[idx] = s / (float)P;
+    }
+  } else {
   for (int idx = threadIdx.x; idx < 2 * RR; idx += blockDim.x) {
     const int role = idx / RR, pix = idx - role * RR;
     const float* al = blend_alpha + ((int64_t)img * 2 + role) * 77;
@@ -111,6 +137,7 @@ __global__ void __launch_bounds__(256) local_blend_kernel(const float* __restric
         s += t;
       }
     mp[idx] = s / (float)(n_layers * heads);
+  }
   }
   __syncthreads();
   float lm[2] = {-3.0e38f, -3.0e38f};
@@ -133,8 +160,8 @@ __global__ void __launch_bounds__(256) local_blend_kernel(const float* __restric
     red[(threadIdx.x >> 6) * 2 + 1] = lm[1];
   }
   __syncthreads();
-  const float m0 = fmaxf(fmaxf(red[0], red[2]), fmaxf(red[4], red[6]));
-  const float m1 = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+  float m0 = red[0], m1 = red[1];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { m0 = fmaxf(m0, red[2 * w]); m1 = fmaxf(m1, red[2 * w + 1]); }
   const float sc = (float)res / (float)L;
   const int LL = L * L;
   float* xs = x + (int64_t)img * 4 * LL;
@@ -170,9 +197,25 @@ int launch_word_maps(const float* maps_acc, int n_layers, int n_img_cap, int row
 int launch_local_blend(const float* maps_acc, int n_layers, int n_img_cap, int heads, int res, int L, float* x, int n_img,
                        const float* blend_alpha, float thres, hipStream_t s) {
   ETAINV_CHECK(maps_acc && x && blend_alpha && n_img > 0, "bad arguments");
-  const size_t lds = (size_t)(4 * res * res + 8) * sizeof(float);
-  hipLaunchKernelGGL(local_blend_kernel, dim3(n_img), dim3(256), lds, s, maps_acc, n_layers, n_img_cap, heads, res, L, x, n_img,
-                     blend_alpha, thres);
+  const int RR = res * res, P = n_layers * heads;
+  const size_t lds = (size_t)(4 * RR + 32) * sizeof(float);
+  // partials workspace [n_img][2][RR][P] (2.6 MB at B = 32, L = 64): one allocation per device, grown on demand (launches on a device are serialised by the caller's stream)
+  static float* ws[kMaxDevices] = {};
+  static size_t ws_bytes[kMaxDevices] = {};
+  const int dev = current_device();
+  float* tpart = nullptr;
+  if (!env_on("ETAINV_BLEND_NOSPLIT")) {
+    const size_t need = (size_t)n_img * 2 * RR * P * sizeof(float);
+    if (need > ws_bytes[dev]) {
+      if (ws[dev]) { ETAINV_HIP(hipStreamSynchronize(s)); ETAINV_HIP(hipFree(ws[dev])); }
+      ETAINV_HIP(hipMalloc(&ws[dev], need));
+      ws_bytes[dev] = need;
+    }
+    tpart = ws[dev];
+    hipLaunchKernelGGL(blend_partials_kernel, dim3(P, 2, n_img), dim3(256), 0, s, maps_acc, n_img_cap, heads, RR, blend_alpha, tpart, P);
+  }
+  hipLaunchKernelGGL(local_blend_kernel, dim3(n_img), dim3(1024), lds, s, maps_acc, n_layers, n_img_cap, heads, res, L, x, n_img,
+                     blend_alpha, thres, (const float*)tpart);
   ETAINV_LAUNCH_CHECK();
   return 0;
 }

@@ -1132,3 +1132,13 @@ def test_word_maps_and_local_blend_vs_oracle(capi):
         ref = lb(torch.stack([x[img], x[n_img + img]]), store)
         torch.testing.assert_close(xd[img].cpu(), ref[0], rtol=1e-6, atol=1e-6)
         torch.testing.assert_close(xd[n_img + img].cpu(), ref[1], rtol=1e-6, atol=1e-6)
+    # round 6: the partial dot products of a (role, pixel) item are split over several threads and summed in the old order -- the same bits as the unsplit loop
+    import os
+    x2 = x.clone().cuda()
+    os.environ["ETAINV_BLEND_NOSPLIT"] = "1"
+    try:
+        capi.check(lib.etainv_op_local_blend(capi.ptr(acc_d), 5, n_img, heads, res, L, capi.ptr(x2), n_img, capi.ptr(ad), 0.3, capi.stream_ptr()))
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["ETAINV_BLEND_NOSPLIT"]
+    assert torch.equal(x2, xd)
