@@ -741,6 +741,418 @@ __global__ void __launch_bounds__(256, OCC) self_attn40_kernel(const T* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------ self, head_dim 40: persistent one-wave-per-SIMD form
+// Round 6 (profiles/r06_attention_persistent.log holds every number quoted here).  What the measurements said about self_attn40_kernel:
+//   * a block costs ~10 us beside its tiles (a launch cut to ONE tile per block: 0.347 ms for 16384 blocks = 10.8 us per round of the chip): dispatch, the dependent
+//     Q / first K-V loads, the first barrier, the epilogue -- 10 % of a 64-tile block;
+//   * every 16 bytes per lane that LDS returns cost the SIMD ~20 matrix cycles, and with two waves of two query blocks each SIMD receives the tile's K / V^T
+//     fragments twice: a two-wave build of THIS kernel (QB = 2, eight waves) runs 2220 cycles per tile with the exponentials removed, for 1792 cycles of MFMAs;
+//   * a lone wave issues in order and pays every instruction's issue time itself (tools/experiments/valu_beside_mfma.hip: v_exp_f32 9.75 cycles, v_cvt_pk ~4, and exactly
+//     two v_exp_f32 + one v_cvt_pk fit under one 32-cycle MFMA), but it receives the fragments ONCE for four query blocks and has 512 registers.
+// So: 256 blocks (one per CU, 4 waves, QB = 4 query blocks of 32 per wave) walk the (row, head, 512-query block) items.  The tile loop is a software pipeline over units
+// (key tile j, query block q) written in the order it must issue: each unit has 14 MFMAs -- the scores of the NEXT unit (6), then P V of the PREVIOUS unit (8) -- and behind
+// each MFMA 2-3 v_exp_f32 of the CURRENT unit's scores plus the v_cvt_pk of the pair the previous interval finished; every operand was produced a whole unit earlier.
+// K / V tiles: a ring of four LDS buffers = two stages of two tiles, ONE barrier per 128 keys; a tile is requested two tiles before it is stored (two register sets:
+// nobody covers a lone wave's wait for memory) and stored a unit before the barrier that publishes it.  The stream runs on into the next item's first four tiles, the next
+// item's Q fragments are requested under the last P V MFMAs, and an item change costs the reference-maximum pre-pass (24 MFMAs) + the output stores: ~12 k of ~184 k cycles.
+// Reference maximum: m' = the exact maximum over the item's first 64 keys (pre-pass), then the speculative scheme of self_attn40_kernel: no maximum in the tile loop; a block
+// whose denominators come out non-finite repeats the item with the running maximum (the tracked tiles at the end of the item loop), correct for every input.
+// Measured (same box, N = 4096 x 128 rows / N = 9216 x 32 rows): 3.06 / 3.53 ms against 3.18-3.20 / 3.74 for self_attn40_kernel; the tile loop runs 2670 cycles per tile against an
+// in-order issue sum of ~2400 (128 v_exp_f32 = 1250 of it).  QB = 2 with eight waves (NW = 8: same code, 256 registers, 13 spilled): 3.10 ms, not dispatched.
+// head_dim 80 (the (L/2)^2 level; 24 MFMAs per unit, matrix-bound) runs the same code with QB = 2, NW = 4 and items of 256 queries: 0.443 against 0.491 ms at N = 1024 x 128 rows.
+// Requirements (persistent_self_ok): N a multiple of the item's queries and of 256 (tiles: a multiple of 4, >= 16), the QKV tensor below 4 GB (one buffer descriptor, 32-bit
+// scalar offsets), >= 2 items per CU.  ETAINV_A40_PERSIST=0 / ETAINV_A80_PERSIST=0: self_attn40_kernel as before.
+template <typename T, int D, int QB, int NW>
+__global__ void __launch_bounds__(64 * NW, 1) self_attn40q_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int heads, float q_scale, int mode, int n_img,
+                                                              int nqb, int n_items, int first_row, int hm_rows, int xcd_remap, unsigned qkv_bytes) {
+  typedef typename Frag<T>::v8 v8;
+  typedef A32<D> GEO;
+  constexpr int NT = 64 * NW;             // threads: four waves (one per SIMD) of QB 32-query blocks; eight waves = two per SIMD
+  constexpr int QI = 32 * QB * NW;        // queries per item
+  constexpr int KV = GEO::KV, KS = GEO::KS, KROW = GEO::KROW, VROW = GEO::VROW, KBUF = GEO::KBUF, VBUF = GEO::VBUF, DT = GEO::DT, NCH = GEO::NCH;
+  constexpr int NLD = (KV * NCH + NT - 1) / NT;   // staging chunks per thread and tensor
+  constexpr int NM = 2 * KS + 4 * DT;   // MFMAs per unit
+  constexpr int NE = 32;                 // exponentials per unit and lane
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NBUF = 4;                  // two stages of two key tiles: one barrier per 128 keys
+  T* sK = reinterpret_cast<T*>(smem);      // [NBUF][KV][KROW]
+  T* sV = sK + NBUF * KBUF;                // [NBUF][KV][VROW]
+  T* sZ = sV + NBUF * VBUF;                // [KV][VROW] zeros
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int C = heads * D, C3 = 3 * C;
+  const int ntiles = N / KV;
+
+  // ---- one-time LDS constants (they outlive the items): pad chunks (1, 0 x 7) of every K and V row of both buffers, the all-zero V image
+  {
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    u32x4 one4 = zero4;
+    {
+      T one[2] = {(T)1.0f, (T)0.0f};
+      one4[0] = *reinterpret_cast<unsigned*>(one);
+    }
+    for (int idx = tid; idx < NBUF * KV; idx += NT) {
+      *reinterpret_cast<u32x4*>(sK + idx * KROW + D) = one4;
+#pragma unroll
+      for (int c = D + 8; c < KROW; c += 8) *reinterpret_cast<u32x4*>(sK + idx * KROW + c) = zero4;
+      *reinterpret_cast<u32x4*>(sV + idx * VROW + D) = one4;
+#pragma unroll
+      for (int c = D + 8; c < VROW; c += 8) *reinterpret_cast<u32x4*>(sV + idx * VROW + c) = zero4;
+    }
+    if (GEO::ZBUF)
+      for (int idx = tid; idx < VBUF / 8; idx += NT) *reinterpret_cast<u32x4*>(sZ + idx * 8) = zero4;
+  }
+
+  // ---- item-independent per-lane offsets.  One descriptor over the whole QKV tensor; (row, head, tile) enter as the scalar offset of each load
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(qkv), 0, qkv_bytes, 0x00020000);
+  // K / V staging without a branch in the tile loop (a branch ends the scheduling region, and LLVM sinks a unit's exponentials across it to their first use): every
+  // wave carries NLD chunk groups, the groups past the tile's KV * NCH chunks repeat the lane's first chunk (same bytes to the same LDS address)
+  unsigned goff[NLD];
+  int ldk[NLD], ldv[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    int c = tid + NT * i;
+    if (c >= KV * NCH) c = tid;
+    const int row = c / NCH, ch = c - row * NCH;
+    goff[i] = hm_rows ? (unsigned)c * 16u : (unsigned)row * C3 * 2u + (unsigned)ch * 16u;
+    ldk[i] = row * KROW + ch * 8;
+    ldv[i] = row * VROW + ch * 8;
+  }
+  const unsigned tile_bytes = hm_rows ? (unsigned)KV * D * 2u : (unsigned)KV * C3 * 2u;
+  // Q fragments (B operand of S^T): lane (query r, half h) holds dims 16 s + 8 h .. + 7 of K step s; the chunk at dims D .. D + 7 (step MS, half MH) is the pad chunk
+  // (element 0 carries -m', the rest 0): its lanes load whatever follows the head's row (inside the tensor) and are zeroed
+  unsigned qoff[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) qoff[qb] = (unsigned)(wid * (32 * QB) + qb * 32 + r) * (hm_rows ? D : C3) * 2u + (unsigned)h * 16u;
+  const int kA = r * KROW + h * 8;                                    // K A-operand: key r of the 32-key block, dims 16 s + 8 h
+  const int gi = lane & 15, vg = (lane >> 4) & 1, vq = gi >> 2, vp = gi & 3;
+  const int vA = (4 * h + vq) * VROW + 16 * vg + 4 * vp;              // V^T A-operand through ds_read_b64_tr_b16 (self_attn40_kernel)
+
+  // item -> (query block, head, batch row) and the rows its Q / K / V come from (prompt-to-prompt / MasaCtrl couplings: self_attn40_kernel); byte offsets of the
+  // item's Q block, K plane and V plane.  All wave-uniform
+  auto decode = [&](int item, int& qblk, int& hd, int& b, unsigned& qo, unsigned& ko, unsigned& vo) __attribute__((always_inline)) {
+    if (xcd_remap) {   // ids of one residue class modulo 8 (one XCD: the grid is a multiple of 8) take the query blocks of one (row, head) in turn
+      const int xcd = item & 7, slot = item >> 3;
+      const int set = (slot / nqb) * 8 + xcd;
+      qblk = slot - (slot / nqb) * nqb;
+      hd = set % heads;
+      b = set / heads;
+    } else {
+      qblk = item % nqb;
+      const int t = item / nqb;
+      hd = t % heads;
+      b = t / heads;
+    }
+    int bq = b, bk = b, bv = b;
+    if (mode != 0) {
+      int half, role, img;
+      if (first_row < 0) {
+        if (mode == 1 && b / n_img == 1) { bq = b + n_img; bk = b + n_img; }
+      } else {
+        row_roles(b + first_row, n_img, half, role, img);
+        if (mode == 1 && half == 1 && role == 1) { bq = b - n_img; bk = b - n_img; }
+        if (mode == 2 && role == 1) { bk = b - n_img; bv = b - n_img; }
+      }
+    }
+    const int64_t q0 = (int64_t)qblk * QI;
+    if (hm_rows) {
+      qo = (unsigned)(((((int64_t)bq * heads + hd) * N + q0) * D) * 2);
+      ko = (unsigned)(((((int64_t)hm_rows + bk) * heads + hd) * N * D) * 2);
+      vo = (unsigned)(((((int64_t)2 * hm_rows + bv) * heads + hd) * N * D) * 2);
+    } else {
+      qo = (unsigned)((((int64_t)bq * N + q0) * C3 + hd * D) * 2);
+      ko = (unsigned)(((int64_t)bk * N * C3 + C + hd * D) * 2);
+      vo = (unsigned)(((int64_t)bv * N * C3 + 2 * C + hd * D) * 2);
+    }
+  };
+  auto load_q = [&](unsigned qo, v8 (&dst)[QB][KS]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, qoff[qb] + (unsigned)s * 32u, qo, 0));
+        dst[qb][s] = *reinterpret_cast<v8*>(&v);
+      }
+  };
+
+  // two register sets in flight: a tile is requested TWO tiles before it is stored to LDS (one wave per SIMD: nobody covers a wait for memory)
+  u32x4 rk[2][NLD], rv[2][NLD];
+  auto store_p = [&](int set, int bufi) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      *reinterpret_cast<u32x4*>(sK + bufi * KBUF + ldk[i]) = rk[set][i];
+      *reinterpret_cast<u32x4*>(sV + bufi * VBUF + ldv[i]) = rv[set][i];
+    }
+  };
+  v8 kf[2][KS], vf[4][DT];
+  auto read_k = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int st = 0; st < KS; ++st) kf[kb][st] = *reinterpret_cast<const v8*>(sK + buf * KBUF + kA + kb * 32 * KROW + st * 16);
+  };
+  auto read_vt = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      // lanes with vg = 1 read dims 32 dt + 16 .. + 31, which lie past the row for the last tile of D = 40 (rows 48 .. 63 of V^T are zero: the zero image)
+      const T* tv = sV + buf * VBUF + vA + dt * 32;
+      if (dt * 32 + 16 >= VROW && vg) tv = sZ + vA - 16;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const T* vp_ = tv + ks * 16 * VROW;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp_));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp_ + 8 * VROW));
+        vf[ks][dt] = __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+    }
+  };
+  f32x16 zero16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+  v8 zero8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero8[e] = (T)0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vf[ks][dt] = zero8;   // (the first unit of an item multiplies them by P = 0: anything finite will do afterwards)
+
+  v8 qf[QB][KS];
+  float mref[QB];
+  f32x16 o[QB][DT];
+  bool warm = false;   // the previous item left this item's tiles 0, 1 in LDS buffers 0, 1, tiles 2, 3 in the two register sets and requested its Q fragments into qf
+
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    int qblk, hd, b;
+    unsigned qo, ko, vo;
+    decode(item, qblk, hd, b, qo, ko, vo);
+    const bool has_next = item + (int)gridDim.x < n_items;
+    unsigned qo2 = qo, ko2 = ko + (unsigned)(ntiles - 4) * tile_bytes, vo2 = vo + (unsigned)(ntiles - 4) * tile_bytes;   // no next item: the stream re-reads this item's last tiles
+    if (has_next) {
+      int qblk2, hd2, b2;
+      decode(item + gridDim.x, qblk2, hd2, b2, qo2, ko2, vo2);
+    }
+    auto load_p = [&](int set, int tile) __attribute__((always_inline)) {   // tiles ntiles .. ntiles + 3: the next item's first four
+      const unsigned sk = tile < ntiles ? ko + (unsigned)tile * tile_bytes : ko2 + (unsigned)(tile - ntiles) * tile_bytes;
+      const unsigned sv = tile < ntiles ? vo + (unsigned)tile * tile_bytes : vo2 + (unsigned)(tile - ntiles) * tile_bytes;
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        rk[set][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i], sk, 0));
+        rv[set][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i], sv, 0));
+      }
+    };
+    if (!warm) {
+      load_q(qo, qf);
+      load_p(0, 0);
+      load_p(1, 1);
+      store_p(0, 0);
+      store_p(1, 1);
+      __syncthreads();
+      load_p(0, 2);
+      load_p(1, 3);
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      if (h == GEO::MH) qf[qb][GEO::MS] = zero8;   // the pad chunk
+      if (q_scale != 1.0f) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) qf[qb][s][j] = (T)((float)qf[qb][s][j] * q_scale);
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[qb][dt] = zero16;
+    }
+
+    // ---- m' of every query block = the exact maximum over the first 64 keys (24 MFMAs per item; the pipeline then recomputes tile 0 against it)
+    read_k(0);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      f32x16 t[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int st = 0; st < KS; ++st) t[kb] = Frag32<T>::mfma(kf[kb][st], qf[qb][st], st == 0 ? zero16 : t[kb]);
+      const float m = max32(t);
+      float ma = m, mb = m;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));   // (inline asm: see self_attn40_kernel)
+      const T mt = (T)fmaxf(ma, mb);                                                   // m' stays representable in the operand type
+      mref[qb] = (float)mt;
+      if (h == GEO::MH) qf[qb][GEO::MS][0] = (T)(-mref[qb]);
+    }
+    f32x16 sc[2], sn[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int st = 0; st < KS; ++st) sc[kb] = Frag32<T>::mfma(kf[kb][st], qf[0][st], st == 0 ? zero16 : sc[kb]);
+    // P of the previous unit (B operands of its P V MFMAs) and of the current one, as packed pairs: one v_cvt_pk per pair, written where the schedule below puts it (a
+    // v8 assembled element by element is converted by four v_cvt_pk in a row at the point where its last element arrives: 24 issue cycles in one MFMA interval)
+    u32x4 pfp[4], pfc[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) pfp[ks] = u32x4{0u, 0u, 0u, 0u};
+
+    // one unit: MFMA m of the unit, then 2-3 exponentials of the current scores and the v_cvt_pk of the pairs the PREVIOUS interval finished (a lone wave issues in
+    // order: 2 x 9.75 cycles of v_exp_f32 + one conversion + the MFMA's own issue fill the 32 cycles the matrix pipe needs); sched_barrier(0) pins the order written here
+    auto unit = [&](auto qtag) __attribute__((always_inline)) {
+      constexpr int q = decltype(qtag)::value, qnx = (q + 1) % QB, qpv = (q + QB - 1) % QB;
+      constexpr bool PV_FIRST = q == QB - 1;   // the unit that needs the next tile's K fragments: their LDS latency under the eight P V MFMAs
+      float ex[NE];
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const int mm = PV_FIRST ? (m < 4 * DT ? m + 2 * KS : m - 4 * DT) : m;   // 0 .. 2 KS - 1: scores (the two 32-key blocks alternate), then P V (the O^T tiles alternate)
+        if (mm < 2 * KS) {
+          const int kb = mm & 1, st = mm >> 1;
+          sn[kb] = Frag32<T>::mfma(kf[kb][st], qf[qnx][st], st == 0 ? zero16 : sn[kb]);
+        } else {
+          const int pv = mm - 2 * KS, ks = pv / DT, dt = pv - ks * DT;
+          o[qpv][dt] = Frag32<T>::mfma(vf[ks][dt], __builtin_bit_cast(v8, pfp[ks]), o[qpv][dt]);
+        }
+        const int e0 = NE * m / NM, e1 = NE * (m + 1) / NM;                     // exponentials of this interval
+        const int c0 = m == 0 ? 0 : (NE * (m - 1) / NM) / 2, c1 = m == NM - 1 ? NE / 2 : e0 / 2;   // pairs converted here: complete since the previous interval (last: all)
+#pragma unroll
+        for (int i = e0; i < e1; ++i) ex[i] = __builtin_amdgcn_exp2f(sc[i >> 4][i & 15]);
+#pragma unroll
+        for (int pr = c0; pr < c1; ++pr) {
+          typedef T T2 __attribute__((ext_vector_type(2)));
+          const T2 two = {(T)ex[2 * pr], (T)ex[2 * pr + 1]};
+          pfc[pr >> 2][pr & 3] = __builtin_bit_cast(unsigned, two);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) sc[kb] = sn[kb];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) pfp[ks] = pfc[ks];
+    };
+    // two tiles per trip = one stage of the LDS ring (buffers b0, b0 + 1; the other stage b2, b2 + 1 receives tiles j + 2, j + 3, requested two tiles earlier)
+    for (int j = 0; j < ntiles; j += 2) {
+      const int b0 = j & 2, b2 = b0 ^ 2;
+      unit(std::integral_constant<int, 0>{});          // scores (j, 1) | P V (j - 1, last) with the previous tile's V^T fragments | exp (j, 0)
+      read_vt(b0);                                     // V^T of tile j: first used by the P V MFMAs of the next unit, behind its six score MFMAs
+      if constexpr (QB == 4) unit(std::integral_constant<int, 1>{});
+      store_p(0, b2);                                  // tile j + 2: the other stage's last readers passed the previous barrier; the stores complete under the units that follow
+      load_p(0, j + 4);
+      if constexpr (QB == 4) unit(std::integral_constant<int, 2>{});
+      read_k(b0 + 1);                                  // K of tile j + 1 (same stage: visible since the previous barrier)
+      unit(std::integral_constant<int, QB - 1>{});     // P V (j, last - 1) | scores (j + 1, 0) | exp (j, last)
+      unit(std::integral_constant<int, 0>{});
+      read_vt(b0 + 1);
+      if constexpr (QB == 4) unit(std::integral_constant<int, 1>{});
+      store_p(1, b2 + 1);                              // tile j + 3
+      load_p(1, j + 5);
+      if constexpr (QB == 4) unit(std::integral_constant<int, 2>{});
+      __syncthreads();                                 // the one barrier per 128 keys: tiles j + 2, j + 3 visible; every wave is done reading this stage's V / the tile j + 1 K
+      read_k(b2);                                      // K of tile j + 2 (last trip: the next item's tile 0 -- those scores are never used)
+      unit(std::integral_constant<int, QB - 1>{});
+    }
+    if (has_next) load_q(qo2, qf);   // the item's Q fragments are done (the exact pass below reloads them): the next item's arrive under the last P V MFMAs and the output stores
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[QB - 1][dt] = Frag32<T>::mfma(vf[ks][dt], __builtin_bit_cast(v8, pfp[ks]), o[QB - 1][dt]);
+    bool bad = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) bad |= !(fabsf(o[qb][GEO::LT][GEO::LI]) < 1.0e30f);   // (lanes that do not hold row D: another row's sum of the same P)
+    warm = has_next;
+    if (__syncthreads_or(bad)) {
+      // ---- the exact pass: running maximum in every tile (the tile of self_attn40_kernel with four query blocks).  It restages the item from tile 0 and leaves
+      // nothing of the next item behind
+      warm = false;
+      load_q(qo, qf);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        mref[qb] = 0.f;
+        if (h == GEO::MH) qf[qb][GEO::MS] = zero8;
+        if (q_scale != 1.0f) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[qb][s][j] = (T)((float)qf[qb][s][j] * q_scale);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qb][dt] = zero16;
+      }
+      load_p(0, 0);
+      store_p(0, 0);
+      __syncthreads();
+      for (int j = 0; j < ntiles; ++j) {
+        const int cur = j & 1;
+        if (j + 1 < ntiles) load_p(0, j + 1);
+        read_k(cur);
+        f32x16 s[QB][2];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int st = 0; st < KS; ++st) s[qb][kb] = Frag32<T>::mfma(kf[kb][st], qf[qb][st], st == 0 ? zero16 : s[qb][kb]);
+        float mx[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          const float m = max32(s[qb]);
+          float ma = m, mb = m;
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
+          mx[qb] = fmaxf(ma, mb);
+        }
+        const bool first = j == 0;
+        if (first || __builtin_amdgcn_ballot_w64(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[QB - 2], mx[QB - 1])) > A40_THR) != 0) {
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            const float d = first ? mx[qb] : fmaxf(mx[qb], 0.f);
+            const T mt = (T)(mref[qb] + d);
+            const float mnew = (float)mt, de = mnew - mref[qb];
+            mref[qb] = mnew;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+              for (int i = 0; i < 16; ++i) s[qb][kb][i] -= de;
+            if (!first) {
+              const float f = __builtin_amdgcn_exp2f(-de);
+#pragma unroll
+              for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[qb][dt][i] *= f;
+            }
+            if (h == GEO::MH) qf[qb][GEO::MS][0] = (T)(-mnew);
+          }
+        }
+        read_vt(cur);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          v8 pf[4];
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[ks][e] = (T)__builtin_amdgcn_exp2f(s[qb][ks >> 1][(ks & 1) * 8 + e]);
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[qb][dt] = Frag32<T>::mfma(vf[ks][dt], pf[ks], o[qb][dt]);
+        }
+        if (j + 1 < ntiles) store_p(0, cur ^ 1);
+        __syncthreads();
+      }
+    }
+
+    // ---- normalise and store: lane (query r, half h) holds dims (i&3) + 8(i>>2) + 4h (+32); the denominator is row D of O^T
+    const int q_base = qblk * QI + wid * (32 * QB);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const float l = __shfl(o[qb][GEO::LT][GEO::LI], r + 32 * GEO::LH, 64);
+      const float inv = 1.f / l;
+      const int query = q_base + qb * 32 + r;
+      T* op = out + ((int64_t)b * N + query) * C + hd * D + 4 * h;
+#pragma unroll
+      for (int g4 = 0; g4 < D / 8; ++g4) {
+        const int dt = g4 >> 2, i0 = (g4 & 3) * 4;
+        T v[4] = {(T)(o[qb][dt][i0] * inv), (T)(o[qb][dt][i0 + 1] * inv), (T)(o[qb][dt][i0 + 2] * inv), (T)(o[qb][dt][i0 + 3] * inv)};
+        *reinterpret_cast<u32x2*>(op + 8 * g4) = *reinterpret_cast<u32x2*>(v);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ cross
 // EDIT = false: no source-key tile and no source-probability scratch in LDS (a third of the footprint: 6 instead of 2 resident blocks per
 // CU for a kernel that waits on one dependent Q load per 16-query tile).  Only the cond-target rows of a prompt-to-prompt call need
@@ -1062,6 +1474,46 @@ static int launch_self40(const void* qkv, void* out, int b, int n, int heads, in
   return 0;
 }
 
+// the persistent one-wave-per-SIMD kernel (self_attn40q_kernel): one block per CU walks the (row, head, query block of 32 QB NW queries) items
+template <typename T, int D, int QB, int NW>
+static int launch_self40q(const void* qkv, void* out, int b, int n, int heads, int mode, int n_img, int q_prescaled, hipStream_t s, int first_row, int head_major, int n_cu) {
+  const int hm_rows = head_major ? b : 0;
+  const int nqb = n / (32 * QB * NW);
+  const int n_items = nqb * heads * b;
+  const int remap = ((b * heads) % 8) == 0;
+  const float q_scale = q_prescaled ? 1.0f : (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+  constexpr size_t lds = (size_t)(4 * (A32<D>::KBUF + A32<D>::VBUF) + A32<D>::VBUF) * 2;   // four tile buffers + the zero image (90 / 112 KB at head_dim 40 / 80; one block per CU)
+  static bool attr_set[kMaxDevices] = {};
+  const int dev = current_device();
+  if (!attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn40q_kernel<T, D, QB, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set[dev] = true;
+  }
+  ProfScope prof(PROF_SELF_ATTN, 4.0 * (double)b * heads * (double)n * (double)n * D, s);
+  const unsigned qkv_bytes = (unsigned)((int64_t)3 * b * n * heads * D * 2);
+  const int grid = n_items < n_cu ? n_items / 8 * 8 : n_cu / 8 * 8;
+  hipLaunchKernelGGL((self_attn40q_kernel<T, D, QB, NW>), dim3(grid), dim3(64 * NW), lds, s, (const T*)qkv, (T*)out, n, heads, q_scale, mode, n_img, nqb, n_items, first_row, hm_rows, remap,
+                     qkv_bytes);
+  ETAINV_LAUNCH_CHECK();
+  return 0;
+}
+
+static int device_cu_count() {
+  static int n_cu[kMaxDevices] = {};
+  const int dev = current_device();
+  if (n_cu[dev] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 8;
+    n_cu[dev] = v;
+  }
+  return n_cu[dev];
+}
+
+// what self_attn40q_kernel asks of a launch: whole items, a tile count the four-buffer ring divides, a tensor one buffer descriptor spans, two items per CU
+static bool persistent_self_ok(int b, int n, int heads, int d, int item_queries) {
+  return n % item_queries == 0 && n % 256 == 0 && n >= 1024 && (int64_t)3 * b * n * heads * d * 2 < ((int64_t)1 << 32) && (int64_t)(n / item_queries) * heads * b >= 2 * device_cu_count();
+}
+
 bool self_attn_head_major_ok(int d, int dtype) {   // which launches read the head-major QKV planes (the 32x32x16 kernel of head_dim 40 / 80)
   static const bool v2_80 = !env_on("ETAINV_ATT80_OLD");
   return dtype != ETAINV_F32 && self_attn40_v2_enabled() && (d == 40 || (d == 80 && v2_80));
@@ -1084,10 +1536,17 @@ int launch_self_attention_mode(const void* qkv, void* out, int b, int n, int hea
     // few blocks (single-image calls: N = 4096, 8 heads, 1 row = 128 blocks of 256 queries on 256 CUs): one 32-query block per wave, twice the blocks
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 40, 1, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s, first_row, head_major)));
   }
+  // enough (row, head, query block) items for two per CU: the persistent one-wave-per-SIMD kernel (items of 512 queries at head_dim 40, 256 at head_dim 80)
+  if (d == 40 && self_attn40_v2_enabled() && persistent_self_ok(b, n, heads, d, 512) && env_flag("ETAINV_A40_PERSIST", true)) {
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40q<T, 40, 4, 4>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s, first_row, head_major, device_cu_count())));
+  }
   if (d == 40 && self_attn40_v2_enabled()) {
     // two 32-query blocks per wave, 2 waves per SIMD (one block per wave with 3 / 4 waves per SIMD: +10 % / +52 % time, re-measured in round 6 on the lean staging:
     // profiles/r06_attention_experiments.log)
     ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40<T, 40, 2, 2>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s, first_row, head_major)));
+  }
+  if (d == 80 && self_attn40_v2_enabled() && persistent_self_ok(b, n, heads, d, 256) && env_flag("ETAINV_A80_PERSIST", true)) {
+    ETAINV_DISPATCH_HALF(dtype, T, return (launch_self40q<T, 80, 2, 4>(qkv, out, b, n, heads, mode, n_img, q_prescaled, s, first_row, head_major, device_cu_count())));
   }
   static const bool v2_80 = !env_on("ETAINV_ATT80_OLD");   // A/B: head_dim 80 on the 32x32x16 kernel (one 32-query block per wave)
   if (d == 80 && self_attn40_v2_enabled() && v2_80) {

@@ -887,13 +887,14 @@ def test_self_attention_d40_maximum_jumps_late(capi):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_self_attention_d40_single_row_call_equals_the_row_of_a_batch(capi, dtype):
+def test_self_attention_d40_single_row_call_equals_the_row_of_a_batch(capi, dtype, monkeypatch):
     """Round 6: a launch of <= 256 blocks (single-image calls) runs one 32-query block per wave instead of two -- the same arithmetic per query block: a row
     computed alone must be bit-equal to the same row inside a 16-row call."""
     lib = capi.load()
     b, heads, n, d = 16, 8, 4096, 40
     qkv = rnd(b, n, 3 * heads * d, seed=9, dtype=dtype)
     out = torch.empty(b, n, heads * d, dtype=dtype, device="cuda")
+    monkeypatch.setenv("ETAINV_A40_PERSIST", "0")   # (16 rows would otherwise take the persistent kernel, whose first tile is rounded differently)
     capi.check(lib.etainv_op_self_attention(capi.ptr(qkv), capi.ptr(out), b, n, heads, d, 0, 1, capi.dtype_code(dtype), capi.stream_ptr()))
     one_in, one = qkv[3:4].contiguous(), torch.empty(1, n, heads * d, dtype=dtype, device="cuda")
     capi.check(lib.etainv_op_self_attention(capi.ptr(one_in), capi.ptr(one), 1, n, heads, d, 0, 1, capi.dtype_code(dtype), capi.stream_ptr()))
@@ -930,6 +931,101 @@ def test_self_attention_d40_speculative_maximum(capi, dtype):
     for row in range(b):
         assert relerr(out[row], ref[row]) < 1.5 * TOL[dtype], row
     assert relerr(out[2, 300, 3 * d:4 * d], ref[2, 300, 3 * d:4 * d]) < 2 * TOL[dtype]     # the query whose key forced the fallback pass in fp16
+
+
+def _self40(capi, qkv, b, n, heads, mode=0, n_img=1, d=40):
+    lib = capi.load()
+    out = torch.empty(b, n, heads * d, dtype=qkv.dtype, device="cuda")
+    capi.check(lib.etainv_op_self_attention(capi.ptr(qkv), capi.ptr(out), b, n, heads, d, mode, n_img, capi.dtype_code(qkv.dtype), capi.stream_ptr()))
+    return out
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,b,heads", [(2048, 16, 8), (1024, 33, 8), (2048, 33, 4), (4096, 9, 8)])
+def test_self_attention_d40_persistent_kernel(capi, dtype, n, b, heads, monkeypatch):
+    """Round 6: launches with at least two (row, head, 512-query block) items per CU run self_attn40q_kernel (one block per CU walks the items: attention.hip).  Item
+    counts that divide the 256 blocks evenly (512) and that do not (528, 576: some blocks run one item more; the K / V stream of a block's last item has no successor),
+    head counts with and without the XCD-aware item order (b * heads % 8).  Against the fp32 reference and against the kernel it replaces."""
+    qkv = rnd(b, n, 3 * heads * 40, seed=n + b, dtype=dtype)
+    out = _self40(capi, qkv, b, n, heads)
+    monkeypatch.setenv("ETAINV_A40_PERSIST", "0")
+    old = _self40(capi, qkv, b, n, heads)
+    ref = ref_self_attention(qkv, heads)
+    assert torch.isfinite(out).all()
+    assert relerr(out, ref) < TOL[dtype]
+    assert abs(relerr(out, ref) - relerr(old, ref)) < 0.1 * TOL[dtype]       # the same precision as the kernel it replaces ...
+    assert not torch.equal(out, old) or n < 1024                               # ... which is another kernel (the switch works)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,b,heads,mode", [(1024, 16, 8, 0), (2304, 8, 8, 0), (1024, 33, 4, 0), (1024, 16, 8, 1), (1024, 16, 8, 2)])
+def test_self_attention_d80_persistent_kernel(capi, dtype, n, b, heads, mode, monkeypatch):
+    """The same kernel at head_dim 80 (two query blocks per wave, items of 256 queries; N = 2304 is the 768^2 image's level): even and uneven item counts, both item orders,
+    the prompt-to-prompt / MasaCtrl row couplings (n_img = 4).  Against the fp32 reference and the kernel it replaces (ETAINV_A80_PERSIST=0)."""
+    d, n_img = 80, 4 if mode else 1
+    qkv = rnd(b, n, 3 * heads * d, seed=n + b + mode, dtype=dtype)
+    out = _self40(capi, qkv, b, n, heads, mode, n_img, d)
+    monkeypatch.setenv("ETAINV_A80_PERSIST", "0")
+    old = _self40(capi, qkv, b, n, heads, mode, n_img, d)
+    ident = torch.arange(b)
+    qm, km, vm = ident.clone(), ident.clone(), ident.clone()
+    for img in range(n_img if mode else 0):
+        u_s, u_t, c_s, c_t = img, n_img + img, 2 * n_img + img, 3 * n_img + img
+        if mode == 1:
+            qm[c_t], km[c_t] = c_s, c_s
+        else:
+            km[u_t], vm[u_t], km[c_t], vm[c_t] = u_s, u_s, c_s, c_s
+    ref = ref_self_attention(qkv, heads, qm, km, vm)
+    assert torch.isfinite(out).all()
+    assert relerr(out, ref) < TOL[dtype]
+    assert abs(relerr(out, ref) - relerr(old, ref)) < 0.1 * TOL[dtype]
+    assert not torch.equal(out, old)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_self_attention_d40_persistent_kernel_exact_pass(capi, dtype):
+    """The four regimes of test_self_attention_d40_speculative_maximum inside a 16-row launch of the persistent kernel: an item whose denominators overflow (fp16,
+    row 2) is repeated with the running maximum INSIDE the item loop, and the block then restarts its K / V stream for the next item."""
+    b, heads, n, d = 16, 8, 2048, 40
+    qkv = rnd(b, n, 3 * heads * d, seed=321, dtype=dtype)
+    q, k = qkv[..., : heads * d], qkv[..., heads * d: 2 * heads * d]
+    sc = 1.0 / (d ** 0.5)
+    def boost(row, head, key, query, log2_gain):
+        qv = q[row, query, head * d:(head + 1) * d].float()
+        t = (log2_gain * 0.6931 + 6.0) / (float(qv @ qv) * sc)
+        k[row, key, head * d:(head + 1) * d] = (qv * t).to(dtype)
+    for i, (key, g) in enumerate([(700, 6), (1300, 9), (2000, 12), (1999, 8)]):
+        boost(1, i % heads, key, 64 * i + 7, g)
+    for row, head, key, query in [(2, 3, 1500, 300), (7, 0, 100, 1999), (15, 7, 2047, 0)]:   # fp16: three items (first, middle, last query block) take the exact pass
+        boost(row, head, key, query, 40)
+    k[3, :64] = (k[3, :64] * 0.02).to(dtype)
+    q[3] = (q[3] * 3).to(dtype)
+    out = _self40(capi, qkv, b, n, heads)
+    ref = ref_self_attention(qkv, heads)
+    assert torch.isfinite(out).all()
+    for row in range(b):
+        assert relerr(out[row], ref[row]) < 1.5 * TOL[dtype], row
+    for row, head, query in [(2, 3, 300), (7, 0, 1999), (15, 7, 0)]:
+        assert relerr(out[row, query, head * d:(head + 1) * d], ref[row, query, head * d:(head + 1) * d]) < 2 * TOL[dtype], (row, head, query)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_self_attention_d40_persistent_kernel_remaps(capi, mode, dtype):
+    """prompt-to-prompt self-replace (mode 1) and MasaCtrl (mode 2) row couplings through the persistent kernel's item decoder (n_img = 4: 16 rows, 512 items)"""
+    n_img, heads, n = 4, 8, 2048
+    b = 4 * n_img
+    qkv = rnd(b, n, 3 * heads * 40, seed=5 + mode, dtype=dtype)
+    out = _self40(capi, qkv, b, n, heads, mode, n_img)
+    ident = torch.arange(b)
+    qm, km, vm = ident.clone(), ident.clone(), ident.clone()
+    for img in range(n_img):
+        u_s, u_t, c_s, c_t = img, n_img + img, 2 * n_img + img, 3 * n_img + img
+        if mode == 1:
+            qm[c_t], km[c_t] = c_s, c_s
+        else:
+            km[u_t], vm[u_t], km[c_t], vm[c_t] = u_s, u_s, c_s, c_s
+    assert relerr(out, ref_self_attention(qkv, heads, qm, km, vm)) < TOL[dtype]
 
 
 @pytest.mark.parametrize("mode", [1, 2])

@@ -1,3 +1,4 @@
+import os
 #!/usr/bin/env python3
 """Micro-benchmark of the hot kernels at the shapes of one UNet call (rows = UNet batch rows).  GPU box only.
     python tools/bench_ops.py [--rows 64] [--dtype bf16]"""
@@ -11,7 +12,7 @@ import torch  # noqa: E402
 from etainv import _capi  # noqa: E402
 
 
-def timeit(fn, iters=10, warm=3):
+def timeit(fn, iters=int(os.environ.get("ETAINV_BENCH_ITERS", "10")), warm=3):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
