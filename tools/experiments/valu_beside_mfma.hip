@@ -1,6 +1,7 @@
 // What one wave per SIMD pays for VALU instructions issued between its own MFMAs (gfx950; block of 256 threads per CU, 512 registers per wave).
 //   hipcc --offload-arch=gfx950 -O3 -o valu_beside_mfma tools/experiments/valu_beside_mfma.hip && ./valu_beside_mfma
-// Each mode: 8 x (one v_mfma_f32_32x32x16_bf16 on alternating accumulators + the listed independent VALU instructions); s_memtime ticks per MFMA.
+// Each mode: 8 x (one v_mfma_f32_32x32x16_bf16 on alternating accumulators + the listed independent VALU instructions); s_memtime (shader cycles) per MFMA.
+// Measured: profiles/r06_attention_persistent.log, section 3.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -65,7 +66,7 @@ void run(const char* name) {
   hipMemcpy(h.data(), cyc, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
   double sum = 0;
   for (auto v : h) sum += v;
-  printf("%-58s %7.2f ticks per group of 8\n", name, sum / h.size() / iters / 8);
+  printf("%-58s %7.2f cycles per MFMA (modes without an MFMA: per 8 instructions)\n", name, sum / h.size() / iters / 8);
   hipFree(out);
   hipFree(cyc);
 }
