@@ -1588,7 +1588,11 @@ static int launch_cross_t(const void* q, const void* kv, void* out, int b, const
     // (round 6, profiles/r06_cross_attention_xcd_heads_ab.log; ETAINV_CROSS_BLOCKS overrides the target)
     static const int target_env = getenv("ETAINV_CROSS_BLOCKS") ? std::max(64, atoi(getenv("ETAINV_CROSS_BLOCKS"))) : 0;
     const int target = target_env ? target_env : p.N >= 2048 ? (edit ? 2048 : 6144) : 1024;   // (the edit launch stages two key sets and its tables: fewer, longer blocks at every N)
-    const int gx = std::max(1, std::min(nqb, cdiv(target, rows * p.heads)));
+    // ... and a cap by token count, from a sweep of 1 .. 32 blocks per (row, head) at 32 / 64 / 96 / 128 rows, 300 launches each (profiles/r06_cross_attention_blocks_sweep.log): N = 256
+    // (head_dim 160) wants ONE block at every row count (0.021 / 0.040 / 0.059 ms against 0.028 / 0.053 / 0.079 with two), N = 1024 at most two, N = 4096 at most eight (32 rows: 0.052 against
+    // 0.064 ms with 24; the other row counts unchanged)
+    const int cap = target_env ? nqb : p.N <= 256 ? 1 : p.N <= 1024 ? 2 : p.N <= 4096 ? 8 : nqb;
+    const int gx = std::max(1, std::min(std::min(nqb, cap), cdiv(target, rows * p.heads)));
     const bool xcd_heads = env_flag("ETAINV_CROSS_XCD", true);   // (read per launch: tests/test_kernels_gpu.py compares the two placements in one process)
     CrossParams pl = p;
     dim3 grid(gx, p.heads, rows);
